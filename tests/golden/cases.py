@@ -1,0 +1,155 @@
+"""Seeded input generators shared by make_golden.py (which runs the reference on them, in the build
+container only) and the parity tests (which regenerate the same inputs on the GPU box).
+
+Fixtures store the reference's OUTPUTS plus a checksum of the inputs, never reference code.
+Input distributions follow SURVEY.md 8(d): u ~ N(0,1), delta_raw ~ N(0,0.5^2), A = -(1..N) times a
+"trained-like" jitter, B,C,z ~ N(0,1), D ~ 1, dt_bias = softplus^-1(logU[1e-3,1e-1]) (MS:104-109).
+"""
+import numpy as np
+
+# (name, batch, dim, len, dstate, has_z, has_D, has_bias, softplus)
+SCAN_CASES = [
+    ("l1", 2, 8, 1, 16, True, True, True, True),
+    ("l64", 2, 16, 64, 16, True, True, True, True),
+    ("l65", 2, 16, 65, 16, True, True, True, True),
+    ("l65_plain", 2, 16, 65, 16, False, False, False, False),
+    ("l65_noz", 2, 16, 65, 16, False, True, True, True),
+    ("l65_nod", 2, 16, 65, 16, True, False, False, True),
+    ("l513", 1, 8, 513, 16, True, True, True, True),
+    ("l2049", 1, 4, 2049, 16, True, True, True, True),
+    ("l130_n4", 2, 8, 130, 4, True, True, True, True),
+    ("l577_n8", 1, 6, 577, 8, True, True, True, True),
+]
+
+# (name, batch, dim, len, width, has_bias)
+CONV_CASES = [
+    ("l1", 2, 8, 1, 4, True),
+    ("l3", 2, 8, 3, 4, True),
+    ("l65", 2, 8, 65, 4, True),
+    ("l513", 1, 16, 513, 4, True),
+    ("l65_nobias", 2, 8, 65, 4, False),
+    ("l70_w3", 1, 4, 70, 3, True),
+]
+
+# (name, rows(list shape), cols, has_residual, prenorm)
+NORM_CASES = [
+    ("r130_c192_res_pre", (2, 65), 192, True, True),
+    ("r130_c192_nores_pre", (2, 65), 192, False, True),
+    ("r33_c768_res", (1, 33), 768, True, False),
+    ("r7_c100_res_pre", (7,), 100, True, True),
+]
+
+# (name, mode, batch, d_model, len)      mode: v1 (Fo-Bi), v2 (Bi-Bi), none (Fo-Fo)
+INNER_CASES = [
+    ("v1_d16_l65", "v1", 2, 16, 65),
+    ("v1_d16_l513", "v1", 2, 16, 513),
+    ("v1_d64_l65", "v1", 2, 64, 65),
+    ("none_d16_l65", "none", 2, 16, 65),
+    ("v2_d16_l65", "v2", 2, 16, 65),
+    ("v2_d64_l130", "v2", 1, 64, 130),
+]
+
+
+def _rng(tag):
+    seed = int.from_bytes(tag.encode(), "little") % (2 ** 31 - 1)
+    return np.random.default_rng(seed)
+
+
+def checksum(arrs):
+    """Order-dependent fp64 checksum of a dict of arrays (guards against generator drift)."""
+    tot = 0.0
+    for i, k in enumerate(sorted(arrs)):
+        a = arrs[k]
+        if a is None:
+            continue
+        a = np.asarray(a, np.float64).ravel()
+        tot += float((a * np.cos(np.arange(a.size) * 0.37 + i)).sum())
+    return np.float64(tot)
+
+
+def dt_bias_init(rng, dim, dt_min=1e-3, dt_max=1e-1):
+    dt = np.exp(rng.random(dim) * (np.log(dt_max) - np.log(dt_min)) + np.log(dt_min)).clip(min=1e-4)
+    return (dt + np.log(-np.expm1(-dt))).astype(np.float32)
+
+
+def scan_inputs(name, batch, dim, length, dstate, has_z, has_D, has_bias, softplus):
+    r = _rng("scan_" + name)
+    f = np.float32
+    A = -(np.arange(1, dstate + 1, dtype=f)[None, :] * np.exp(r.normal(0, 0.1, (dim, dstate)))).astype(f)
+    d = dict(
+        u=r.normal(0, 1, (batch, dim, length)).astype(f),
+        delta=(r.normal(0, 0.5, (batch, dim, length)) if softplus
+               else np.abs(r.normal(0, 0.05, (batch, dim, length))) + 1e-3).astype(f),
+        A=A,
+        B=r.normal(0, 1, (batch, dstate, length)).astype(f),
+        C=r.normal(0, 1, (batch, dstate, length)).astype(f),
+        D=(1.0 + r.normal(0, 0.1, dim)).astype(f) if has_D else None,
+        z=r.normal(0, 1, (batch, dim, length)).astype(f) if has_z else None,
+        delta_bias=dt_bias_init(r, dim) if has_bias else None,
+        dout=r.normal(0, 1, (batch, dim, length)).astype(f),
+    )
+    if softplus and has_bias:
+        # exercise the softplus linear branch (x > 20) and a very negative input
+        d["delta"][0, 0, 0] = 25.0
+        if length > 2:
+            d["delta"][-1, -1, 2] = -12.0
+    return d
+
+
+def conv_inputs(name, batch, dim, length, width, has_bias):
+    r = _rng("conv_" + name)
+    f = np.float32
+    return dict(
+        x=r.normal(0, 1, (batch, dim, length)).astype(f),
+        weight=r.normal(0, 0.5, (dim, width)).astype(f),
+        bias=r.normal(0, 0.2, dim).astype(f) if has_bias else None,
+        dout=r.normal(0, 1, (batch, dim, length)).astype(f),
+    )
+
+
+def norm_inputs(name, lead, cols, has_res, prenorm):
+    r = _rng("norm_" + name)
+    f = np.float32
+    return dict(
+        x=r.normal(0, 1, lead + (cols,)).astype(f),
+        residual=r.normal(0, 2, lead + (cols,)).astype(f) if has_res else None,
+        weight=(1 + r.normal(0, 0.2, cols)).astype(f),
+        dy=r.normal(0, 1, lead + (cols,)).astype(f),
+        dres=r.normal(0, 1, lead + (cols,)).astype(f) if prenorm else None,
+    )
+
+
+def inner_params(r, d_model, d_state=16, d_conv=4, expand=2, v2=False):
+    """Parameter tensors with the shapes of Mamba.__init__ (MS:74-167), trained-like values."""
+    f = np.float32
+    E = expand * d_model
+    R = -(-d_model // 16)
+    p = dict(
+        conv_w=r.normal(0, 0.4, (E, 1, d_conv)).astype(f),
+        conv_b=r.normal(0, 0.2, E).astype(f),
+        x_proj_w=(r.normal(0, 1, (R + 2 * d_state, E)) / np.sqrt(E)).astype(f),
+        dt_proj_w=r.uniform(-R ** -0.5, R ** -0.5, (E, R)).astype(f),
+        dt_bias=dt_bias_init(r, E),
+        A=-(np.arange(1, d_state + 1, dtype=f)[None, :] * np.exp(r.normal(0, 0.1, (E, d_state)))).astype(f),
+        D=(1.0 + r.normal(0, 0.1, E)).astype(f),
+        out_proj_w=(r.normal(0, 1, (d_model, E)) / np.sqrt(E)).astype(f),
+    )
+    p["A_b"] = -(np.arange(1, d_state + 1, dtype=f)[None, :] * np.exp(r.normal(0, 0.1, (E, d_state)))).astype(f)
+    if v2:
+        p["conv_w_b"] = r.normal(0, 0.4, (E, 1, d_conv)).astype(f)
+        p["conv_b_b"] = r.normal(0, 0.2, E).astype(f)
+        p["x_proj_w_b"] = (r.normal(0, 1, (R + 2 * d_state, E)) / np.sqrt(E)).astype(f)
+        p["dt_proj_w_b"] = r.uniform(-R ** -0.5, R ** -0.5, (E, R)).astype(f)
+        p["dt_bias_b"] = dt_bias_init(r, E)
+        p["D_b"] = (1.0 + r.normal(0, 0.1, E)).astype(f)
+    return p
+
+
+def inner_inputs(name, mode, batch, d_model, length):
+    r = _rng("inner_" + name)
+    f = np.float32
+    p = inner_params(r, d_model, v2=(mode == "v2"))
+    E = 2 * d_model
+    p["xz"] = r.normal(0, 1, (batch, 2 * E, length)).astype(f)
+    p["dout"] = r.normal(0, 1, (batch, length, d_model)).astype(f)
+    return p

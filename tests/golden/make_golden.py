@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own pure-PyTorch functions on CPU.
+
+Runs only in the build container (needs /root/reference; no-op elsewhere).  Nothing from the
+reference is copied: the fixtures hold the outputs of
+  selective_scan_ref      (SSI:86-152)  + autograd grads
+  MS:272 conv expression  (act(conv1d(x)[..., :L])) + autograd grads
+  rms_norm_ref            (LN:35-48, upcast=True) + autograd grads
+  mamba_inner_ref / bimamba_inner_ref (SSI:636-709) and the v2 composition of MS:214-246 + grads
+for the seeded inputs defined in cases.py, plus an input checksum.
+
+Import recipe: the CUDA extension modules the reference imports at module scope
+(causal_conv1d, causal_conv1d_cuda, selective_scan_cuda) are absent here, so empty stand-in MODULE
+OBJECTS are registered in sys.modules for the duration of this script -- they provide no arithmetic;
+every number written below comes from the reference's own *_ref code paths.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.path.insert(0, HERE)
+import cases  # noqa: E402
+
+
+def import_reference():
+    import importlib.machinery
+    import torch
+    import torch.nn.functional as F
+
+    for name in ("causal_conv1d_cuda", "selective_scan_cuda"):
+        sys.modules[name] = types.ModuleType(name)
+    cc = types.ModuleType("causal_conv1d")
+    cc.causal_conv1d_fn = None
+    cc.causal_conv1d_update = None
+    sys.modules["causal_conv1d"] = cc
+    # namespace stub so mamba_ssm/__init__.py (which pulls transformers-era names) is skipped
+    pkg = types.ModuleType("mamba_ssm")
+    pkg.__path__ = [os.path.join(REF, "vim-mamba_ssm", "mamba_ssm")]
+    pkg.__spec__ = importlib.machinery.ModuleSpec("mamba_ssm", None, is_package=True)
+    sys.modules["mamba_ssm"] = pkg
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    import mamba_ssm.ops.triton.layernorm as ln
+
+    def conv_fn(x, weight, bias=None, activation=None):
+        # the reference's own non-fused expression, MS:272: act(conv1d(x)[..., :seqlen])
+        w = weight.shape[-1]
+        y = F.conv1d(x, weight.unsqueeze(1), bias, padding=w - 1, groups=x.shape[1])[..., : x.shape[-1]]
+        return F.silu(y) if activation in ("silu", "swish") else y
+
+    ssi.causal_conv1d_fn = conv_fn
+    ssi.selective_scan_fn = ssi.selective_scan_ref
+    return torch, ssi, ln, conv_fn
+
+
+def T(torch, a, grad=True, dtype=None):
+    if a is None:
+        return None
+    t = torch.tensor(np.asarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.requires_grad_(grad)
+
+
+def npy(t):
+    return None if t is None else t.detach().float().cpu().numpy()
+
+
+def main():
+    if not os.path.isdir(REF):
+        print("reference not present; nothing to do")
+        return
+    torch, ssi, ln, conv_fn = import_reference()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    # ---------------------------------------------------------------- selective_scan_ref
+    out = {}
+    for case in cases.SCAN_CASES:
+        name = case[0]
+        has_z, has_D, has_bias, softplus = case[5:]
+        d = cases.scan_inputs(*case)
+        for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            if dt_name == "bf16" and name not in ("l65", "l513"):
+                continue
+            act = lambda a: T(torch, a, True, dt)
+            u, delta, z = act(d["u"]), act(d["delta"]), act(d["z"])
+            Bm, Cm = act(d["B"][:, None]), act(d["C"][:, None])       # (B,1,N,L) as the fused path passes them
+            A, D, bias = T(torch, d["A"]), T(torch, d["D"]), T(torch, d["delta_bias"])
+            o, last = ssi.selective_scan_ref(u, delta, A, Bm, Cm, D, z, bias, softplus, True)
+            (o.float() * torch.tensor(d["dout"])).sum().backward()
+            pre = f"{name}.{dt_name}."
+            out[pre + "out"] = npy(o)
+            out[pre + "last_state"] = npy(last)
+            for k, t in (("du", u), ("ddelta", delta), ("dA", A), ("dB", Bm), ("dC", Cm), ("dD", D),
+                         ("dz", z), ("ddelta_bias", bias)):
+                if t is not None:
+                    g = npy(t.grad)
+                    out[pre + k] = g[:, 0] if k in ("dB", "dC") else g
+            if dt_name == "f32":
+                out[name + ".checksum"] = cases.checksum(d)
+                # also pin the 3-D B/C entry (SSI:125-126) and the flipped form used for the reverse
+                # direction (SSI:707-708) so the oracle's `reverse` flag is pinned to reference output
+                with torch.no_grad():
+                    fl = lambda a: None if a is None else torch.tensor(a).flip([-1])
+                    ob = ssi.selective_scan_ref(fl(d["u"]), fl(d["delta"]), torch.tensor(d["A"]), fl(d["B"]),
+                                                fl(d["C"]), T(torch, d["D"], False), fl(d["z"]),
+                                                T(torch, d["delta_bias"], False), softplus).flip([-1])
+                out[name + ".f32.out_reverse"] = npy(ob)
+    np.savez_compressed(os.path.join(HERE, "scan.npz"), **out)
+    print("scan.npz", len(out))
+
+    # ---------------------------------------------------------------- conv (MS:272)
+    out = {}
+    for case in cases.CONV_CASES:
+        name = case[0]
+        d = cases.conv_inputs(*case)
+        x, w, b = T(torch, d["x"]), T(torch, d["weight"]), T(torch, d["bias"])
+        y = conv_fn(x, w, b, "silu")
+        (y * torch.tensor(d["dout"])).sum().backward()
+        out[name + ".y"] = npy(y)
+        out[name + ".dx"], out[name + ".dweight"] = npy(x.grad), npy(w.grad)
+        if b is not None:
+            out[name + ".dbias"] = npy(b.grad)
+        with torch.no_grad():
+            out[name + ".y_nosilu"] = npy(conv_fn(x, w, b, None))
+            # anti-causal form = conv on the flipped sequence, flipped back (MS:229-246)
+            out[name + ".y_reverse"] = npy(conv_fn(x.flip([-1]), w, b, "silu").flip([-1]))
+        out[name + ".checksum"] = cases.checksum(d)
+    np.savez_compressed(os.path.join(HERE, "conv.npz"), **out)
+    print("conv.npz", len(out))
+
+    # ---------------------------------------------------------------- rms_norm_ref (LN:35-48)
+    out = {}
+    for case in cases.NORM_CASES:
+        name, lead, cols, has_res, prenorm = case
+        d = cases.norm_inputs(*case)
+        x, res, w = T(torch, d["x"]), T(torch, d["residual"]), T(torch, d["weight"])
+        r = ln.rms_norm_ref(x, w, None, residual=res, eps=1e-5, prenorm=prenorm, upcast=True)
+        y, res_out = (r if prenorm else (r, None))
+        loss = (y * torch.tensor(d["dy"])).sum()
+        if prenorm:
+            loss = loss + (res_out * torch.tensor(d["dres"])).sum()
+        loss.backward()
+        out[name + ".y"] = npy(y)
+        if prenorm:
+            out[name + ".residual_out"] = npy(res_out)
+        out[name + ".dx"], out[name + ".dweight"] = npy(x.grad), npy(w.grad)
+        if has_res:
+            out[name + ".dresidual"] = npy(res.grad)
+        out[name + ".checksum"] = cases.checksum(d)
+    np.savez_compressed(os.path.join(HERE, "norm.npz"), **out)
+    print("norm.npz", len(out))
+
+    # ---------------------------------------------------------------- inner blocks
+    out = {}
+    for case in cases.INNER_CASES:
+        name, mode, batch, d_model, length = case
+        p = cases.inner_inputs(*case)
+        t = {k: T(torch, v) for k, v in p.items() if k != "dout"}
+        if mode == "v1":
+            o = ssi.bimamba_inner_ref(t["xz"], t["conv_w"], t["conv_b"], t["x_proj_w"], t["dt_proj_w"],
+                                      t["out_proj_w"], None, t["A"], t["A_b"], None, None, t["D"],
+                                      delta_bias=t["dt_bias"], delta_softplus=True)
+        elif mode == "none":
+            o = ssi.mamba_inner_ref(t["xz"], t["conv_w"], t["conv_b"], t["x_proj_w"], t["dt_proj_w"],
+                                    t["out_proj_w"], None, t["A"], None, None, t["D"],
+                                    delta_bias=t["dt_bias"], delta_softplus=True)
+        else:  # v2 = MS:214-246 with if_devide_out=True, built from the reference's mamba_inner_ref
+            E = 2 * d_model
+            eye = torch.eye(E)     # out_proj = identity turns mamba_inner_ref into its no-out-proj form
+            of = ssi.mamba_inner_ref(t["xz"], t["conv_w"], t["conv_b"], t["x_proj_w"], t["dt_proj_w"],
+                                     eye, None, t["A"], None, None, t["D"], delta_bias=t["dt_bias"],
+                                     delta_softplus=True)          # (B, L, E)
+            ob = ssi.mamba_inner_ref(t["xz"].flip([-1]), t["conv_w_b"], t["conv_b_b"], t["x_proj_w_b"],
+                                     t["dt_proj_w_b"], eye, None, t["A_b"], None, None, t["D_b"],
+                                     delta_bias=t["dt_bias_b"], delta_softplus=True)
+            o = torch.nn.functional.linear((of + ob.flip([1])) / 2, t["out_proj_w"], None)
+        (o * torch.tensor(p["dout"])).sum().backward()
+        out[name + ".out"] = npy(o)
+        for k, v in t.items():
+            if v.grad is not None:
+                out[name + ".d_" + k] = npy(v.grad)
+        out[name + ".checksum"] = cases.checksum(p)
+    np.savez_compressed(os.path.join(HERE, "inner.npz"), **out)
+    print("inner.npz", len(out))
+
+
+if __name__ == "__main__":
+    main()
