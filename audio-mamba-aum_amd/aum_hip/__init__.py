@@ -1,0 +1,346 @@
+"""aum_hip -- ctypes binding of libaum_hip.so (the C ABI in include/aum_hip.h) for PyTorch-ROCm tensors.
+
+PyTorch is plumbing here (device memory, streams); every op below enqueues hand-written gfx950 kernels on the
+current HIP stream through the C ABI.  There is NO fallback: if the shared library is missing the import of
+the product path fails loudly (`python audio-mamba-aum_amd/csrc/build.py` builds it with hipcc).
+
+The functions mirror the reference's extension modules:
+  scan_fwd / scan_bwd          <- selective_scan_cuda.fwd / .bwd   (SSI:37, 62-65, 499-505, 541-552)
+  conv1d_fwd / conv1d_bwd      <- causal_conv1d_cuda.causal_conv1d_fwd / _bwd (SSI:463, 594-596)
+  rmsnorm_fwd / rmsnorm_bwd    <- _layer_norm_fwd / _layer_norm_bwd (LN:123-177, 293-377)
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libaum_hip.so")
+
+AUM_F32, AUM_BF16, AUM_F16 = 0, 1, 2
+SCAN_SOFTPLUS, SCAN_REVERSE = 1, 2
+CONV_SILU, CONV_REVERSE = 1, 2
+_DT = {torch.float32: AUM_F32, torch.bfloat16: AUM_BF16, torch.float16: AUM_F16}
+_ERR = {-1: "AUM_E_NULL", -2: "AUM_E_SHAPE", -3: "AUM_E_DTYPE", -4: "AUM_E_UNSUPPORTED", -5: "AUM_E_WORKSPACE",
+        -6: "AUM_E_LAUNCH"}
+
+_i64, _i32, _u32, _vp, _fp = C.c_int64, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p
+
+
+class ScanFwdArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("u", "delta", "z", "B", "C", "A", "A_b", "D", "delta_bias", "out", "out_pre",
+                                    "last_state", "workspace")]
+                + [(n, _i64) for n in ("workspace_bytes", "u_bs", "u_ds", "delta_bs", "delta_ds", "z_bs", "z_ds", "B_bs",
+                                       "B_ns", "C_bs", "C_ns", "out_bs", "out_ds")]
+                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32)])
+
+
+class ScanBwdArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("u", "delta", "z", "B", "C", "dout", "out_pre", "A", "A_b", "D", "delta_bias", "du",
+                                    "ddelta", "dz", "dA", "dA_b", "dB", "dC", "dD", "ddelta_bias", "workspace")]
+                + [(n, _i64) for n in ("workspace_bytes", "u_bs", "u_ds", "delta_bs", "delta_ds", "z_bs", "z_ds", "B_bs",
+                                       "B_ns", "C_bs", "C_ns", "dout_bs", "dout_ds", "out_bs", "out_ds", "du_bs", "du_ds",
+                                       "ddelta_bs", "ddelta_ds", "dz_bs", "dz_ds", "dB_bs", "dB_ns", "dC_bs", "dC_ns")]
+                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32)])
+
+
+class ConvArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("x", "dy", "weight", "bias", "y", "dx", "dweight", "dbias")]
+                + [(n, _i64) for n in ("x_bs", "x_ds", "y_bs", "y_ds", "dy_bs", "dy_ds", "dx_bs", "dx_ds")]
+                + [(n, _i32) for n in ("batch", "dim", "len", "width", "dtype")] + [("flags", _u32)])
+
+
+class NormArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("x", "residual", "dy", "dresidual_out", "weight", "rstd_in", "y", "residual_out",
+                                    "dx", "dresidual_in", "rstd_out", "dweight_partial")]
+                + [(n, _i64) for n in ("row_stride_x", "row_stride_res", "row_stride_y", "row_stride_res_out",
+                                       "row_stride_dy", "row_stride_dres_out", "row_stride_dx", "row_stride_dres_in")]
+                + [("eps", C.c_float)] + [(n, _i32) for n in ("rows", "cols", "x_dtype", "res_dtype", "y_dtype")]
+                + [("flags", _u32)])
+
+
+EXPORTS = ["aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
+           "aum_selective_scan_workspace_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
+           "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy"]
+
+
+class Lib:
+    """A loaded C-ABI library.  `host=True` marks the tests-only lane-array build that takes host pointers."""
+
+    def __init__(self, path, host=False):
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: the HIP extension is not built.  Run `python audio-mamba-aum_amd/csrc/build.py` "
+                "(hipcc, gfx950).  There is no CPU fallback on the product path.")
+        self.path, self.host = path, host
+        self.c = C.CDLL(path)
+        for name in EXPORTS:
+            getattr(self.c, name)   # AttributeError if a declared symbol is missing
+        self.c.aum_selective_scan_workspace_bytes.restype = _i64
+        self.c.aum_selective_scan_workspace_bytes.argtypes = [_i32] * 6
+        for n in ("aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd",
+                  "aum_rmsnorm_fwd", "aum_rmsnorm_bwd"):
+            getattr(self.c, n).argtypes = [_vp, _vp]
+        self.c.aum_selftest_wave_scan.argtypes = [_vp, _vp, C.c_int, _vp]
+        self.c.aum_hbm_copy.argtypes = [_vp, _vp, _i64, _vp]
+        assert self.c.aum_abi_version() == 1
+        self.max_single_pass_len = int(self.c.aum_scan_max_single_pass_len())
+
+    def stream(self, t):
+        if self.host:
+            return None
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    def check_tensor(self, t):
+        if t is None:
+            return
+        if self.host:
+            if t.device.type != "cpu":
+                raise RuntimeError("lane-array (test) library takes host tensors")
+        elif t.device.type != "cuda":
+            raise RuntimeError("libaum_hip.so needs device (HIP) tensors; there is no CPU path in the product library")
+
+
+_product = None
+
+
+def get():
+    """The product library (libaum_hip.so).  Raises ImportError if it has not been built."""
+    global _product
+    if _product is None:
+        _product = Lib(_SO, host=False)
+    return _product
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _unit(t, name):
+    if t is not None and t.stride(-1) != 1 and t.shape[-1] != 1:
+        raise RuntimeError(f"{name}: the time axis must be unit-stride (SSI:19-30)")
+
+
+def _f32c(t):
+    return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+def _bc3(t):
+    """(batch, 1, dstate, len) -> (batch, dstate, len) view (the G=1 case, SSI:31-36)."""
+    if t.dim() == 4:
+        if t.shape[1] != 1:
+            raise RuntimeError("only one B/C group is supported (G=1), as used by Mamba (SSI:473-493)")
+        t = t[:, 0]
+    return t
+
+
+def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, reverse=False, A_b=None,
+             want_out_pre=False, want_last_state=False, lib=None):
+    """selective_scan_cuda.fwd.  Returns (out, out_pre|None, last_state|None).  A_b != None: fused bidirectional."""
+    lib = lib or get()
+    B, C = _bc3(B), _bc3(C)
+    for n, t in (("u", u), ("delta", delta), ("z", z), ("B", B), ("C", C)):
+        _unit(t, n)
+        lib.check_tensor(t)
+    if u.dtype not in _DT or any(t is not None and t.dtype != u.dtype for t in (delta, z, B, C)):
+        raise RuntimeError("u, delta, z, B, C must share one dtype in {fp32, bf16, fp16}")
+    batch, dim, length = u.shape
+    dstate = A.shape[1]
+    if A.shape != (dim, dstate) or B.shape != (batch, dstate, length) or C.shape != B.shape:
+        raise RuntimeError("shape mismatch in selective scan arguments")
+    A, A_b, D, delta_bias = _f32c(A), _f32c(A_b), _f32c(D), _f32c(delta_bias)
+    out = torch.empty((batch, dim, length), dtype=u.dtype, device=u.device)
+    out_pre = torch.empty_like(out) if want_out_pre else None
+    last = torch.empty((batch, dim, dstate), dtype=torch.float32, device=u.device) if want_last_state else None
+    a = ScanFwdArgs()
+    a.u, a.delta, a.z, a.B, a.C = _ptr(u), _ptr(delta), _ptr(z), _ptr(B), _ptr(C)
+    a.A, a.A_b, a.D, a.delta_bias = _ptr(A), _ptr(A_b), _ptr(D), _ptr(delta_bias)
+    a.out, a.out_pre, a.last_state = _ptr(out), _ptr(out_pre), _ptr(last)
+    a.u_bs, a.u_ds = u.stride(0), u.stride(1)
+    a.delta_bs, a.delta_ds = delta.stride(0), delta.stride(1)
+    if z is not None:
+        a.z_bs, a.z_ds = z.stride(0), z.stride(1)
+    a.B_bs, a.B_ns = B.stride(0), B.stride(1)
+    a.C_bs, a.C_ns = C.stride(0), C.stride(1)
+    a.out_bs, a.out_ds = out.stride(0), out.stride(1)
+    a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
+    a.flags = (SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0)
+    _chk(lib.c.aum_selective_scan_fwd(C_byref(a), lib.stream(u)), "aum_selective_scan_fwd")
+    return out, out_pre, last
+
+
+def C_byref(s):
+    return C.cast(C.byref(s), C.c_void_p)
+
+
+def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=False, reverse=False, A_b=None,
+             dz_out=None, lib=None):
+    """selective_scan_cuda.bwd.  Returns dict(du, ddelta, dA, dA_b, dB, dC, dD, dz, ddelta_bias); dB/dC fp32
+    (batch, dstate, len).  dz_out: optional preallocated (possibly strided) tensor written in place (SSI:537-545)."""
+    lib = lib or get()
+    B, C = _bc3(B), _bc3(C)
+    for n, t in (("u", u), ("delta", delta), ("z", z), ("B", B), ("C", C), ("dout", dout), ("out_pre", out_pre)):
+        _unit(t, n)
+        lib.check_tensor(t)
+    batch, dim, length = u.shape
+    dstate = A.shape[1]
+    dev = u.device
+    A, A_b, D, delta_bias = _f32c(A), _f32c(A_b), _f32c(D), _f32c(delta_bias)
+    du = torch.empty((batch, dim, length), dtype=u.dtype, device=dev)
+    ddelta = torch.empty_like(du)
+    dz = None
+    if z is not None:
+        dz = dz_out if dz_out is not None else torch.empty_like(du)
+        _unit(dz, "dz")
+    f32 = dict(dtype=torch.float32, device=dev)
+    dA = torch.zeros((dim, dstate), **f32)
+    dA_b = torch.zeros((dim, dstate), **f32) if A_b is not None else None
+    dB = torch.zeros((batch, dstate, length), **f32)
+    dC = torch.zeros((batch, dstate, length), **f32)
+    dD = torch.zeros((dim,), **f32) if D is not None else None
+    dbias = torch.zeros((dim,), **f32) if delta_bias is not None else None
+    ws_bytes = int(lib.c.aum_selective_scan_workspace_bytes(batch, dim, length, dstate, int(A_b is not None), 1))
+    ws = torch.empty((max(ws_bytes, 4) // 4,), **f32) if ws_bytes else None
+    a = ScanBwdArgs()
+    a.u, a.delta, a.z, a.B, a.C, a.dout, a.out_pre = map(_ptr, (u, delta, z, B, C, dout, out_pre))
+    a.A, a.A_b, a.D, a.delta_bias = _ptr(A), _ptr(A_b), _ptr(D), _ptr(delta_bias)
+    a.du, a.ddelta, a.dz = _ptr(du), _ptr(ddelta), _ptr(dz)
+    a.dA, a.dA_b, a.dB, a.dC, a.dD, a.ddelta_bias = map(_ptr, (dA, dA_b, dB, dC, dD, dbias))
+    a.workspace, a.workspace_bytes = _ptr(ws), ws_bytes
+    a.u_bs, a.u_ds = u.stride(0), u.stride(1)
+    a.delta_bs, a.delta_ds = delta.stride(0), delta.stride(1)
+    if z is not None:
+        a.z_bs, a.z_ds = z.stride(0), z.stride(1)
+        a.out_bs, a.out_ds = out_pre.stride(0), out_pre.stride(1)
+        a.dz_bs, a.dz_ds = dz.stride(0), dz.stride(1)
+    a.B_bs, a.B_ns, a.C_bs, a.C_ns = B.stride(0), B.stride(1), C.stride(0), C.stride(1)
+    a.dout_bs, a.dout_ds = dout.stride(0), dout.stride(1)
+    a.du_bs, a.du_ds = du.stride(0), du.stride(1)
+    a.ddelta_bs, a.ddelta_ds = ddelta.stride(0), ddelta.stride(1)
+    a.dB_bs, a.dB_ns, a.dC_bs, a.dC_ns = dB.stride(0), dB.stride(1), dC.stride(0), dC.stride(1)
+    a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
+    a.flags = (SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0)
+    _chk(lib.c.aum_selective_scan_bwd(C_byref(a), lib.stream(u)), "aum_selective_scan_bwd")
+    return dict(du=du, ddelta=ddelta, dA=dA, dA_b=dA_b, dB=dB, dC=dC, dD=dD, dz=dz, ddelta_bias=dbias)
+
+
+def conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, lib=None):
+    """causal_conv1d_cuda.causal_conv1d_fwd(x, weight(dim,width), bias, None, silu) -> y (batch, dim, len) contiguous."""
+    lib = lib or get()
+    _unit(x, "x")
+    lib.check_tensor(x)
+    batch, dim, length = x.shape
+    weight = _f32c(weight.reshape(dim, -1))
+    bias = _f32c(bias)
+    y = torch.empty((batch, dim, length), dtype=x.dtype, device=x.device)
+    a = ConvArgs()
+    a.x, a.weight, a.bias, a.y = _ptr(x), _ptr(weight), _ptr(bias), _ptr(y)
+    a.x_bs, a.x_ds, a.y_bs, a.y_ds = x.stride(0), x.stride(1), y.stride(0), y.stride(1)
+    a.batch, a.dim, a.len, a.width, a.dtype = batch, dim, length, weight.shape[1], _DT[x.dtype]
+    a.flags = (CONV_SILU if silu else 0) | (CONV_REVERSE if reverse else 0)
+    _chk(lib.c.aum_causal_conv1d_fwd(C_byref(a), lib.stream(x)), "aum_causal_conv1d_fwd")
+    return y
+
+
+def conv1d_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, lib=None):
+    """causal_conv1d_cuda.causal_conv1d_bwd -> (dx, dweight(dim,width) fp32, dbias fp32|None); dx_out may be a
+    preallocated strided view written in place (SSI:594-596)."""
+    lib = lib or get()
+    _unit(x, "x")
+    _unit(dy, "dy")
+    lib.check_tensor(x)
+    lib.check_tensor(dy)
+    batch, dim, length = x.shape
+    weight = _f32c(weight.reshape(dim, -1))
+    bias = _f32c(bias)
+    dx = dx_out if dx_out is not None else torch.empty((batch, dim, length), dtype=x.dtype, device=x.device)
+    _unit(dx, "dx")
+    dw = torch.zeros_like(weight)
+    db = torch.zeros((dim,), dtype=torch.float32, device=x.device) if bias is not None else None
+    a = ConvArgs()
+    a.x, a.dy, a.weight, a.bias, a.dx, a.dweight, a.dbias = map(_ptr, (x, dy, weight, bias, dx, dw, db))
+    a.x_bs, a.x_ds, a.dy_bs, a.dy_ds = x.stride(0), x.stride(1), dy.stride(0), dy.stride(1)
+    a.dx_bs, a.dx_ds = dx.stride(0), dx.stride(1)
+    a.batch, a.dim, a.len, a.width, a.dtype = batch, dim, length, weight.shape[1], _DT[x.dtype]
+    a.flags = (CONV_SILU if silu else 0) | (CONV_REVERSE if reverse else 0)
+    _chk(lib.c.aum_causal_conv1d_bwd(C_byref(a), lib.stream(x)), "aum_causal_conv1d_bwd")
+    return dx, dw, db
+
+
+def rmsnorm_fwd(x, weight, residual=None, eps=1e-5, residual_dtype=None, lib=None):
+    """_layer_norm_fwd(is_rms_norm=True) (LN:123-177).  x: (rows, cols).  Returns (y, rstd, residual_out) where
+    residual_out is x itself when no new residual tensor is needed (LN:176-177)."""
+    lib = lib or get()
+    lib.check_tensor(x)
+    rows, cols = x.shape
+    assert x.stride(1) == 1
+    if residual is not None:
+        residual_dtype = residual.dtype
+        assert residual.stride(1) == 1 and residual.shape == x.shape
+    weight = _f32c(weight)
+    y = torch.empty_like(x, memory_format=torch.contiguous_format)
+    need_res_out = residual is not None or (residual_dtype is not None and residual_dtype != x.dtype)
+    res_out = torch.empty((rows, cols), dtype=residual_dtype, device=x.device) if need_res_out else None
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    a = NormArgs()
+    a.x, a.residual, a.weight, a.y, a.residual_out, a.rstd_out = map(_ptr, (x, residual, weight, y, res_out, rstd))
+    a.row_stride_x, a.row_stride_y = x.stride(0), y.stride(0)
+    if residual is not None:
+        a.row_stride_res = residual.stride(0)
+    if res_out is not None:
+        a.row_stride_res_out = res_out.stride(0)
+    a.eps, a.rows, a.cols = eps, rows, cols
+    a.x_dtype = a.y_dtype = _DT[x.dtype]
+    a.res_dtype = _DT[residual_dtype] if need_res_out else _DT[x.dtype]
+    _chk(lib.c.aum_rmsnorm_fwd(C_byref(a), lib.stream(x)), "aum_rmsnorm_fwd")
+    return y, rstd, (res_out if res_out is not None else x)
+
+
+def rmsnorm_bwd(dy, x_saved, weight, rstd, dresidual=None, has_residual=False, x_dtype=None, lib=None):
+    """_layer_norm_bwd(is_rms_norm=True) (LN:293-377).  x_saved = residual_out of the forward.  Returns
+    (dx [x_dtype], dweight fp32, dresidual_in | None)."""
+    lib = lib or get()
+    lib.check_tensor(dy)
+    rows, cols = x_saved.shape
+    x_dtype = x_dtype or x_saved.dtype
+    assert dy.stride(1) == 1 and x_saved.stride(1) == 1 and dy.dtype == x_dtype
+    weight = _f32c(weight)
+    dx = torch.empty((rows, cols), dtype=x_dtype, device=dy.device)
+    dres_in = torch.empty_like(x_saved) if (has_residual and x_dtype != x_saved.dtype) else None
+    n_part = int(lib.c.aum_rmsnorm_bwd_partials(rows))
+    dwp = torch.empty((n_part, cols), dtype=torch.float32, device=dy.device)
+    a = NormArgs()
+    a.x, a.dy, a.dresidual_out, a.weight, a.rstd_in = map(_ptr, (x_saved, dy, dresidual, weight, rstd))
+    a.dx, a.dresidual_in, a.dweight_partial = _ptr(dx), _ptr(dres_in), _ptr(dwp)
+    a.row_stride_x, a.row_stride_dy, a.row_stride_dx = x_saved.stride(0), dy.stride(0), dx.stride(0)
+    if dresidual is not None:
+        assert dresidual.dtype == x_saved.dtype and dresidual.stride(1) == 1
+        a.row_stride_dres_out = dresidual.stride(0)
+    if dres_in is not None:
+        a.row_stride_dres_in = dres_in.stride(0)
+    a.rows, a.cols = rows, cols
+    a.x_dtype = a.y_dtype = _DT[x_dtype]
+    a.res_dtype = _DT[x_saved.dtype]
+    _chk(lib.c.aum_rmsnorm_bwd(C_byref(a), lib.stream(dy)), "aum_rmsnorm_bwd")
+    dw = dwp.sum(0)
+    if has_residual and dres_in is None:
+        dres_in = dx
+    return dx, dw, dres_in
+
+
+def selftest_wave_scan(P, S, rev=False, lib=None):
+    lib = lib or get()
+    inp = torch.cat([P.float().reshape(64), S.float().reshape(64)]).contiguous()
+    out = torch.empty_like(inp)
+    _chk(lib.c.aum_selftest_wave_scan(_ptr(inp), _ptr(out), int(rev), lib.stream(inp)), "aum_selftest_wave_scan")
+    return out[:64], out[64:]
+
+
+def hbm_copy(src, dst, lib=None):
+    lib = lib or get()
+    _chk(lib.c.aum_hbm_copy(_ptr(src), _ptr(dst), src.numel() * src.element_size(), lib.stream(src)), "aum_hbm_copy")

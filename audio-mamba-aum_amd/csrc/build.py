@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Build libaum_hip.so for gfx950 with hipcc (no GPU needed to compile).  In-tree output so the .so
+travels with the gpurun snapshot:  audio-mamba-aum_amd/aum_hip/libaum_hip.so"""
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = os.path.join(os.path.dirname(HERE), "aum_hip")
+OBJ_DIR = os.path.join(HERE, "_obj")
+SRC = os.path.join(HERE, "aum_hip.hip")
+DEPS = ["aum_hip.hip", "aum_api.inc", "wave.h", "scan_kernels.h", "conv_norm_kernels.h",
+        os.path.join("..", "..", "include", "aum_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def _digest():
+    h = hashlib.sha256()
+    for d in DEPS:
+        with open(os.path.join(HERE, d), "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def parts():
+    out = []
+    for part in (1, 2):
+        for dt in (0, 1, 2):
+            out.append((f"scan_p{part}_d{dt}.o", [f"-DAUM_API_PART={part}", f"-DAUM_DTYPE_ONLY={dt}"]))
+    out.append(("api.o", ["-DAUM_API_PART=3"]))
+    return out
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(OUT_DIR, exist_ok=True)
+    so = os.path.join(OUT_DIR, "libaum_hip.so")
+    stamp = os.path.join(OBJ_DIR, "digest")
+    dig = _digest()
+    if not force and os.path.exists(so) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return so
+
+    def cc(item):
+        name, defs = item
+        cmd = [HIPCC] + FLAGS + defs + ["-c", SRC, "-o", os.path.join(OBJ_DIR, name)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return name, r.returncode, r.stdout + r.stderr
+
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+        res = list(ex.map(cc, parts()))
+    for name, rc, log in res:
+        if rc != 0:
+            sys.stderr.write(log)
+            raise RuntimeError(f"hipcc failed on {name}")
+        if verbose and log.strip():
+            print(log)
+    objs = [os.path.join(OBJ_DIR, n) for n, _ in parts()]
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs)
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return so
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,266 @@
+// wave.h -- the 64-lane wavefront programming layer every kernel in this library is written against.
+//
+// Each kernel body is ONE source, written as straight-line "per-lane" code over the types vf / vi / vm
+// and the free functions below.  It is compiled two ways:
+//
+//   * device build (hipcc --offload-arch=gfx950):  vf = float, vi = int, vm = bool; the functions map
+//     1:1 onto CDNA4 instructions (v_exp_f32, v_rcp_f32, DPP row_shr/row_shl/wave_shr, v_readlane_b32,
+//     ds_read/ds_write, global_atomic_add_f32 ...).  This is the product.
+//
+//   * lane-array build (-DAUM_EMU, host clang++):  vf = struct{float v[64]} etc. and every function
+//     applies the gfx950 semantics lane by lane.  It exists ONLY so tests/ can check a kernel's index
+//     arithmetic, tails, carries and reductions on a machine without a GPU (tests/emu).  It is never
+//     loaded by the product path (aum_hip/_lib.py loads libaum_hip.so or fails).
+//
+// All workgroups in this library are exactly one wavefront (64 threads): cross-lane traffic is DPP /
+// readlane / wave-synchronous LDS, never a multi-wave barrier.
+#pragma once
+#include <stdint.h>
+
+#ifdef AUM_EMU
+#include <cmath>
+#include <cstring>
+#define AUM_DEV inline
+#define AUM_UNROLL _Pragma("unroll")
+#else
+#include <hip/hip_runtime.h>
+#define AUM_DEV __device__ __forceinline__
+#define AUM_UNROLL _Pragma("unroll")
+#endif
+
+namespace aum {
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------------------------------------
+// Element types of the activation tensors.  fp32 internal math always (SSI:101-103).
+// ------------------------------------------------------------------------------------------------
+struct bf16_t { uint16_t bits; };
+struct f16_t { uint16_t bits; };
+
+AUM_DEV float bits_to_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+AUM_DEV uint32_t f32_to_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+AUM_DEV float elem_to_f32(float x) { return x; }
+AUM_DEV float elem_to_f32(bf16_t x) { return bits_to_f32(((uint32_t)x.bits) << 16); }
+AUM_DEV float elem_to_f32(f16_t x) { return (float)__builtin_bit_cast(_Float16, x.bits); }
+
+AUM_DEV void f32_to_elem(float f, float& o) { o = f; }
+AUM_DEV void f32_to_elem(float f, bf16_t& o) {  // round-to-nearest-even, NaN kept quiet
+    uint32_t u = f32_to_bits(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) { o.bits = (uint16_t)((u >> 16) | 0x40u); return; }
+    u += 0x7fffu + ((u >> 16) & 1u);
+    o.bits = (uint16_t)(u >> 16);
+}
+AUM_DEV void f32_to_elem(float f, f16_t& o) { o.bits = __builtin_bit_cast(uint16_t, (_Float16)f); }
+
+#ifndef AUM_EMU
+// =================================================================================================
+// Device backend: one lane per thread.
+// =================================================================================================
+using vf = float;
+using vi = int;
+using vm = bool;
+
+AUM_DEV vi lane_id() { return (int)threadIdx.x; }
+AUM_DEV vf splat(float x) { return x; }
+AUM_DEV vi spl_i(int x) { return x; }
+AUM_DEV vf vfma(vf a, vf b, vf c) { return __builtin_fmaf(a, b, c); }
+AUM_DEV vf vexp2(vf x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+AUM_DEV vf vlog2(vf x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
+AUM_DEV vf vrcp(vf x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32
+AUM_DEV vf vrsqrt(vf x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32
+AUM_DEV vf vdiv(vf a, vf b) { return a / b; }                  // IEEE division (correctly rounded)
+AUM_DEV vf vsqrt(vf x) { return __builtin_sqrtf(x); }
+AUM_DEV vf vmax(vf a, vf b) { return __builtin_fmaxf(a, b); }
+AUM_DEV vf vsel(vm m, vf a, vf b) { return m ? a : b; }
+AUM_DEV vi vsel_i(vm m, vi a, vi b) { return m ? a : b; }
+AUM_DEV bool any_lane(vm m) { return __any(m); }
+
+template <class T> AUM_DEV vf gload(const T* p, vi idx, vm m) { return m ? elem_to_f32(p[idx]) : 0.f; }
+template <class T> AUM_DEV void gstore(T* p, vi idx, vf v, vm m) { if (m) f32_to_elem(v, p[idx]); }
+AUM_DEV void gatomic_add(float* p, vi idx, vf v, vm m) { if (m) atomicAdd(p + idx, v); }
+// L1-bypassing accesses for scratch that this wave wrote earlier in the same launch
+AUM_DEV vf gload_coherent(const float* p, vi idx, vm m) {
+    return m ? __hip_atomic_load(p + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+}
+AUM_DEV void gstore_coherent(float* p, vi idx, vf v, vm m) {
+    if (m) __hip_atomic_store(p + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+AUM_DEV vf lds_read(const float* lds, vi idx) { return lds[idx]; }
+AUM_DEV void lds_write(float* lds, vi idx, vf v) { lds[idx] = v; }
+AUM_DEV void wave_sync() { __syncthreads(); }  // single-wave workgroup: orders LDS traffic, ~free
+
+template <int CTRL> AUM_DEV vf dpp_mov(vf x, vf old) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+// lane i <- lane i-N of its 16-lane row; lanes with (i%16) < N keep `old`
+template <int N> AUM_DEV vf dpp_row_shr(vf x, vf old) { return dpp_mov<0x110 + N>(x, old); }
+// lane i <- lane i+N of its row; lanes with (i%16)+N > 15 keep `old`
+template <int N> AUM_DEV vf dpp_row_shl(vf x, vf old) { return dpp_mov<0x100 + N>(x, old); }
+AUM_DEV vf dpp_wave_shr1(vf x, vf old) { return dpp_mov<0x138>(x, old); }  // lane i <- i-1, lane 0 keeps old
+AUM_DEV vf dpp_wave_shl1(vf x, vf old) { return dpp_mov<0x130>(x, old); }  // lane i <- i+1, lane 63 keeps old
+AUM_DEV float readlane(vf x, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+#define AUM_LDS(type, name, count) __shared__ type name[count]
+
+#else
+// =================================================================================================
+// Lane-array backend (tests only): gfx950 semantics applied lane by lane on the host.
+// =================================================================================================
+struct vf { float v[WAVE]; };
+struct vi { int v[WAVE]; };
+struct vm { bool v[WAVE]; };
+
+#define AUM_LANES for (int l = 0; l < WAVE; ++l)
+inline vi lane_id() { vi r; AUM_LANES r.v[l] = l; return r; }
+inline vf splat(float x) { vf r; AUM_LANES r.v[l] = x; return r; }
+inline vi spl_i(int x) { vi r; AUM_LANES r.v[l] = x; return r; }
+
+#define AUM_BINOP_F(op)                                                                         \
+    inline vf operator op(const vf& a, const vf& b) { vf r; AUM_LANES r.v[l] = a.v[l] op b.v[l]; return r; } \
+    inline vf operator op(const vf& a, float b) { vf r; AUM_LANES r.v[l] = a.v[l] op b; return r; }          \
+    inline vf operator op(float a, const vf& b) { vf r; AUM_LANES r.v[l] = a op b.v[l]; return r; }
+AUM_BINOP_F(+) AUM_BINOP_F(-) AUM_BINOP_F(*)
+inline vf operator-(const vf& a) { vf r; AUM_LANES r.v[l] = -a.v[l]; return r; }
+inline vf& operator+=(vf& a, const vf& b) { AUM_LANES a.v[l] += b.v[l]; return a; }
+#define AUM_CMP_F(op)                                                                          \
+    inline vm operator op(const vf& a, const vf& b) { vm r; AUM_LANES r.v[l] = a.v[l] op b.v[l]; return r; } \
+    inline vm operator op(const vf& a, float b) { vm r; AUM_LANES r.v[l] = a.v[l] op b; return r; }
+AUM_CMP_F(<) AUM_CMP_F(>) AUM_CMP_F(<=) AUM_CMP_F(>=) AUM_CMP_F(==)
+#define AUM_BINOP_I(op)                                                                         \
+    inline vi operator op(const vi& a, const vi& b) { vi r; AUM_LANES r.v[l] = a.v[l] op b.v[l]; return r; } \
+    inline vi operator op(const vi& a, int b) { vi r; AUM_LANES r.v[l] = a.v[l] op b; return r; }            \
+    inline vi operator op(int a, const vi& b) { vi r; AUM_LANES r.v[l] = a op b.v[l]; return r; }
+AUM_BINOP_I(+) AUM_BINOP_I(-) AUM_BINOP_I(*) AUM_BINOP_I(/) AUM_BINOP_I(%) AUM_BINOP_I(&) AUM_BINOP_I(>>)
+#define AUM_CMP_I(op)                                                                          \
+    inline vm operator op(const vi& a, const vi& b) { vm r; AUM_LANES r.v[l] = a.v[l] op b.v[l]; return r; } \
+    inline vm operator op(const vi& a, int b) { vm r; AUM_LANES r.v[l] = a.v[l] op b; return r; }
+AUM_CMP_I(<) AUM_CMP_I(>) AUM_CMP_I(<=) AUM_CMP_I(>=) AUM_CMP_I(==) AUM_CMP_I(!=)
+inline vm operator&&(const vm& a, const vm& b) { vm r; AUM_LANES r.v[l] = a.v[l] && b.v[l]; return r; }
+inline vm operator&&(const vm& a, bool b) { vm r; AUM_LANES r.v[l] = a.v[l] && b; return r; }
+inline vm operator||(const vm& a, const vm& b) { vm r; AUM_LANES r.v[l] = a.v[l] || b.v[l]; return r; }
+inline vm operator!(const vm& a) { vm r; AUM_LANES r.v[l] = !a.v[l]; return r; }
+
+inline vf vfma(const vf& a, const vf& b, const vf& c) { vf r; AUM_LANES r.v[l] = std::fmaf(a.v[l], b.v[l], c.v[l]); return r; }
+inline vf vfma(const vf& a, float b, const vf& c) { return vfma(a, splat(b), c); }
+inline vf vfma(float a, const vf& b, const vf& c) { return vfma(splat(a), b, c); }
+inline vf vfma(const vf& a, const vf& b, float c) { return vfma(a, b, splat(c)); }
+inline vf vexp2(const vf& x) { vf r; AUM_LANES r.v[l] = std::exp2(x.v[l]); return r; }
+inline vf vlog2(const vf& x) { vf r; AUM_LANES r.v[l] = std::log2(x.v[l]); return r; }
+inline vf vrcp(const vf& x) { vf r; AUM_LANES r.v[l] = 1.0f / x.v[l]; return r; }
+inline vf vrsqrt(const vf& x) { vf r; AUM_LANES r.v[l] = 1.0f / std::sqrt(x.v[l]); return r; }
+inline vf vsqrt(const vf& x) { vf r; AUM_LANES r.v[l] = std::sqrt(x.v[l]); return r; }
+inline vf vdiv(const vf& a, const vf& b) { vf r; AUM_LANES r.v[l] = a.v[l] / b.v[l]; return r; }
+inline vf vmax(const vf& a, const vf& b) { vf r; AUM_LANES r.v[l] = std::fmax(a.v[l], b.v[l]); return r; }
+inline vf vsel(const vm& m, const vf& a, const vf& b) { vf r; AUM_LANES r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
+inline vf vsel(const vm& m, const vf& a, float b) { return vsel(m, a, splat(b)); }
+inline vf vsel(const vm& m, float a, const vf& b) { return vsel(m, splat(a), b); }
+inline vi vsel_i(const vm& m, const vi& a, const vi& b) { vi r; AUM_LANES r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
+inline bool any_lane(const vm& m) { bool r = false; AUM_LANES r = r || m.v[l]; return r; }
+// scalar (wave-uniform) overloads so kernel code can mix uniform floats freely
+inline float vfma(float a, float b, float c) { return std::fmaf(a, b, c); }
+inline float vexp2(float x) { return std::exp2(x); }
+inline float vlog2(float x) { return std::log2(x); }
+inline float vrcp(float x) { return 1.0f / x; }
+inline float vsel(bool m, float a, float b) { return m ? a : b; }
+
+template <class T> inline vf gload(const T* p, const vi& idx, const vm& m) {
+    vf r; AUM_LANES r.v[l] = m.v[l] ? elem_to_f32(p[idx.v[l]]) : 0.f; return r;
+}
+template <class T> inline void gstore(T* p, const vi& idx, const vf& v, const vm& m) {
+    AUM_LANES if (m.v[l]) f32_to_elem(v.v[l], p[idx.v[l]]);
+}
+inline void gatomic_add(float* p, const vi& idx, const vf& v, const vm& m) { AUM_LANES if (m.v[l]) p[idx.v[l]] += v.v[l]; }
+inline vf gload_coherent(const float* p, const vi& idx, const vm& m) { return gload(p, idx, m); }
+inline void gstore_coherent(float* p, const vi& idx, const vf& v, const vm& m) { gstore(p, idx, v, m); }
+inline vf lds_read(const float* lds, const vi& idx) { vf r; AUM_LANES r.v[l] = lds[idx.v[l]]; return r; }
+inline void lds_write(float* lds, const vi& idx, const vf& v) { AUM_LANES lds[idx.v[l]] = v.v[l]; }
+inline void wave_sync() {}
+
+template <int N> inline vf dpp_row_shr(const vf& x, const vf& old) {
+    vf r; AUM_LANES r.v[l] = ((l & 15) >= N) ? x.v[l - N] : old.v[l]; return r;
+}
+template <int N> inline vf dpp_row_shl(const vf& x, const vf& old) {
+    vf r; AUM_LANES r.v[l] = ((l & 15) + N <= 15) ? x.v[l + N] : old.v[l]; return r;
+}
+inline vf dpp_wave_shr1(const vf& x, const vf& old) { vf r; AUM_LANES r.v[l] = l >= 1 ? x.v[l - 1] : old.v[l]; return r; }
+inline vf dpp_wave_shl1(const vf& x, const vf& old) { vf r; AUM_LANES r.v[l] = l < WAVE - 1 ? x.v[l + 1] : old.v[l]; return r; }
+template <int N> inline vf dpp_row_shr(const vf& x, float old) { return dpp_row_shr<N>(x, splat(old)); }
+template <int N> inline vf dpp_row_shl(const vf& x, float old) { return dpp_row_shl<N>(x, splat(old)); }
+inline vf dpp_wave_shr1(const vf& x, float old) { return dpp_wave_shr1(x, splat(old)); }
+inline vf dpp_wave_shl1(const vf& x, float old) { return dpp_wave_shl1(x, splat(old)); }
+inline float readlane(const vf& x, int lane) { return x.v[lane]; }
+#define AUM_LDS(type, name, count) type name[count]
+#endif  // AUM_EMU
+
+// ------------------------------------------------------------------------------------------------
+// Backend-independent helpers built from the primitives above.
+// ------------------------------------------------------------------------------------------------
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+AUM_DEV vf vexp(vf x) { return vexp2(x * LOG2E); }
+AUM_DEV vf vsigmoid(vf x) { return vrcp(splat(1.0f) + vexp2(x * (-LOG2E))); }
+
+// torch softplus(beta=1, threshold=20) (SSI:106-107): x > 20 ? x : log1p(exp(x)), with an accurate
+// log1p for small exp(x) (log(1+e) * e / ((1+e) - 1), exact e when 1+e rounds to 1).
+AUM_DEV vf vsoftplus(vf x) {
+    vf e = vexp(x);
+    vf w = e + 1.0f;
+    vf d = w - 1.0f;
+    vf lg = vlog2(w) * LN2;
+    vf r = vsel(d == 0.0f, e, lg * vdiv(e, vsel(d == 0.0f, splat(1.0f), d)));
+    return vsel(x > 20.0f, x, r);
+}
+
+// Sum over the 64 lanes, result wave-uniform.  4 DPP row steps + 3 cross-row v_readlane.
+AUM_DEV float wave_sum(vf x) {
+    x = x + dpp_row_shr<1>(x, splat(0.f));
+    x = x + dpp_row_shr<2>(x, splat(0.f));
+    x = x + dpp_row_shr<4>(x, splat(0.f));
+    x = x + dpp_row_shr<8>(x, splat(0.f));
+    return (readlane(x, 15) + readlane(x, 31)) + (readlane(x, 47) + readlane(x, 63));
+}
+
+// ------------------------------------------------------------------------------------------------
+// The associative scan of the selective-scan recurrence x' = a*x + b over the 64 lanes.
+// Each lane holds the composition (P, S) of its own K steps:  x_out = P * x_in + S.
+// Operator (earlier) o (later):  (P1,S1) o (P2,S2) = (P1*P2, P2*S1 + S2)      (SURVEY 8a')
+//
+// REV = false: time runs lane 0 -> 63 (inclusive prefix scan); REV = true: 63 -> 0 (suffix scan).
+// On return S holds, for every lane, the state AFTER that lane's last step given a zero state before
+// the first lane (a carry-in is folded into the first lane's S by the caller).  P is left holding
+// partial products and must not be used afterwards.
+// Intra-row: 4 Hillis-Steele steps with DPP row_shr / row_shl (identity filled into invalid lanes).
+// Cross-row: the three row totals travel through SGPRs via v_readlane_b32.
+// ------------------------------------------------------------------------------------------------
+template <bool REV> AUM_DEV void wave_scan_affine(vf& P, vf& S) {
+#define AUM_SCAN_STEP(N)                                                               \
+    {                                                                                  \
+        vf Pp = REV ? dpp_row_shl<N>(P, splat(1.f)) : dpp_row_shr<N>(P, splat(1.f));   \
+        vf Sp = REV ? dpp_row_shl<N>(S, splat(0.f)) : dpp_row_shr<N>(S, splat(0.f));   \
+        S = vfma(P, Sp, S);                                                            \
+        P = P * Pp;                                                                    \
+    }
+    AUM_SCAN_STEP(1) AUM_SCAN_STEP(2) AUM_SCAN_STEP(4) AUM_SCAN_STEP(8)
+#undef AUM_SCAN_STEP
+    // row totals sit in the last (first, for REV) lane of each 16-lane row
+    const int t0 = REV ? 48 : 15, t1 = REV ? 32 : 31, t2 = REV ? 16 : 47;
+    const float P0 = readlane(P, t0), S0 = readlane(S, t0);
+    const float P1 = readlane(P, t1), S1 = readlane(S, t1);
+    const float P2 = readlane(P, t2), S2 = readlane(S, t2);
+    // exclusive composition entering rows 1,2,3 (in scan order)
+    const float E1P = P0, E1S = S0;
+    const float E2P = P0 * P1, E2S = vfma(P1, S0, S1);
+    const float E3S = vfma(P2, E2S, S2);
+    const vi row = lane_id() >> 4;                        // 0..3
+    const vi ord = REV ? (3 - row) : row;                 // position of this row in scan order
+    const vf inS = vsel(ord == 1, splat(E1S), vsel(ord == 2, splat(E2S), vsel(ord == 3, splat(E3S), splat(0.f))));
+    S = vfma(P, inS, S);
+    (void)E1P; (void)E2P;
+}
+
+}  // namespace aum

@@ -1,0 +1,167 @@
+/*
+ * aum_hip.h -- C ABI of libaum_hip.so: the MI355X (gfx950) implementation of the native boundary that
+ * kaistmm/Audio-Mamba-AuM reaches through two un-vendored CUDA wheels.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *   selective_scan_cuda.fwd / .bwd            call sites vim-mamba_ssm/mamba_ssm/ops/selective_scan_interface.py:37,
+ *                                             62-65, 213-215, 247-251, 354-356, 389-393, 499-505, 541-552
+ *   causal_conv1d_cuda.causal_conv1d_fwd/_bwd call sites selective_scan_interface.py:177, 239, 281-283, 318, 380,
+ *                                             425-427, 463, 532, 594-596 (arithmetic: modules/mamba_simple.py:272)
+ *   Triton _layer_norm_fwd_1pass_kernel / _layer_norm_bwd_kernel (fused residual-add + RMSNorm)
+ *                                             vim-mamba_ssm/mamba_ssm/ops/triton/layernorm.py:123-177, 293-377
+ *
+ * Conventions (same as the reference's extension ABI, SURVEY.md 8b "Conventions"):
+ *   - every pointer is a DEVICE pointer; nothing is allocated, freed or synchronised inside the library;
+ *     every call only enqueues kernels on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - activation tensors (u, delta, z, B, C, x, dout, ...) share one element type `dtype`;
+ *     A, D, delta_bias, conv weights/bias, norm weights and every parameter gradient are fp32;
+ *   - the time axis is always unit-stride; batch / channel strides are explicit, in ELEMENTS;
+ *   - return value 0 on success, a negative AUM_E_* code on invalid arguments (no exceptions cross the ABI).
+ */
+#ifndef AUM_HIP_H
+#define AUM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AUM_ABI_VERSION 1
+
+enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
+
+enum {
+    AUM_OK = 0,
+    AUM_E_NULL = -1,        /* a required pointer is NULL */
+    AUM_E_SHAPE = -2,       /* non-positive or unsupported size */
+    AUM_E_DTYPE = -3,       /* unknown dtype enum */
+    AUM_E_UNSUPPORTED = -4, /* combination not implemented (e.g. dstate > 256) */
+    AUM_E_WORKSPACE = -5,   /* workspace missing or too small */
+    AUM_E_LAUNCH = -6       /* hipLaunchKernel reported an error */
+};
+
+/* flags */
+#define AUM_SCAN_SOFTPLUS 1u /* delta = softplus(delta + delta_bias)  (delta_softplus=True)                     */
+#define AUM_SCAN_REVERSE 2u  /* run the recurrence from t=len-1 down to 0 (replaces the .flip([-1]) copies of   */
+                             /* selective_scan_interface.py:503-507,547-561 and mamba_simple.py:229-246)        */
+#define AUM_CONV_SILU 1u
+#define AUM_CONV_REVERSE 2u  /* anti-causal: y[l] = act(b + sum_w W[w] x[l+(W-1)-w])                            */
+#define AUM_NORM_PRENORM 1u  /* also return residual_out                                                        */
+
+/*
+ * Selective scan forward (selective_scan_cuda.fwd).
+ *   u, delta, z, out, out_pre : (batch, dim, len)        B, C : (batch, dstate, len)   [the G=1 (B,1,N,L) case]
+ *   A, A_b : (dim, dstate) fp32    D, delta_bias : (dim) fp32 or NULL     last_state : (batch, dim, dstate) fp32 or NULL
+ * A_b != NULL selects the direction-fused bidirectional form of BiMambaInnerFn.forward
+ * (selective_scan_interface.py:499-507): out = scan(A, forward) + scan(A_b, time-reversed), inputs read once, no flip
+ * copies.  z == NULL: no gate.  out_pre (optional) receives the pre-gate value y + D*u summed over directions (what
+ * the reference saves as `out` / `out_f`,`out_b` for the backward's dz).
+ * workspace: needed only when len > aum_scan_max_single_pass_len(); size from aum_selective_scan_workspace_bytes().
+ */
+typedef struct AumScanFwdArgs {
+    const void *u, *delta, *z, *B, *C;
+    const float *A, *A_b, *D, *delta_bias;
+    void *out, *out_pre;
+    float *last_state;
+    void *workspace;
+    int64_t workspace_bytes;
+    int64_t u_bs, u_ds;         /* batch / channel strides of u (elements) */
+    int64_t delta_bs, delta_ds; /* ... of delta */
+    int64_t z_bs, z_ds;
+    int64_t B_bs, B_ns;         /* batch / state strides of B */
+    int64_t C_bs, C_ns;
+    int64_t out_bs, out_ds;     /* strides of out and out_pre */
+    int32_t batch, dim, len, dstate;
+    int32_t dtype;
+    uint32_t flags;
+} AumScanFwdArgs;
+
+/*
+ * Selective scan backward (selective_scan_cuda.bwd).  dout is the gradient of `out`.
+ *   du, ddelta, dz : (batch, dim, len) in `dtype` (written; dz only when z != NULL)
+ *   dA, dA_b : (dim, dstate); dD, ddelta_bias : (dim); dB, dC : (batch, dstate, len) -- all fp32, ACCUMULATED INTO
+ *   (the caller zero-fills them; the fused bidirectional call adds both directions, selective_scan_interface.py:554-559).
+ * out_pre is the tensor saved by the forward (required when z != NULL; it feeds dz).
+ * The gradient is the mathematically complete one (autograd of bimamba_inner_ref), see DESIGN.md "dz".
+ */
+typedef struct AumScanBwdArgs {
+    const void *u, *delta, *z, *B, *C, *dout, *out_pre;
+    const float *A, *A_b, *D, *delta_bias;
+    void *du, *ddelta, *dz;
+    float *dA, *dA_b, *dB, *dC, *dD, *ddelta_bias;
+    void *workspace;
+    int64_t workspace_bytes;
+    int64_t u_bs, u_ds, delta_bs, delta_ds, z_bs, z_ds, B_bs, B_ns, C_bs, C_ns;
+    int64_t dout_bs, dout_ds, out_bs, out_ds; /* out_* = strides of out_pre */
+    int64_t du_bs, du_ds, ddelta_bs, ddelta_ds, dz_bs, dz_ds;
+    int64_t dB_bs, dB_ns, dC_bs, dC_ns;
+    int32_t batch, dim, len, dstate;
+    int32_t dtype;
+    uint32_t flags;
+} AumScanBwdArgs;
+
+int aum_selective_scan_fwd(const AumScanFwdArgs* args, void* stream);
+int aum_selective_scan_bwd(const AumScanBwdArgs* args, void* stream);
+/* longest `len` handled in one pass per row (no workspace needed, direction fusion available) */
+int aum_scan_max_single_pass_len(void);
+int64_t aum_selective_scan_workspace_bytes(int32_t batch, int32_t dim, int32_t len, int32_t dstate, int32_t bidirectional,
+                                           int32_t backward);
+
+/*
+ * Depthwise causal conv1d + bias + SiLU (causal_conv1d_cuda.causal_conv1d_fwd / _bwd).
+ *   x, y, dy, dx : (batch, dim, len) in `dtype`;  weight : (dim, width) fp32;  bias : (dim) fp32 or NULL
+ *   dweight (dim, width), dbias (dim): fp32, accumulated into (caller zero-fills).
+ */
+typedef struct AumConvArgs {
+    const void *x, *dy;  /* dy: backward only */
+    const float *weight, *bias;
+    void *y;             /* forward: output.  backward: unused */
+    void *dx;            /* backward */
+    float *dweight, *dbias;
+    int64_t x_bs, x_ds, y_bs, y_ds, dy_bs, dy_ds, dx_bs, dx_ds;
+    int32_t batch, dim, len, width;
+    int32_t dtype;
+    uint32_t flags;
+} AumConvArgs;
+
+int aum_causal_conv1d_fwd(const AumConvArgs* args, void* stream);
+int aum_causal_conv1d_bwd(const AumConvArgs* args, void* stream);
+
+/*
+ * Fused residual-add + RMSNorm (rms_norm_fn -> LayerNormFn, layernorm.py:380-478).
+ *   x (rows, cols) in x_dtype; residual (rows, cols) in res_dtype or NULL; weight (cols) fp32;
+ *   y (rows, cols) in y_dtype; residual_out (rows, cols) in res_dtype or NULL; rstd (rows) fp32.
+ * backward: dy (rows, cols) in y_dtype; dresidual_out in res_dtype or NULL; x = the saved residual_out (or the input x
+ * when no residual stream exists) in res_dtype; writes dx in x_dtype, dresidual_in (res_dtype, optional, receives the same
+ * values as dx), and per-workgroup partial sums dweight_partial (n_partials, cols) fp32 that the caller reduces
+ * (layernorm.py:333-372 does the same); n_partials = aum_rmsnorm_bwd_partials(rows).
+ */
+typedef struct AumNormArgs {
+    const void *x, *residual, *dy, *dresidual_out;
+    const float *weight, *rstd_in;
+    void *y, *residual_out, *dx, *dresidual_in;
+    float *rstd_out, *dweight_partial;
+    int64_t row_stride_x, row_stride_res, row_stride_y, row_stride_res_out;
+    int64_t row_stride_dy, row_stride_dres_out, row_stride_dx, row_stride_dres_in;
+    float eps;
+    int32_t rows, cols;
+    int32_t x_dtype, res_dtype, y_dtype;
+    uint32_t flags;
+} AumNormArgs;
+
+int aum_rmsnorm_fwd(const AumNormArgs* args, void* stream);
+int aum_rmsnorm_bwd(const AumNormArgs* args, void* stream);
+int aum_rmsnorm_bwd_partials(int32_t rows);
+
+/* Self-tests and calibration (used by tests/ and bench.py; not part of the reference's surface). */
+int aum_abi_version(void);
+/* runs wave_scan_affine<rev> on 64 (P,S) pairs: in/out are device arrays of 128 floats (P[0..63], S[0..63]) */
+int aum_selftest_wave_scan(const float* in, float* out, int rev, void* stream);
+/* float4 streaming copy, the measured-HBM-roofline denominator of SURVEY.md 8(d) */
+int aum_hbm_copy(const void* src, void* dst, int64_t bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUM_HIP_H */

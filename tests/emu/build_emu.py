@@ -1,0 +1,33 @@
+"""TEST INFRASTRUCTURE: build tests/emu/_build/libaum_emu.so (host lane-array build of the kernel sources)."""
+import hashlib
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "audio-mamba-aum_amd", "csrc")
+CXX = os.environ.get("AUM_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+DEPS = [os.path.join(HERE, "aum_emu.cpp")] + [os.path.join(CSRC, f) for f in
+        ("aum_api.inc", "wave.h", "scan_kernels.h", "conv_norm_kernels.h")] + [os.path.join(ROOT, "include", "aum_hip.h")]
+
+
+def build():
+    out_dir = os.path.join(HERE, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libaum_emu.so")
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(open(d, "rb").read())
+    dig = h.hexdigest()
+    stamp = os.path.join(out_dir, "digest")
+    if os.path.exists(so) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return so
+    subprocess.check_call([CXX, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                           "-Wno-unused-variable", "-Wno-unused-function",
+                           os.path.join(HERE, "aum_emu.cpp"), "-o", so])
+    open(stamp, "w").write(dig)
+    return so
+
+
+if __name__ == "__main__":
+    print(build())

@@ -1,0 +1,134 @@
+"""Shared parity checks: run an aum_hip.Lib (the product libaum_hip.so on a GPU, or the tests-only lane-array
+build on the host) against the oracle on seeded inputs.  Used by test_emu_kernels.py (CPU) and
+test_gpu_kernels.py (-m gpu)."""
+import numpy as np
+import torch
+
+import aum_hip
+import cases
+from conftest import rel_err
+from oracle import oracle as O
+
+TOL_F32 = 1e-4      # north_star bar for fp32 is 1e-3; the kernels are held to 1e-4 of the fp64 oracle
+TOL_BF16 = 1e-2     # north_star bar for bf16 I/O
+
+
+def T(a, dev, dtype=torch.float32):
+    return None if a is None else torch.tensor(np.asarray(a)).to(dtype).to(dev)
+
+
+def N(t):
+    return None if t is None else t.detach().float().cpu().numpy()
+
+
+def rq(a, dtype):
+    """round-trip through the activation dtype (what the kernel will see)."""
+    return None if a is None else torch.tensor(np.asarray(a)).to(dtype).float().numpy()
+
+
+def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, tol=None, strided=False):
+    name, batch, dim, length, dstate, has_z, has_D, has_bias, softplus = case
+    d = cases.scan_inputs(*case)
+    tol = tol or (TOL_F32 if dtype == torch.float32 else TOL_BF16)
+    act = lambda a: T(a, dev, dtype)
+    q = {k: rq(d[k], dtype) for k in ("u", "delta", "z", "B", "C", "dout")}
+    rng = np.random.default_rng(7)
+    A_b = (d["A"] * np.exp(rng.normal(0, 0.1, d["A"].shape))).astype(np.float32) if bidir else None
+    u, delta, z = act(d["u"]), act(d["delta"]), act(d["z"])
+    if strided:   # d-major storage like the reference's xz view (MS:185-189): batch stride = len
+        mk = lambda t: None if t is None else t.permute(1, 0, 2).contiguous().permute(1, 0, 2)
+        u, delta, z = mk(u), mk(delta), mk(z)
+    Bm, Cm = act(d["B"]).unsqueeze(1), act(d["C"]).unsqueeze(1)
+    A, D, bias = T(d["A"], dev), T(d["D"], dev), T(d["delta_bias"], dev)
+    out, out_pre, last = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, softplus, reverse, T(A_b, dev),
+                                          want_out_pre=True, want_last_state=not bidir, lib=lib)
+    ref = O.scan_fwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], softplus,
+                     reverse, "f64")
+    ref_out, ref_pre = ref["out"], ref["y_pre"]
+    if bidir:
+        rb = O.scan_fwd(q["u"], q["delta"], A_b, q["B"], q["C"], d["D"], q["z"], d["delta_bias"], softplus, True, "f64")
+        ref_out, ref_pre = ref_out + rb["out"], ref_pre + rb["y_pre"]
+    errs = {"out": rel_err(N(out), ref_out), "out_pre": rel_err(N(out_pre), ref_pre)}
+    if not bidir:
+        errs["last_state"] = rel_err(N(last), ref["last_state"])
+    # backward
+    dout = act(d["dout"])
+    g = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, out_pre if has_z else None, softplus, reverse,
+                         T(A_b, dev), lib=lib)
+    gr = O.scan_bwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus,
+                    reverse, "f64")
+    if bidir:
+        gb = O.scan_bwd(q["u"], q["delta"], A_b, q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus,
+                        True, "f64")
+        for k in ("du", "ddelta", "dB", "dC", "dD", "dz", "ddelta_bias"):
+            if gr[k] is not None:
+                gr[k] = gr[k] + gb[k]
+        gr["dA_b"] = gb["dA"]
+    for k in ("du", "ddelta", "dA", "dA_b", "dB", "dC", "dD", "dz", "ddelta_bias"):
+        if gr.get(k) is None:
+            assert g.get(k) is None, k
+            continue
+        errs[k] = rel_err(N(g[k]), gr[k])
+    bad = {k: v for k, v in errs.items() if not (v < tol * (4 if k.startswith("d") else 1))}
+    assert not bad, (name, str(dtype), "rev" if reverse else "fwd", "bidir" if bidir else "uni", bad, errs)
+    return errs
+
+
+def check_conv(lib, dev, case, dtype=torch.float32, reverse=False, silu=True):
+    name = case[0]
+    d = cases.conv_inputs(*case)
+    tol = 1e-5 if dtype == torch.float32 else TOL_BF16
+    q = {k: rq(d[k], dtype) for k in ("x", "dout")}
+    x, dy = T(d["x"], dev, dtype), T(d["dout"], dev, dtype)
+    w, b = T(d["weight"], dev), T(d["bias"], dev)
+    y = aum_hip.conv1d_fwd(x, w, b, silu, reverse, lib=lib)
+    ry = O.conv1d_fwd(q["x"], d["weight"], d["bias"], silu, reverse, "f64")
+    dx, dw, db = aum_hip.conv1d_bwd(x, w, b, dy, silu, reverse, lib=lib)
+    rg = O.conv1d_bwd(q["x"], d["weight"], d["bias"], q["dout"], silu, reverse, "f64")
+    errs = {"y": rel_err(N(y), ry), "dx": rel_err(N(dx), rg["dx"]), "dw": rel_err(N(dw), rg["dweight"])}
+    if b is not None:
+        errs["db"] = rel_err(N(db), rg["dbias"])
+    bad = {k: v for k, v in errs.items() if not v < tol * (4 if k != "y" else 1)}
+    assert not bad, (name, bad)
+    return errs
+
+
+def check_norm(lib, dev, case, dtype=torch.float32, res_dtype=torch.float32):
+    name, lead, cols, has_res, prenorm = case
+    d = cases.norm_inputs(*case)
+    tol = 1e-5 if dtype == torch.float32 else TOL_BF16
+    x = T(d["x"], dev, dtype).reshape(-1, cols)
+    res = T(d["residual"], dev, res_dtype)
+    res = None if res is None else res.reshape(-1, cols)
+    w = T(d["weight"], dev)
+    y, rstd, res_out = aum_hip.rmsnorm_fwd(x, w, res, 1e-5, residual_dtype=res_dtype, lib=lib)
+    qx = rq(d["x"], dtype).reshape(-1, cols)
+    qr = None if d["residual"] is None else rq(d["residual"], res_dtype).reshape(-1, cols)
+    r = O.rmsnorm_fwd(qx, d["weight"], None, qr, 1e-5, "f64")
+    errs = {"y": rel_err(N(y), r["y"]), "res_out": rel_err(N(res_out), r["residual_out"]),
+            "rstd": rel_err(N(rstd), r["rstd"])}
+    dy = T(d["dy"], dev, dtype).reshape(-1, cols)
+    dres = None if d["dres"] is None else T(d["dres"], dev, res_out.dtype).reshape(-1, cols)
+    dx, dw, dres_in = aum_hip.rmsnorm_bwd(dy, res_out, w, rstd, dres, has_res, x_dtype=dtype, lib=lib)
+    qdres = None if d["dres"] is None else rq(d["dres"], res_out.dtype).reshape(-1, cols)
+    rb = O.rmsnorm_bwd(rq(d["dy"], dtype).reshape(-1, cols), N(res_out), d["weight"], N(rstd), qdres, False, "f64")
+    errs["dx"] = rel_err(N(dx), rb["dx"])
+    errs["dw"] = rel_err(N(dw), rb["dweight"])
+    if has_res:
+        errs["dres_in"] = rel_err(N(dres_in), rb["dx"])
+    bad = {k: v for k, v in errs.items() if not v < tol * 4}
+    assert not bad, (name, bad)
+    return errs
+
+
+def check_wave_scan(lib, dev):
+    rng = np.random.default_rng(3)
+    for rev in (False, True):
+        P = rng.uniform(0.2, 1.0, 64).astype(np.float32)
+        S = rng.normal(0, 1, 64).astype(np.float32)
+        _, So = aum_hip.selftest_wave_scan(T(P, dev), T(S, dev), rev, lib=lib)
+        x, ref = 0.0, np.zeros(64)
+        for l in (range(63, -1, -1) if rev else range(64)):
+            x = float(P[l]) * x + float(S[l])
+            ref[l] = x
+        assert rel_err(N(So), ref) < 1e-5, ("wave scan", rev)

@@ -1,0 +1,76 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/aum_hip.h declares, and the ctypes
+structure layouts match the header.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import aum_hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "aum_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(aum_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def so_path():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("aum_build", os.path.join(ROOT, "audio-mamba-aum_amd", "csrc", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build()
+
+
+def test_every_declared_symbol_is_exported(so_path):
+    names = declared_functions()
+    assert len(names) >= 12 and set(aum_hip.EXPORTS) == set(names)
+    lib = ctypes.CDLL(so_path)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.aum_abi_version() == 1
+    assert lib.aum_scan_max_single_pass_len() == 1024
+    assert lib.aum_rmsnorm_bwd_partials(32832) == 1024
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """Compile a tiny C program against the header and compare sizeof/offsetof with the ctypes mirrors."""
+    probes = {
+        "AumScanFwdArgs": (aum_hip.ScanFwdArgs, ["u", "A", "out", "workspace_bytes", "u_bs", "out_ds", "batch", "flags"]),
+        "AumScanBwdArgs": (aum_hip.ScanBwdArgs, ["u", "dout", "A", "du", "dA", "workspace_bytes", "dC_ns", "batch", "flags"]),
+        "AumConvArgs": (aum_hip.ConvArgs, ["x", "weight", "y", "dweight", "x_bs", "dx_ds", "batch", "flags"]),
+        "AumNormArgs": (aum_hip.NormArgs, ["x", "weight", "y", "rstd_out", "row_stride_x", "eps", "rows", "flags"]),
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']
+    for cname, (_, fields) in probes.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for f in fields:
+            lines.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    lines += ['return 0;}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, (cls, fields) in probes.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for f in fields:
+            assert int(got[f"{cname}.{f}"]) == getattr(cls, f).offset, (cname, f)
+
+
+def test_product_library_refuses_host_tensors(so_path):
+    import torch
+    lib = aum_hip.Lib(so_path)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        aum_hip.conv1d_fwd(torch.zeros(1, 2, 8), torch.zeros(2, 4), None, lib=lib)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        aum_hip.Lib(str(tmp_path / "libaum_hip.so"))

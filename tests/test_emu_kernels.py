@@ -1,0 +1,58 @@
+"""Kernel SOURCES vs the oracle, on the host: the lane-array build (tests/emu) executes the same kernel
+bodies that hipcc compiles for gfx950, one 64-lane wavefront at a time, so index arithmetic, tails, chunk
+carries, direction handling and reductions are checked here without a GPU.  (The GPU parity tests proper
+are in test_gpu_kernels.py and run the real libaum_hip.so.)"""
+import os
+import sys
+
+import pytest
+import torch
+
+import aum_hip
+import cases
+import kernel_checks as KC
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import build_emu
+    return aum_hip.Lib(build_emu.build(), host=True)
+
+
+def test_wave_scan_primitive(emu):
+    KC.check_wave_scan(emu, "cpu")
+
+
+@pytest.mark.parametrize("case", cases.SCAN_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+def test_scan(emu, case, mode):
+    if mode == "bidir" and case[3] > emu.max_single_pass_len:
+        pytest.skip("direction fusion is single-pass only; host composes two reverse-flag calls")
+    KC.check_scan(emu, "cpu", case, torch.float32, reverse=(mode == "rev"), bidir=(mode == "bidir"))
+
+
+@pytest.mark.parametrize("mode", ["fwd", "bidir"])
+def test_scan_bf16_and_strided(emu, mode):
+    case = [c for c in cases.SCAN_CASES if c[0] == "l65"][0]
+    KC.check_scan(emu, "cpu", case, torch.bfloat16, bidir=(mode == "bidir"))
+    KC.check_scan(emu, "cpu", case, torch.float16, bidir=(mode == "bidir"), tol=2e-3)
+    KC.check_scan(emu, "cpu", case, torch.float32, bidir=(mode == "bidir"), strided=True)
+
+
+@pytest.mark.parametrize("case", cases.CONV_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_conv(emu, case, reverse):
+    KC.check_conv(emu, "cpu", case, torch.float32, reverse=reverse)
+    KC.check_conv(emu, "cpu", case, torch.float32, reverse=reverse, silu=False)
+
+
+def test_conv_bf16(emu):
+    KC.check_conv(emu, "cpu", cases.CONV_CASES[2], torch.bfloat16)
+
+
+@pytest.mark.parametrize("case", cases.NORM_CASES, ids=lambda c: c[0])
+def test_norm(emu, case):
+    KC.check_norm(emu, "cpu", case, torch.float32)
+    KC.check_norm(emu, "cpu", case, torch.bfloat16, torch.float32)

@@ -1,0 +1,93 @@
+"""GPU parity tests proper: the product library libaum_hip.so (hand-written gfx950 kernels, called through the
+C ABI) against the oracle on the same seeded inputs.  Run with -m gpu on an MI355X."""
+import pytest
+import torch
+
+import aum_hip
+import cases
+import kernel_checks as KC
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    return aum_hip.get()     # raises ImportError if the extension is missing: no fallback
+
+
+def test_wave_scan_primitive(lib):
+    KC.check_wave_scan(lib, "cuda")
+
+
+@pytest.mark.parametrize("case", cases.SCAN_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+def test_scan_f32(lib, case, mode):
+    if mode == "bidir" and case[3] > lib.max_single_pass_len:
+        pytest.skip("direction fusion is single-pass only")
+    KC.check_scan(lib, "cuda", case, torch.float32, reverse=(mode == "rev"), bidir=(mode == "bidir"))
+
+
+@pytest.mark.parametrize("case", ["l65", "l513", "l2049", "l130_n4"])
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_scan_16bit(lib, case, mode, dtype):
+    c = [x for x in cases.SCAN_CASES if x[0] == case][0]
+    if mode == "bidir" and c[3] > lib.max_single_pass_len:
+        pytest.skip("direction fusion is single-pass only")
+    KC.check_scan(lib, "cuda", c, dtype, reverse=(mode == "rev"), bidir=(mode == "bidir"),
+                  tol=1e-2 if dtype == torch.bfloat16 else 2e-3)
+
+
+def test_scan_strided_layout(lib):
+    c = [x for x in cases.SCAN_CASES if x[0] == "l65"][0]
+    KC.check_scan(lib, "cuda", c, torch.float32, bidir=True, strided=True)
+    KC.check_scan(lib, "cuda", c, torch.bfloat16, bidir=False, strided=True)
+
+
+@pytest.mark.parametrize("case", cases.CONV_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_conv(lib, case, reverse):
+    KC.check_conv(lib, "cuda", case, torch.float32, reverse=reverse)
+    KC.check_conv(lib, "cuda", case, torch.float32, reverse=reverse, silu=False)
+    KC.check_conv(lib, "cuda", case, torch.bfloat16, reverse=reverse)
+
+
+@pytest.mark.parametrize("case", cases.NORM_CASES, ids=lambda c: c[0])
+def test_norm(lib, case):
+    KC.check_norm(lib, "cuda", case, torch.float32)
+    KC.check_norm(lib, "cuda", case, torch.bfloat16, torch.float32)
+    KC.check_norm(lib, "cuda", case, torch.float16, torch.float32)
+
+
+def test_scan_full_size_properties(lib):
+    """AuM-Base scan shape (B=8 of the 64, E=1536, L=513, N=16, bf16): size-independent properties instead of the
+    oracle -- (1) the fused bidirectional call equals the sum of a forward-time and a reverse-time call,
+    (2) linearity in u for fixed delta (the recurrence is linear in u), (3) the reverse call equals flip/forward/flip."""
+    torch.manual_seed(0)
+    Bsz, E, L, N = 8, 1536, 513, 16
+    dev, dt = "cuda", torch.bfloat16
+    u = torch.randn(Bsz, E, L, device=dev).to(dt)
+    delta = (0.5 * torch.randn(Bsz, E, L, device=dev)).to(dt)
+    z = torch.randn(Bsz, E, L, device=dev).to(dt)
+    Bm = torch.randn(Bsz, 1, N, L, device=dev).to(dt)
+    Cm = torch.randn(Bsz, 1, N, L, device=dev).to(dt)
+    A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(E, 1)
+    A_b = A * 1.1
+    D = torch.ones(E, device=dev)
+    bias = torch.full((E,), -4.0, device=dev)
+    f = lambda **kw: aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, None, bias, True, lib=lib, **kw)[0].float()
+    o_bi = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, None, bias, True, A_b=A_b, lib=lib)[0].float()
+    o_f = f()
+    o_r = aum_hip.scan_fwd(u, delta, A_b, Bm, Cm, D, None, bias, True, reverse=True, lib=lib)[0].float()
+    scale = o_bi.abs().max()
+    assert ((o_f + o_r) - o_bi).abs().max() / scale < 2e-2          # each term rounded to bf16 separately
+    fl = lambda t: t.flip([-1]).contiguous()
+    o_r2 = aum_hip.scan_fwd(fl(u), fl(delta), A_b, fl(Bm), fl(Cm), D, None, bias, True, lib=lib)[0].float().flip([-1])
+    assert (o_r - o_r2).abs().max() / scale < 1e-2
+    o2 = aum_hip.scan_fwd((2 * u.float()).to(dt), delta, A, Bm, Cm, D, None, bias, True, lib=lib)[0].float()
+    assert (o2 - 2 * o_f).abs().max() / scale < 2e-2
+    # gated output: out == out_pre * silu(z)
+    out, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, lib=lib)
+    ref = pre.float() * torch.nn.functional.silu(z.float())
+    assert (out.float() - ref).abs().max() / ref.abs().max() < 1e-2

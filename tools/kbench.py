@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Per-kernel timing at AuM-Base shapes (B=64, E=1536, L=513, N=16) through the C ABI.
+HIP events on the current stream; prints one JSON line per kernel with achieved algorithmic GB/s
+(byte formulas of SURVEY.md 8d)."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "audio-mamba-aum_amd"))
+import aum_hip  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--dmodel", type=int, default=768)
+    ap.add_argument("--len", type=int, default=513)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
+    s = 2 if dt != torch.float32 else 4
+    Bsz, E, L, N = a.batch, 2 * a.dmodel, a.len, 16
+    dev = "cuda"
+    torch.manual_seed(0)
+    # d-major layout [E][B][L] viewed as (B,E,L), as the host package stores it
+    mk = lambda: torch.randn(E, Bsz, L, device=dev).to(dt).permute(1, 0, 2)
+    u, z, dout = mk(), mk(), mk()
+    delta = (0.5 * torch.randn(E, Bsz, L, device=dev)).to(dt).permute(1, 0, 2)
+    Bm = torch.randn(Bsz, 1, N, L, device=dev).to(dt)
+    Cm = torch.randn(Bsz, 1, N, L, device=dev).to(dt)
+    A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(E, 1) * (1 + 0.1 * torch.rand(E, N, device=dev))
+    A_b = A * 1.05
+    D = torch.ones(E, device=dev)
+    bias = torch.full((E,), -4.0, device=dev) + torch.rand(E, device=dev)
+    T = Bsz * E * L
+    res = []
+
+    def rec(name, sec, alg_bytes):
+        r = {"kernel": name, "ms": round(sec * 1e3, 4), "alg_GB": round(alg_bytes / 1e9, 4),
+             "alg_GBps": round(alg_bytes / sec / 1e9, 1), "frac_of_8TBps": round(alg_bytes / sec / 8e12, 4)}
+        res.append(r)
+        print(json.dumps(r), flush=True)
+
+    want = lambda n: (not a.only) or a.only in n
+    if want("hbm_copy"):
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255)
+        dst = torch.empty_like(src)
+        rec("hbm_copy_1GiB", timeit(lambda: aum_hip.hbm_copy(src, dst)), 2 * src.numel())
+        rec("torch_copy_1GiB", timeit(lambda: dst.copy_(src)), 2 * src.numel())
+        del src, dst
+    bc = 2 * Bsz * N * L * s
+    if want("scan_fwd"):
+        rec("scan_fwd_uni", timeit(lambda: aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True)), 4 * T * s + bc)
+        rec("scan_fwd_bidir", timeit(lambda: aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b)), 4 * T * s + bc)
+        rec("scan_fwd_bidir_train", timeit(lambda: aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True)), 5 * T * s + bc)
+    if want("scan_bwd"):
+        _, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True)
+        bw_bytes = 8 * T * s + bc + 2 * Bsz * N * L * 4
+        rec("scan_bwd_uni", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True), iters=10), bw_bytes)
+        rec("scan_bwd_bidir", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, A_b=A_b), iters=10), bw_bytes)
+    if want("conv"):
+        w = torch.randn(E, 4, device=dev)
+        b = torch.randn(E, device=dev)
+        rec("conv_fwd", timeit(lambda: aum_hip.conv1d_fwd(u, w, b)), 2 * T * s)
+        rec("conv_bwd", timeit(lambda: aum_hip.conv1d_bwd(u, w, b, dout)), 3 * T * s)
+    if want("norm"):
+        M, C = Bsz * L, a.dmodel
+        x = torch.randn(M, C, device=dev).to(dt)
+        r = torch.randn(M, C, device=dev)
+        wn = torch.ones(C, device=dev)
+        rec("rmsnorm_fwd", timeit(lambda: aum_hip.rmsnorm_fwd(x, wn, r, 1e-5)), M * C * (2 * s + 8))
+        y, rstd, ro = aum_hip.rmsnorm_fwd(x, wn, r, 1e-5)
+        dy = torch.randn(M, C, device=dev).to(dt)
+        rec("rmsnorm_bwd", timeit(lambda: aum_hip.rmsnorm_bwd(dy, ro, wn, rstd, r, True, x_dtype=dt)), M * C * (2 * s + 12))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"kbench_{a.dtype}_B{a.batch}.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
