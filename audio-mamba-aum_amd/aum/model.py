@@ -1,0 +1,132 @@
+"""AuM (Audio Mamba) assembled from the drop-in mamba_ssm package: patch embed -> middle cls token -> abs pos embed
+-> depth x [fused add+RMSNorm -> Mamba mixer] -> final fused add+RMSNorm -> cls -> linear head.
+
+Mirrors the default configuration of the reference's AudioMamba (/root/reference/src/models/mamba_models.py = "MM":
+forward_features MM:509-667, Block.forward MM:58-99, defaults MM:191-242) and produces the SAME state-dict keys
+(patch_embed.proj.*, cls_token, pos_embed.pos_embed, layers.{i}.mixer.*, layers.{i}.norm.weight, norm_f.weight,
+head.*) so published checkpoints load.  Options off the default path (rope, double cls, flexible patch sizes,
+drop-path > 0, if_bidirectional layer pairing) are out of scope and rejected.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from mamba_ssm.modules.mamba_simple import Mamba
+from mamba_ssm.ops.triton.layernorm import RMSNorm, rms_norm_fn
+
+AUM_SIZES = {"base": 768, "small": 384, "tiny": 192}      # embed dims; depth 24 for all three (RUN:227-237)
+
+
+class PatchEmbed(nn.Module):
+    """FlexiPatchEmbed default branch (TOK:278-310): conv2d(kernel=stride=patch) -> flatten -> (B, N, Dm)."""
+
+    def __init__(self, patch_size, strides, in_chans, embed_dim):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=strides)
+        fan_in = in_chans * patch_size[0] * patch_size[1]
+        nn.init.trunc_normal_(self.proj.weight, std=math.sqrt(1.0 / fan_in) / 0.87962566103423978)   # lecun_normal_
+        nn.init.zeros_(self.proj.bias)
+
+    def forward(self, x):
+        return F.conv2d(x, self.proj.weight, self.proj.bias, stride=self.proj.stride).flatten(2).transpose(1, 2)
+
+
+class PosEmbed(nn.Module):
+    """FlexiPosEmbed with pos_embed_prefix=True (TOK:330-451): row 0 belongs to the cls token, rows 1.. to the patches."""
+
+    def __init__(self, n_tokens, embed_dim):
+        super().__init__()
+        self.pos_embed = nn.Parameter(torch.zeros(1, n_tokens, embed_dim))
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+
+
+class Block(nn.Module):
+    """MM:30-99 with fused_add_norm=True, residual_in_fp32=True, drop_path=0."""
+
+    def __init__(self, dim, mixer, eps):
+        super().__init__()
+        self.mixer = mixer
+        self.norm = RMSNorm(dim, eps=eps)
+
+    def forward(self, hidden_states, residual=None):
+        hidden_states, residual = rms_norm_fn(hidden_states, self.norm.weight, self.norm.bias, residual=residual,
+                                              prenorm=True, residual_in_fp32=True, eps=self.norm.eps)
+        return self.mixer(hidden_states), residual
+
+
+class AudioMamba(nn.Module):
+    def __init__(self, spectrogram_size=(128, 1024), patch_size=(16, 16), strides=(16, 16), depth=24, embed_dim=768,
+                 channels=1, num_classes=527, norm_epsilon=1e-5, bimamba_type="v1", if_devide_out=True,
+                 use_middle_cls_token=True, ssm_cfg=None, device=None, dtype=None):
+        super().__init__()
+        if tuple(patch_size) != tuple(strides):
+            raise NotImplementedError("overlapping patches are off the default path")
+        self.embed_dim = self.d_model = embed_dim
+        self.num_classes = num_classes
+        self.use_middle_cls_token = use_middle_cls_token
+        fdim = (spectrogram_size[0] - patch_size[0]) // strides[0] + 1
+        tdim = (spectrogram_size[1] - patch_size[1]) // strides[1] + 1
+        self.patch_grid_size = (fdim, tdim)
+        self.num_patches = fdim * tdim
+        self.num_tokens = 1
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        self.layers = nn.ModuleList([
+            Block(embed_dim, Mamba(embed_dim, layer_idx=i, bimamba_type=bimamba_type, if_devide_out=if_devide_out,
+                                   **(ssm_cfg or {})), norm_epsilon)
+            for i in range(depth)])
+        self.norm_f = RMSNorm(embed_dim, eps=norm_epsilon)
+        if isinstance(self.head, nn.Linear):                       # segm_init_weights, MM:179-184
+            nn.init.trunc_normal_(self.head.weight, std=0.02)
+            nn.init.zeros_(self.head.bias)
+        nn.init.trunc_normal_(self.cls_token, std=0.02)
+        self.apply(lambda m: _init_weights(m, depth))              # MM:146-176
+        self.patch_embed = PatchEmbed(tuple(patch_size), tuple(strides), channels, embed_dim)
+        self.pos_embed = PosEmbed(self.num_patches + self.num_tokens, embed_dim)
+        if device is not None or dtype is not None:
+            self.to(device=device, dtype=dtype)
+
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token"}
+
+    def tokens(self, x):
+        """(B, T, F) spectrogram -> (B, N+1, Dm) token sequence with the cls token in the middle (MM:509-541)."""
+        x = x.unsqueeze(1).transpose(2, 3)                         # B x 1 x F x T
+        x = self.patch_embed(x)                                    # token index = f * n_t + t
+        Bsz, Np, _ = x.shape
+        pe = self.pos_embed.pos_embed
+        pos = Np // 2 if self.use_middle_cls_token else 0
+        cls = (self.cls_token + pe[:, :1]).expand(Bsz, -1, -1)
+        x = x + pe[:, 1:]
+        return torch.cat((x[:, :pos], cls.to(x.dtype), x[:, pos:]), dim=1), pos
+
+    def forward_features(self, x):
+        hidden, pos = self.tokens(x)
+        residual = None
+        for layer in self.layers:
+            hidden, residual = layer(hidden, residual)
+        hidden = rms_norm_fn(hidden, self.norm_f.weight, self.norm_f.bias, eps=self.norm_f.eps, residual=residual,
+                             prenorm=False, residual_in_fp32=True)                            # MM:646-657
+        return hidden[:, pos]
+
+    def forward(self, x, return_features=False):
+        f = self.forward_features(x)
+        return f if return_features else self.head(f)
+
+
+def _init_weights(module, n_layer):
+    """MM:146-176: zero Linear biases (unless _no_reinit), rescale out_proj by 1/sqrt(n_layer)."""
+    if isinstance(module, nn.Linear) and module.bias is not None and not getattr(module.bias, "_no_reinit", False):
+        nn.init.zeros_(module.bias)
+    for name, p in module.named_parameters(recurse=False):
+        pass
+    if isinstance(module, Mamba):
+        nn.init.kaiming_uniform_(module.out_proj.weight, a=math.sqrt(5))
+        with torch.no_grad():
+            module.out_proj.weight /= math.sqrt(n_layer)
+
+
+def build_aum(size="base", **kw):
+    return AudioMamba(embed_dim=AUM_SIZES[size], **kw)

@@ -139,8 +139,16 @@ def _bc3(t):
     return t
 
 
+def _alloc(batch, dim, length, dtype, device, dmajor):
+    """(batch, dim, len) tensor; dmajor=True stores it channel-major [dim][batch][len] (the layout of the reference's
+    xz view, MS:185-189) so the projections on either side of the kernels are transpose-free GEMMs."""
+    if dmajor:
+        return torch.empty((dim, batch, length), dtype=dtype, device=device).permute(1, 0, 2)
+    return torch.empty((batch, dim, length), dtype=dtype, device=device)
+
+
 def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, reverse=False, A_b=None,
-             want_out_pre=False, want_last_state=False, lib=None):
+             want_out_pre=False, want_last_state=False, dmajor=False, lib=None):
     """selective_scan_cuda.fwd.  Returns (out, out_pre|None, last_state|None).  A_b != None: fused bidirectional."""
     lib = lib or get()
     B, C = _bc3(B), _bc3(C)
@@ -154,8 +162,8 @@ def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     if A.shape != (dim, dstate) or B.shape != (batch, dstate, length) or C.shape != B.shape:
         raise RuntimeError("shape mismatch in selective scan arguments")
     A, A_b, D, delta_bias = _f32c(A), _f32c(A_b), _f32c(D), _f32c(delta_bias)
-    out = torch.empty((batch, dim, length), dtype=u.dtype, device=u.device)
-    out_pre = torch.empty_like(out) if want_out_pre else None
+    out = _alloc(batch, dim, length, u.dtype, u.device, dmajor)
+    out_pre = _alloc(batch, dim, length, u.dtype, u.device, dmajor) if want_out_pre else None
     last = torch.empty((batch, dim, dstate), dtype=torch.float32, device=u.device) if want_last_state else None
     a = ScanFwdArgs()
     a.u, a.delta, a.z, a.B, a.C = _ptr(u), _ptr(delta), _ptr(z), _ptr(B), _ptr(C)
@@ -179,7 +187,7 @@ def C_byref(s):
 
 
 def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=False, reverse=False, A_b=None,
-             dz_out=None, lib=None):
+             dz_out=None, dmajor=False, lib=None):
     """selective_scan_cuda.bwd.  Returns dict(du, ddelta, dA, dA_b, dB, dC, dD, dz, ddelta_bias); dB/dC fp32
     (batch, dstate, len).  dz_out: optional preallocated (possibly strided) tensor written in place (SSI:537-545)."""
     lib = lib or get()
@@ -191,11 +199,11 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=
     dstate = A.shape[1]
     dev = u.device
     A, A_b, D, delta_bias = _f32c(A), _f32c(A_b), _f32c(D), _f32c(delta_bias)
-    du = torch.empty((batch, dim, length), dtype=u.dtype, device=dev)
-    ddelta = torch.empty_like(du)
+    du = _alloc(batch, dim, length, u.dtype, dev, dmajor)
+    ddelta = _alloc(batch, dim, length, u.dtype, dev, dmajor)
     dz = None
     if z is not None:
-        dz = dz_out if dz_out is not None else torch.empty_like(du)
+        dz = dz_out if dz_out is not None else _alloc(batch, dim, length, u.dtype, dev, dmajor)
         _unit(dz, "dz")
     f32 = dict(dtype=torch.float32, device=dev)
     dA = torch.zeros((dim, dstate), **f32)
@@ -229,7 +237,7 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=
     return dict(du=du, ddelta=ddelta, dA=dA, dA_b=dA_b, dB=dB, dC=dC, dD=dD, dz=dz, ddelta_bias=dbias)
 
 
-def conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, lib=None):
+def conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, dmajor=False, lib=None):
     """causal_conv1d_cuda.causal_conv1d_fwd(x, weight(dim,width), bias, None, silu) -> y (batch, dim, len) contiguous."""
     lib = lib or get()
     _unit(x, "x")
@@ -237,7 +245,7 @@ def conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, lib=None):
     batch, dim, length = x.shape
     weight = _f32c(weight.reshape(dim, -1))
     bias = _f32c(bias)
-    y = torch.empty((batch, dim, length), dtype=x.dtype, device=x.device)
+    y = _alloc(batch, dim, length, x.dtype, x.device, dmajor)
     a = ConvArgs()
     a.x, a.weight, a.bias, a.y = _ptr(x), _ptr(weight), _ptr(bias), _ptr(y)
     a.x_bs, a.x_ds, a.y_bs, a.y_ds = x.stride(0), x.stride(1), y.stride(0), y.stride(1)

@@ -1,0 +1,141 @@
+"""Drop-in for the reference's mamba_ssm.modules.mamba_simple.Mamba
+(/root/reference/vim-mamba_ssm/mamba_ssm/modules/mamba_simple.py = "MS"): same constructor signature (MS:35-56),
+parameter / sub-module names (the checkpoint contract: in_proj, conv1d, x_proj, dt_proj, out_proj, A_log, D, A_b_log,
+and for v2 conv1d_b, x_proj_b, dt_proj_b, D_b), initialisation (MS:94-127) and forward dispatch (MS:169-311).
+
+Differences: the kernels underneath are libaum_hip.so; Bi-Bi (v2) passes reverse=True instead of flipping xz and the
+result (MS:229-246); single-token decoding (`step`, inference caches, MS:313-458) is out of scope -- AuM never
+passes inference_params (MM:620-622).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from mamba_ssm.ops.selective_scan_interface import (bimamba_inner_fn, mamba_inner_fn, mamba_inner_fn_no_out_proj,
+                                                    selective_scan_fn)
+from causal_conv1d import causal_conv1d_fn
+
+
+class Mamba(nn.Module):
+    def __init__(self, d_model, d_state=16, d_conv=4, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
+                 dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, conv_bias=True, bias=False, use_fast_path=True,
+                 layer_idx=None, device=None, dtype=None, bimamba_type="none", if_devide_out=False,
+                 init_layer_scale=None):
+        fk = {"device": device, "dtype": dtype}
+        super().__init__()
+        self.d_model, self.d_state, self.d_conv, self.expand = d_model, d_state, d_conv, expand
+        self.d_inner = int(expand * d_model)
+        self.dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
+        self.use_fast_path, self.layer_idx = use_fast_path, layer_idx
+        self.bimamba_type, self.if_devide_out = bimamba_type, if_devide_out
+        self.init_layer_scale = init_layer_scale
+        if init_layer_scale is not None:
+            self.gamma = nn.Parameter(init_layer_scale * torch.ones(d_model), requires_grad=True)
+
+        self.in_proj = nn.Linear(d_model, self.d_inner * 2, bias=bias, **fk)
+        self.conv1d = nn.Conv1d(self.d_inner, self.d_inner, d_conv, groups=self.d_inner, padding=d_conv - 1,
+                                bias=conv_bias, **fk)
+        self.activation = "silu"
+        self.act = nn.SiLU()
+        self.x_proj = nn.Linear(self.d_inner, self.dt_rank + 2 * d_state, bias=False, **fk)
+        self.dt_proj = nn.Linear(self.dt_rank, self.d_inner, bias=True, **fk)
+        self._init_dt(self.dt_proj, dt_init, dt_scale, dt_min, dt_max, dt_init_floor, fk)
+        self.A_log = self._make_A_log(device)
+        self.D = nn.Parameter(torch.ones(self.d_inner, device=device))          # fp32 skip, MS:126
+        self.D._no_weight_decay = True
+
+        if bimamba_type in ("v1", "v2"):
+            self.A_b_log = self._make_A_log(device)                              # MS:130-147
+        if bimamba_type == "v2":                                                 # MS:149-165
+            self.conv1d_b = nn.Conv1d(self.d_inner, self.d_inner, d_conv, groups=self.d_inner, padding=d_conv - 1,
+                                      bias=conv_bias, **fk)
+            self.x_proj_b = nn.Linear(self.d_inner, self.dt_rank + 2 * d_state, bias=False, **fk)
+            self.dt_proj_b = nn.Linear(self.dt_rank, self.d_inner, bias=True, **fk)
+            self.D_b = nn.Parameter(torch.ones(self.d_inner, device=device))
+            self.D_b._no_weight_decay = True
+        self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias, **fk)
+
+    # ---- initialisers (MS:94-123) ----------------------------------------------------------------
+    def _init_dt(self, dt_proj, dt_init, dt_scale, dt_min, dt_max, dt_init_floor, fk):
+        std = self.dt_rank ** -0.5 * dt_scale
+        if dt_init == "constant":
+            nn.init.constant_(dt_proj.weight, std)
+        elif dt_init == "random":
+            nn.init.uniform_(dt_proj.weight, -std, std)
+        else:
+            raise NotImplementedError
+        # bias such that softplus(bias) is log-uniform in [dt_min, dt_max]
+        dt = torch.exp(torch.rand(self.d_inner, **fk) * (math.log(dt_max) - math.log(dt_min))
+                       + math.log(dt_min)).clamp(min=dt_init_floor)
+        with torch.no_grad():
+            dt_proj.bias.copy_(dt + torch.log(-torch.expm1(-dt)))
+        dt_proj.bias._no_reinit = True
+
+    def _make_A_log(self, device):
+        A = torch.arange(1, self.d_state + 1, dtype=torch.float32, device=device).repeat(self.d_inner, 1)
+        p = nn.Parameter(torch.log(A))       # S4D-real, kept in fp32
+        p._no_weight_decay = True
+        return p
+
+    # ---- forward (MS:169-311) ---------------------------------------------------------------------
+    def forward(self, hidden_states, inference_params=None):
+        if inference_params is not None:
+            raise NotImplementedError("inference caches / step() are out of scope (AuM passes None, MM:620-622)")
+        batch, seqlen, _ = hidden_states.shape
+        # matmul + transpose in one GEMM: xz is (B, 2E, L) stored channel-major, like MS:185-189
+        xz = torch.matmul(self.in_proj.weight, hidden_states.reshape(batch * seqlen, -1).t())
+        xz = xz.reshape(-1, batch, seqlen).permute(1, 0, 2)
+        if self.in_proj.bias is not None:
+            xz = xz + self.in_proj.bias.to(xz.dtype)[None, :, None]
+        A = -torch.exp(self.A_log.float())
+        if self.use_fast_path:
+            if self.bimamba_type == "v1":
+                A_b = -torch.exp(self.A_b_log.float())
+                out = bimamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
+                                       self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A, A_b, None,
+                                       None, self.D.float(), delta_bias=self.dt_proj.bias.float(),
+                                       delta_softplus=True)
+            elif self.bimamba_type == "v2":
+                A_b = -torch.exp(self.A_b_log.float())
+                out_f = mamba_inner_fn_no_out_proj(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
+                                                   self.dt_proj.weight, A, None, None, self.D.float(),
+                                                   delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
+                out_b = mamba_inner_fn_no_out_proj(xz, self.conv1d_b.weight, self.conv1d_b.bias,
+                                                   self.x_proj_b.weight, self.dt_proj_b.weight, A_b, None, None,
+                                                   self.D_b.float(), delta_bias=self.dt_proj_b.bias.float(),
+                                                   delta_softplus=True, reverse=True)
+                y = out_f + out_b                                          # (B, E, L), both channel-major
+                if self.if_devide_out:
+                    y = y / 2
+                E = y.shape[1]
+                y2 = y.permute(1, 0, 2).reshape(E, batch * seqlen)
+                out = torch.matmul(y2.t(), self.out_proj.weight.t().to(y2.dtype))
+                if self.out_proj.bias is not None:
+                    out = out + self.out_proj.bias.to(out.dtype)
+                out = out.reshape(batch, seqlen, -1)
+            else:
+                out = mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
+                                     self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A, None, None,
+                                     self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
+        else:       # un-fused composition of the same ops (MS:264-308)
+            x, z = xz.chunk(2, dim=1)
+            x = causal_conv1d_fn(x, self.conv1d.weight.reshape(self.d_inner, -1), self.conv1d.bias, self.activation)
+            x_dbl = self.x_proj(x.transpose(1, 2).reshape(batch * seqlen, -1))
+            dt, Bm, Cm = torch.split(x_dbl, [self.dt_rank, self.d_state, self.d_state], dim=-1)
+            dt = (self.dt_proj.weight.to(dt.dtype) @ dt.t()).reshape(-1, batch, seqlen).permute(1, 0, 2)
+            Bm = Bm.reshape(batch, seqlen, -1).transpose(1, 2).contiguous()
+            Cm = Cm.reshape(batch, seqlen, -1).transpose(1, 2).contiguous()
+            y = selective_scan_fn(x, dt.to(x.dtype), A, Bm.to(x.dtype), Cm.to(x.dtype), self.D.float(),
+                                  z=z.to(x.dtype), delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
+            out = self.out_proj(y.transpose(1, 2))
+        if self.init_layer_scale is not None:
+            out = out * self.gamma
+        return out
+
+    def step(self, *args, **kwargs):
+        raise NotImplementedError("autoregressive decode is out of scope for the AuM hot path (SURVEY 2.1 #2)")
+
+    def allocate_inference_cache(self, *args, **kwargs):
+        raise NotImplementedError("autoregressive decode is out of scope for the AuM hot path (SURVEY 2.1 #2)")

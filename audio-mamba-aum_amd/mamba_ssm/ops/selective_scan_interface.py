@@ -1,0 +1,387 @@
+"""Drop-in for the reference's mamba_ssm.ops.selective_scan_interface
+(/root/reference/vim-mamba_ssm/mamba_ssm/ops/selective_scan_interface.py = "SSI"): same public names, argument
+meaning and return conventions, backed by the hand-written gfx950 kernels of libaum_hip.so (aum_hip) instead of the
+selective_scan_cuda / causal_conv1d_cuda wheels.
+
+What is different by design (MI355X-first):
+  * the reverse direction of Fo-Bi / Bi-Bi is a flag on the kernels; none of the .flip([-1]) copies of SSI:504-507,
+    547-561 or MS:229-246 exist;
+  * Fo-Bi runs ONE direction-fused scan launch forward and ONE backward (inputs read once, out_z written once);
+  * activations between the kernels and the projections are stored channel-major [E][B][L] so x_proj / dt_proj /
+    out_proj and all their gradients are transpose-free GEMMs (hipBLASLt -> MFMA);
+  * nothing is recomputed in backward (SSI:218-219 drops conv1d_out/delta to save memory on 16-80 GB parts; on 288 GB
+    of HBM3E the recompute costs more than the bytes), so conv1d_out, delta, out_z and the pre-gate sum are saved;
+  * the backward returns the mathematically complete dz (autograd of bimamba_inner_ref); the reference's fused v1
+    backward drops the reverse-direction dz term at SSI:560/599.  AUM_REF_DZ_DROP=1 reproduces that for A/B runs.
+
+The *_ref functions are this package's own pure-PyTorch statements of the same arithmetic (public names of the
+reference module; usable on CPU).  They are NOT used by the fused path.
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+
+import aum_hip
+
+_custom_fwd = torch.amp.custom_fwd(device_type="cuda")
+_custom_bwd = torch.amp.custom_bwd(device_type="cuda")
+
+
+def _autocast_dtype():
+    return torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
+
+
+# =================================================================================================
+# selective_scan_fn  (SSI:14-83)
+# =================================================================================================
+class SelectiveScanFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                return_last_state=False, reverse=False):
+        if B.dim() < 3 or C.dim() < 3 or A.is_complex():
+            raise NotImplementedError("HIP selective scan implements real A with input-dependent B/C "
+                                      "(the only form Mamba/AuM uses, SSI:473-493)")
+        fix = lambda t: t if t is None or t.stride(-1) == 1 else t.contiguous()      # SSI:19-30
+        u, delta, B, C, z = fix(u), fix(delta), fix(B), fix(C), fix(z)
+        ctx.squeeze_B, ctx.squeeze_C = B.dim() == 3, C.dim() == 3
+        out, out_pre, last = aum_hip.scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, reverse,
+                                              want_out_pre=z is not None, want_last_state=return_last_state)
+        ctx.delta_softplus, ctx.reverse, ctx.has_z = delta_softplus, reverse, z is not None
+        ctx.save_for_backward(u, delta, A, B, C, D, z, delta_bias, out_pre)
+        if return_last_state:
+            ctx.mark_non_differentiable(last)       # SSI:79-82: no gradient through last_state
+            return out, last
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        u, delta, A, B, C, D, z, delta_bias, out_pre = ctx.saved_tensors
+        if dout.stride(-1) != 1:
+            dout = dout.contiguous()
+        g = aum_hip.scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout.to(u.dtype), out_pre, ctx.delta_softplus,
+                             ctx.reverse)
+        dB = g["dB"].to(B.dtype)
+        dC = g["dC"].to(C.dtype)
+        if not ctx.squeeze_B:
+            dB = dB.unsqueeze(1)
+        if not ctx.squeeze_C:
+            dC = dC.unsqueeze(1)
+        return (g["du"], g["ddelta"], g["dA"].to(A.dtype), dB, dC,
+                g["dD"].to(D.dtype) if D is not None else None,
+                g["dz"],
+                g["ddelta_bias"].to(delta_bias.dtype) if delta_bias is not None else None,
+                None, None, None)
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """if return_last_state is True, returns (out, last_state); last_state is (batch, dim, dstate) and carries no
+    gradient (SSI:77-83)."""
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state, False)
+
+
+def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                       return_last_state=False):
+    """Pure-PyTorch statement of the recurrence (same contract as SSI:86-152; real A, variable B/C as (B,N,L) or
+    (B,G,N,L)).  fp32 internal math, result cast back to u.dtype."""
+    dtype_in = u.dtype
+    u32, dt = u.float(), delta.float()
+    if delta_bias is not None:
+        dt = dt + delta_bias.float()[:, None]
+    if delta_softplus:
+        dt = F.softplus(dt)
+    batch, dim, L = u32.shape
+    N = A.shape[1]
+
+    def per_channel(M):      # -> (batch, dim, N, L)
+        M = M.float()
+        if M.dim() == 3:
+            return M[:, None].expand(batch, dim, N, L)
+        return M.repeat_interleave(dim // M.shape[1], dim=1)
+
+    Bf, Cf = per_channel(B), per_channel(C)
+    decay = torch.exp(dt[:, :, None, :] * A.float()[None, :, :, None])      # (batch, dim, N, L)
+    drive = (dt * u32)[:, :, None, :] * Bf
+    h = torch.zeros(batch, dim, N, dtype=torch.float32, device=u.device)
+    ys = torch.empty(batch, dim, L, dtype=torch.float32, device=u.device)
+    for t in range(L):
+        h = decay[..., t] * h + drive[..., t]
+        ys[..., t] = (h * Cf[..., t]).sum(-1)
+    out = ys if D is None else ys + u32 * D.float()[:, None]
+    if z is not None:
+        out = out * F.silu(z.float())
+    out = out.to(dtype_in)
+    return (out, h) if return_last_state else out
+
+
+# =================================================================================================
+# fused inner blocks  (SSI:155-633)
+# =================================================================================================
+def _dm2d(t):
+    """(B, E, L) channel-major tensor -> its [E, B*L] 2-D view (no copy)."""
+    Bsz, E, L = t.shape
+    return t.permute(1, 0, 2).reshape(E, Bsz * L)
+
+
+def _is_dmajor(t):
+    Bsz, E, L = t.shape
+    return t.stride(2) == 1 and t.stride(0) == L and t.stride(1) == Bsz * L
+
+
+def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                   out_proj_bias, A, A_b, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, reverse):
+    if A.is_complex():
+        raise NotImplementedError("real A only (SSI:502 asserts the same for the bidirectional path)")
+    act = _autocast_dtype()
+    if act is not None:                                    # SSI:452-457: only the projection weights are cast
+        x_proj_weight = x_proj_weight.to(act)
+        delta_proj_weight = delta_proj_weight.to(act)
+        out_proj_weight = out_proj_weight.to(act) if out_proj_weight is not None else None
+        out_proj_bias = out_proj_bias.to(act) if out_proj_bias is not None else None
+    if xz.stride(-1) != 1:
+        xz = xz.contiguous()
+    Bsz, two_e, L = xz.shape
+    E = two_e // 2
+    R = delta_proj_weight.shape[1]
+    N = A.shape[-1]
+    x, z = xz[:, :E], xz[:, E:]
+    conv_w = conv1d_weight.reshape(E, -1)
+    conv_out = aum_hip.conv1d_fwd(x, conv_w, conv1d_bias, True, reverse, dmajor=True)        # SSI:463
+    conv2d = _dm2d(conv_out)                                                                 # [E, BL]
+    x_dbl = torch.matmul(conv2d.t(), x_proj_weight.t().to(conv2d.dtype))                     # SSI:467  (BL, R+2N)
+    delta = torch.matmul(delta_proj_weight.to(x_dbl.dtype), x_dbl[:, :R].t())                # SSI:468  [E, BL]
+    delta = delta.reshape(E, Bsz, L).permute(1, 0, 2)
+    Bm = x_dbl[:, R:R + N]
+    Cm = x_dbl[:, R + N:R + 2 * N]
+    if B_proj_bias is not None:
+        Bm = Bm + B_proj_bias.to(Bm.dtype)
+    if C_proj_bias is not None:
+        Cm = Cm + C_proj_bias.to(Cm.dtype)
+    Bm = Bm.reshape(Bsz, L, N).transpose(1, 2).contiguous()                                  # SSI:479  (B, N, L)
+    Cm = Cm.reshape(Bsz, L, N).transpose(1, 2).contiguous()
+    bidir_fused = A_b is not None and L <= aum_hip.get().max_single_pass_len
+    if A_b is None or bidir_fused:
+        out_z, out_pre, _ = aum_hip.scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, reverse,
+                                             A_b=A_b, want_out_pre=True, dmajor=True)        # SSI:499-507, one launch
+        out_pre_b = None
+    else:   # long rows: two reverse-flag launches, still no flip copies
+        of, out_pre, _ = aum_hip.scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, False,
+                                          want_out_pre=True, dmajor=True)
+        ob, out_pre_b, _ = aum_hip.scan_fwd(conv_out, delta, A_b, Bm, Cm, D, z, delta_bias, delta_softplus, True,
+                                            want_out_pre=True, dmajor=True)
+        out_z = of + ob
+    ctx.delta_softplus, ctx.reverse, ctx.bidir_fused = delta_softplus, reverse, bidir_fused
+    ctx.has_out_proj = out_proj_weight is not None
+    ctx.out_proj_bias_is_None = out_proj_bias is None
+    ctx.B_proj_bias_is_None, ctx.C_proj_bias_is_None = B_proj_bias is None, C_proj_bias is None
+    ctx.save_for_backward(xz, conv_w, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight,
+                          conv_out, delta, A, A_b, Bm, Cm, D, delta_bias, out_pre, out_pre_b, out_z)
+    if out_proj_weight is None:
+        return out_z                                                                          # SSI:224
+    out = torch.matmul(_dm2d(out_z).t(), out_proj_weight.t())                                 # SSI:517
+    if out_proj_bias is not None:
+        out = out + out_proj_bias
+    return out.reshape(Bsz, L, -1)
+
+
+def _inner_backward(ctx, dout):
+    (xz, conv_w, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, A_b, Bm,
+     Cm, D, delta_bias, out_pre, out_pre_b, out_z) = ctx.saved_tensors
+    Bsz, two_e, L = xz.shape
+    E = two_e // 2
+    R = delta_proj_weight.shape[1]
+    N = A.shape[-1]
+    x, z = xz[:, :E], xz[:, E:]
+    dxz = torch.empty_like(xz)                      # same (channel-major) strides as xz      SSI:537
+    dx, dz = dxz[:, :E], dxz[:, E:]
+    dout_proj_weight = dout_proj_bias = None
+    if ctx.has_out_proj:
+        dout2 = dout.reshape(Bsz * L, -1).to(out_proj_weight.dtype)
+        dout_z = torch.matmul(out_proj_weight.t(), dout2.t()).reshape(E, Bsz, L).permute(1, 0, 2)   # SSI:540
+        dout_proj_weight = torch.matmul(dout2.t(), _dm2d(out_z).t())                                 # SSI:563
+        dout_proj_bias = dout2.sum(0) if not ctx.out_proj_bias_is_None else None
+    else:
+        dout_z = dout if dout.stride(-1) == 1 else dout.contiguous()
+        dout_z = dout_z.to(xz.dtype)
+    drop = os.environ.get("AUM_REF_DZ_DROP", "0") == "1" and A_b is not None
+    if A_b is None or ctx.bidir_fused:
+        g = aum_hip.scan_bwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_z, out_pre, ctx.delta_softplus,
+                             ctx.reverse, A_b=A_b, dz_out=dz, dmajor=True)                   # SSI:541-561, one launch
+    else:
+        g = aum_hip.scan_bwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_z, out_pre, ctx.delta_softplus, False,
+                             dz_out=dz, dmajor=True)
+        gb = aum_hip.scan_bwd(conv_out, delta, A_b, Bm, Cm, D, z, delta_bias, dout_z, out_pre_b, ctx.delta_softplus,
+                              True, dmajor=True)
+        for k in ("du", "ddelta", "dB", "dC", "dD", "ddelta_bias"):
+            g[k] = g[k] + gb[k]
+        if not drop:
+            dz.add_(gb["dz"])
+        g["dA_b"] = gb["dA"]
+    if drop and ctx.bidir_fused:
+        # reproduce SSI:560/599 for A/B runs against a CUDA run of the reference: keep only the forward term
+        gf = aum_hip.scan_bwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_z,
+                              aum_hip.scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, ctx.delta_softplus, False,
+                                               want_out_pre=True, dmajor=True)[1],
+                              ctx.delta_softplus, False, dz_out=dz, dmajor=True)
+        del gf
+    dconv_out, ddelta = g["du"], g["ddelta"]
+    dx_dbl = torch.empty_like(x_dbl)
+    dx_dbl3 = dx_dbl.view(Bsz, L, -1)
+    dx_dbl3[:, :, R:R + N].copy_(g["dB"].transpose(1, 2))                                    # SSI:570-574
+    dx_dbl3[:, :, R + N:R + 2 * N].copy_(g["dC"].transpose(1, 2))
+    dB_proj_bias = g["dB"].sum((0, 2)) if not ctx.B_proj_bias_is_None else None
+    dC_proj_bias = g["dC"].sum((0, 2)) if not ctx.C_proj_bias_is_None else None
+    ddelta2 = _dm2d(ddelta)                                                                   # [E, BL]
+    ddelta_proj_weight = torch.matmul(ddelta2, x_dbl[:, :R])                                  # SSI:586
+    dx_dbl[:, :R] = torch.matmul(ddelta2.t(), delta_proj_weight.to(ddelta2.dtype))            # SSI:587
+    dx_proj_weight = torch.matmul(dx_dbl.t(), _dm2d(conv_out).t())                            # SSI:589
+    dconv2 = _dm2d(dconv_out)
+    dconv2.addmm_(x_proj_weight.t().to(dx_dbl.dtype), dx_dbl.t())                             # SSI:590
+    _, dconv_w, dconv_b = aum_hip.conv1d_bwd(x, conv_w, conv1d_bias, dconv_out, True, ctx.reverse, dx_out=dx)  # SSI:594
+    return dict(dxz=dxz, dconv_w=dconv_w.reshape(E, 1, -1), dconv_b=dconv_b, dx_proj_w=dx_proj_weight,
+                ddt_proj_w=ddelta_proj_weight, dout_proj_w=dout_proj_weight, dout_proj_b=dout_proj_bias,
+                dA=g["dA"], dA_b=g.get("dA_b"), dD=g["dD"], ddelta_bias=g["ddelta_bias"],
+                dB_proj_bias=dB_proj_bias, dC_proj_bias=dC_proj_bias)
+
+
+def _check_variable_bc(B, C):
+    if B is not None or C is not None:
+        raise NotImplementedError("the fused HIP path implements input-dependent B and C (B=None, C=None), "
+                                  "the only form mamba_simple.Mamba passes (MS:208-209)")
+
+
+class MambaInnerFnNoOutProj(torch.autograd.Function):
+    """SSI:155-289.  Extra trailing argument `reverse` folds the xz.flip(-1)/out.flip(-1) sandwich of MS:229-246."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None, D=None,
+                delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True, checkpoint_lvl=1,
+                reverse=False):
+        _check_variable_bc(B, C)
+        return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, None, None, A,
+                              None, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, reverse)
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dout):
+        g = _inner_backward(ctx, dout)
+        return (g["dxz"], g["dconv_w"], g["dconv_b"], g["dx_proj_w"], g["ddt_proj_w"], g["dA"], None, None, g["dD"],
+                g["ddelta_bias"], g["dB_proj_bias"], g["dC_proj_bias"], None, None, None)
+
+
+class MambaInnerFn(torch.autograd.Function):
+    """SSI:292-434."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True,
+                checkpoint_lvl=1):
+        _check_variable_bc(B, C)
+        return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                              out_proj_bias, A, None, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, False)
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dout):
+        g = _inner_backward(ctx, dout)
+        return (g["dxz"], g["dconv_w"], g["dconv_b"], g["dx_proj_w"], g["ddt_proj_w"], g["dout_proj_w"],
+                g["dout_proj_b"], g["dA"], None, None, g["dD"], g["ddelta_bias"], g["dB_proj_bias"],
+                g["dC_proj_bias"], None, None)
+
+
+class BiMambaInnerFn(torch.autograd.Function):
+    """SSI:437-603 (Fo-Bi / bimamba_type='v1'): shared conv/x_proj/dt_proj, forward scan with A plus time-reversed
+    scan with A_b, summed, one out_proj."""
+
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+                delta_softplus=True, checkpoint_lvl=1):
+        _check_variable_bc(B, C)
+        return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                              out_proj_bias, A, A_b, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, False)
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dout):
+        g = _inner_backward(ctx, dout)
+        return (g["dxz"], g["dconv_w"], g["dconv_b"], g["dx_proj_w"], g["ddt_proj_w"], g["dout_proj_w"],
+                g["dout_proj_b"], g["dA"], g["dA_b"], None, None, g["dD"], g["ddelta_bias"], g["dB_proj_bias"],
+                g["dC_proj_bias"], None, None)
+
+
+def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                   A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+                   delta_softplus=True):
+    return MambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                              out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+
+
+def bimamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                     A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+                     delta_softplus=True):
+    return BiMambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                                out_proj_bias, A, A_b, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+
+
+def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,
+                               D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True,
+                               reverse=False):
+    """`reverse=True` (extension) == flip(fn(flip(xz)))) without the two copies."""
+    return MambaInnerFnNoOutProj.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D,
+                                       delta_bias, B_proj_bias, C_proj_bias, delta_softplus, 1, reverse)
+
+
+# =================================================================================================
+# pure-PyTorch statements of the inner blocks (public names of the reference module: SSI:636-709)
+# =================================================================================================
+def _conv_ref(x, weight, bias):
+    w = weight.reshape(weight.shape[0], -1)
+    y = F.conv1d(x, w[:, None, :], bias, padding=w.shape[1] - 1, groups=x.shape[1])[..., :x.shape[-1]]
+    return F.silu(y)
+
+
+def _inner_pre_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, N, B_proj_bias, C_proj_bias):
+    Bsz, two_e, L = xz.shape
+    E = two_e // 2
+    R = delta_proj_weight.shape[1]
+    x, z = xz[:, :E], xz[:, E:]
+    xc = _conv_ref(x, conv1d_weight, conv1d_bias)
+    proj = xc.transpose(1, 2).reshape(Bsz * L, E) @ x_proj_weight.t()
+    delta = (proj[:, :R] @ delta_proj_weight.t()).reshape(Bsz, L, E).transpose(1, 2)
+    Bm, Cm = proj[:, R:R + N], proj[:, R + N:R + 2 * N]
+    if B_proj_bias is not None:
+        Bm = Bm + B_proj_bias.to(Bm.dtype)
+    if C_proj_bias is not None:
+        Cm = Cm + C_proj_bias.to(Cm.dtype)
+    Bm = Bm.reshape(Bsz, L, N).transpose(1, 2).contiguous()
+    Cm = Cm.reshape(Bsz, L, N).transpose(1, 2).contiguous()
+    return xc, z, delta, Bm, Cm
+
+
+def mamba_inner_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                    A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+                    delta_softplus=True):
+    xc, z, delta, Bm, Cm = _inner_pre_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                                          A.shape[-1], B_proj_bias, C_proj_bias)
+    y = selective_scan_ref(xc, delta, A, Bm if B is None else B, Cm if C is None else C, D, z=z,
+                           delta_bias=delta_bias, delta_softplus=True)
+    return F.linear(y.transpose(1, 2), out_proj_weight, out_proj_bias)
+
+
+def bimamba_inner_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                      out_proj_bias, A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+                      C_proj_bias=None, delta_softplus=True):
+    xc, z, delta, Bm, Cm = _inner_pre_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                                          A.shape[-1], B_proj_bias, C_proj_bias)
+    Bm = Bm if B is None else B
+    Cm = Cm if C is None else C
+    y = selective_scan_ref(xc, delta, A, Bm, Cm, D, z=z, delta_bias=delta_bias, delta_softplus=True)
+    fl = lambda t: t.flip([-1])
+    y_b = selective_scan_ref(fl(xc), fl(delta), A_b, fl(Bm), fl(Cm), D, fl(z), delta_bias, delta_softplus=True)
+    return F.linear((y + fl(y_b)).transpose(1, 2), out_proj_weight, out_proj_bias)

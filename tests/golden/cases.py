@@ -153,3 +153,46 @@ def inner_inputs(name, mode, batch, d_model, length):
     p["xz"] = r.normal(0, 1, (batch, 2 * E, length)).astype(f)
     p["dout"] = r.normal(0, 1, (batch, length, d_model)).astype(f)
     return p
+
+
+# (name, bimamba_type, depth, embed_dim, spectrogram (F, T), num_classes, batch)
+MODEL_CASES = [
+    ("tiny_v1_d2", "v1", 2, 192, (128, 128), 35, 4),
+    ("tiny_v2_d2", "v2", 2, 192, (128, 128), 35, 2),
+    ("tiny_none_d2", "none", 2, 192, (128, 128), 35, 2),
+    ("d64_v1_d3_t256", "v1", 3, 64, (128, 256), 10, 2),
+]
+
+
+def model_state(shapes, tag):
+    """Seeded 'trained-like' values for every entry of an AudioMamba state dict ({key: shape})."""
+    r = _rng("model_" + tag)
+    f = np.float32
+    out = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        leaf = k.split(".")[-2] + "." + k.split(".")[-1] if "." in k else k
+        if k.endswith("A_log") or k.endswith("A_b_log"):
+            v = np.log(np.arange(1, shp[1] + 1, dtype=f)[None, :] * np.exp(r.normal(0, 0.1, shp)))
+        elif k.endswith(".D") or k.endswith(".D_b") or k.endswith("norm.weight") or k.endswith("norm_f.weight"):
+            v = 1.0 + r.normal(0, 0.1, shp)
+        elif "dt_proj" in k and k.endswith("bias"):
+            v = dt_bias_init(r, shp[0])
+        elif "conv1d" in k and k.endswith("weight"):
+            v = r.normal(0, 0.4, shp)
+        elif k.endswith("bias"):
+            v = r.normal(0, 0.1, shp)
+        elif k in ("cls_token", "pos_embed.pos_embed"):
+            v = r.normal(0, 0.5, shp)
+        else:   # dense weights: unit-variance outputs
+            fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else shp[0]
+            v = r.normal(0, 1, shp) / np.sqrt(fan_in)
+        out[k] = np.asarray(v, f)
+    return out
+
+
+def model_inputs(name, bimamba_type, depth, embed_dim, spec, num_classes, batch):
+    r = _rng("modelin_" + name)
+    f = np.float32
+    return dict(x=(0.5 * r.normal(0, 1, (batch, spec[1], spec[0]))).astype(f),
+                dlogits=r.normal(0, 1, (batch, num_classes)).astype(f))

@@ -189,5 +189,83 @@ def main():
     print("inner.npz", len(out))
 
 
+def import_reference_model(torch, ssi, ln):
+    """SURVEY 8c 'whole model on CPU': init-only helper stubs for timm/wget, reference model loaded from its file,
+    fused entry points rebound to the reference's own *_ref functions."""
+    import importlib.machinery
+    import importlib.util
+    import torch.nn as nn
+    timm, tm, tl = (types.ModuleType(n) for n in ("timm", "timm.models", "timm.models.layers"))
+
+    class DropPath(nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    tl.to_2tuple = lambda x: tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+    tl.DropPath = DropPath
+    tl.trunc_normal_ = lambda t, std=0.02, **kw: nn.init.trunc_normal_(t, std=std)
+    tl.lecun_normal_ = lambda t: nn.init.trunc_normal_(t, std=(1.0 / t[0].numel()) ** 0.5)
+    sys.modules.update({"timm": timm, "timm.models": tm, "timm.models.layers": tl, "wget": types.ModuleType("wget")})
+    for name, path in (("src", REF + "/src"), ("src.models", REF + "/src/models"), ("src.utilities", REF + "/src/utilities")):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None, is_package=True)
+        sys.modules[name] = m
+    import mamba_ssm.modules.mamba_simple as ms
+    ms.bimamba_inner_fn = ssi.bimamba_inner_ref
+    ms.mamba_inner_fn = ssi.mamba_inner_ref
+
+    def no_out_proj_ref(xz, cw, cb, xw, dw, A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+                        C_proj_bias=None, delta_softplus=True):
+        eye = torch.eye(xz.shape[1] // 2)
+        return ssi.mamba_inner_ref(xz, cw, cb, xw, dw, eye, None, A, B, C, D, delta_bias=delta_bias,
+                                   delta_softplus=True).transpose(1, 2)
+    ms.mamba_inner_fn_no_out_proj = no_out_proj_ref
+
+    def rms_ref(x, w, b, residual=None, prenorm=False, residual_in_fp32=False, eps=1e-6):
+        return ln.rms_norm_ref(x, w, b, residual=residual, eps=eps, prenorm=prenorm, upcast=True)
+    ln.rms_norm_fn = rms_ref
+    spec = importlib.util.spec_from_file_location("src.models.mamba_models", REF + "/src/models/mamba_models.py")
+    mm = importlib.util.module_from_spec(spec)
+    sys.modules["src.models.mamba_models"] = mm
+    spec.loader.exec_module(mm)
+    mm.rms_norm_fn = rms_ref
+    return mm
+
+
+def model_goldens(torch, ssi, ln):
+    import contextlib
+    import io
+    mm = import_reference_model(torch, ssi, ln)
+    out = {}
+    for case in cases.MODEL_CASES:
+        name, btype, depth, dim, spec, ncls, batch = case
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = mm.AudioMamba(spectrogram_size=spec, depth=depth, embed_dim=dim, num_classes=ncls,
+                                  bimamba_type=btype)
+        sd = model.state_dict()
+        vals = cases.model_state({k: tuple(v.shape) for k, v in sd.items()}, name)
+        model.load_state_dict({k: torch.tensor(v) for k, v in vals.items()})
+        d = cases.model_inputs(*case)
+        logits = model(torch.tensor(d["x"]))
+        (logits * torch.tensor(d["dlogits"])).sum().backward()
+        out[name + ".logits"] = npy(logits)
+        out[name + ".keys"] = np.array(sorted(sd.keys()))
+        for k, p in model.named_parameters():
+            g = npy(p.grad)
+            out[name + ".gnorm." + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            if p.numel() <= 4096:
+                out[name + ".grad." + k] = g
+        out[name + ".checksum"] = cases.checksum(dict(vals, **d))
+    np.savez_compressed(os.path.join(HERE, "model.npz"), **out)
+    print("model.npz", len(out))
+
+
 if __name__ == "__main__":
     main()
+    if os.path.isdir(REF) and "--no-model" not in sys.argv:
+        torch_, ssi_, ln_, _ = import_reference()
+        model_goldens(torch_, ssi_, ln_)

@@ -1,0 +1,213 @@
+"""Host logic of the drop-in package (mamba_ssm / causal_conv1d / aum) on CPU.
+
+The product path has no CPU implementation, so for these tests the tests-only lane-array build of the kernel sources
+(tests/emu) is injected where libaum_hip.so would be.  What is checked here is the Python side: autograd wiring, layouts
+(channel-major tensors, strided dxz views), autocast rules, state-dict keys and dispatch -- against the golden vectors
+produced by the reference's own code (tests/golden/*.npz)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import aum_hip
+import cases
+from conftest import load_golden, rel_err
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emu_as_product():
+    import build_emu
+    old = aum_hip._product
+    aum_hip._product = aum_hip.Lib(build_emu.build(), host=True)
+    yield
+    aum_hip._product = old
+
+
+def P(a, grad=True):
+    return None if a is None else torch.tensor(np.asarray(a)).requires_grad_(grad)
+
+
+@pytest.mark.parametrize("case", [c for c in cases.SCAN_CASES if c[0] in ("l65", "l65_plain", "l65_noz", "l130_n4", "l2049")],
+                         ids=lambda c: c[0])
+def test_selective_scan_fn_autograd_vs_reference(case):
+    from mamba_ssm.ops.selective_scan_interface import selective_scan_fn, selective_scan_ref
+    g = load_golden("scan")
+    name, softplus = case[0], case[8]
+    d = cases.scan_inputs(*case)
+    t = {k: P(d[k]) for k in ("u", "delta", "A", "D", "z", "delta_bias")}
+    Bm, Cm = P(d["B"][:, None]), P(d["C"][:, None])
+    out, last = selective_scan_fn(t["u"], t["delta"], t["A"], Bm, Cm, t["D"], t["z"], t["delta_bias"], softplus, True)
+    (out * torch.tensor(d["dout"])).sum().backward()
+    assert rel_err(out.detach().numpy(), g[name + ".f32.out"]) < 1e-4
+    assert rel_err(last.numpy(), g[name + ".f32.last_state"]) < 1e-4
+    for k, v in (("du", t["u"]), ("ddelta", t["delta"]), ("dA", t["A"]), ("dB", Bm), ("dC", Cm), ("dD", t["D"]),
+                 ("dz", t["z"]), ("ddelta_bias", t["delta_bias"])):
+        if v is not None:
+            got = v.grad.numpy()
+            got = got[:, 0] if k in ("dB", "dC") else got
+            assert rel_err(got, g[f"{name}.f32.{k}"]) < 4e-4, k
+    # the package's own pure-PyTorch statement agrees with the reference's output as well
+    with torch.no_grad():
+        ref = selective_scan_ref(t["u"], t["delta"], t["A"], Bm, Cm, t["D"], t["z"], t["delta_bias"], softplus)
+    assert rel_err(ref.numpy(), g[name + ".f32.out"]) < 2e-5
+
+
+@pytest.mark.parametrize("case", cases.NORM_CASES, ids=lambda c: c[0])
+def test_rms_norm_fn_vs_reference(case):
+    from mamba_ssm.ops.triton.layernorm import rms_norm_fn, rms_norm_ref
+    g = load_golden("norm")
+    name, lead, cols, has_res, prenorm = case
+    d = cases.norm_inputs(*case)
+    x, res, w = P(d["x"]), P(d["residual"]), P(d["weight"])
+    r = rms_norm_fn(x, w, None, residual=res, prenorm=prenorm, residual_in_fp32=True, eps=1e-5)
+    y, res_out = r if prenorm else (r, None)
+    loss = (y * torch.tensor(d["dy"])).sum()
+    if prenorm:
+        loss = loss + (res_out * torch.tensor(d["dres"])).sum()
+    loss.backward()
+    assert rel_err(y.detach().numpy(), g[name + ".y"]) < 1e-5
+    assert rel_err(x.grad.numpy(), g[name + ".dx"]) < 1e-5
+    assert rel_err(w.grad.numpy(), g[name + ".dweight"]) < 1e-5
+    if has_res:
+        assert rel_err(res.grad.numpy(), g[name + ".dresidual"]) < 1e-5
+    with torch.no_grad():
+        assert rel_err(rms_norm_ref(x, w, None, residual=res, eps=1e-5, upcast=True).numpy(), g[name + ".y"]) < 1e-5
+
+
+def _run_inner(case, dmajor_xz):
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    name, mode, batch, d_model, length = case
+    p = cases.inner_inputs(*case)
+    t = {k: P(v) for k, v in p.items() if k != "dout"}
+    xz_leaf = t["xz"]
+    xz = xz_leaf
+    if dmajor_xz:       # the layout Mamba.forward produces (MS:185-189)
+        xz = xz_leaf.permute(1, 0, 2).contiguous().permute(1, 0, 2)
+    if mode == "v1":
+        o = ssi.bimamba_inner_fn(xz, t["conv_w"], t["conv_b"], t["x_proj_w"], t["dt_proj_w"], t["out_proj_w"], None,
+                                 t["A"], t["A_b"], None, None, t["D"], delta_bias=t["dt_bias"], delta_softplus=True)
+    elif mode == "none":
+        o = ssi.mamba_inner_fn(xz, t["conv_w"], t["conv_b"], t["x_proj_w"], t["dt_proj_w"], t["out_proj_w"], None,
+                               t["A"], None, None, t["D"], delta_bias=t["dt_bias"], delta_softplus=True)
+    else:
+        of = ssi.mamba_inner_fn_no_out_proj(xz, t["conv_w"], t["conv_b"], t["x_proj_w"], t["dt_proj_w"], t["A"], None,
+                                            None, t["D"], delta_bias=t["dt_bias"], delta_softplus=True)
+        ob = ssi.mamba_inner_fn_no_out_proj(xz, t["conv_w_b"], t["conv_b_b"], t["x_proj_w_b"], t["dt_proj_w_b"],
+                                            t["A_b"], None, None, t["D_b"], delta_bias=t["dt_bias_b"],
+                                            delta_softplus=True, reverse=True)
+        o = torch.nn.functional.linear(((of + ob) / 2).transpose(1, 2), t["out_proj_w"], None)
+    (o * torch.tensor(p["dout"])).sum().backward()
+    return o, t
+
+
+@pytest.mark.parametrize("case", cases.INNER_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("dmajor_xz", [False, True])
+def test_inner_fns_vs_reference(case, dmajor_xz):
+    g = load_golden("inner")
+    name = case[0]
+    o, t = _run_inner(case, dmajor_xz)
+    assert rel_err(o.detach().numpy(), g[name + ".out"]) < 1e-4
+    keys = [k[len(name) + 3:] for k in g if k.startswith(name + ".d_")]
+    assert len(keys) >= 9
+    for k in keys:
+        assert t[k].grad is not None, k
+        assert rel_err(t[k].grad.numpy(), g[f"{name}.d_{k}"]) < 5e-4, k
+
+
+def test_inner_ref_functions_match_reference():
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    g = load_golden("inner")
+    case = cases.INNER_CASES[0]
+    p = cases.inner_inputs(*case)
+    t = {k: P(v, False) for k, v in p.items()}
+    o = ssi.bimamba_inner_ref(t["xz"], t["conv_w"], t["conv_b"], t["x_proj_w"], t["dt_proj_w"], t["out_proj_w"], None,
+                              t["A"], t["A_b"], None, None, t["D"], delta_bias=t["dt_bias"], delta_softplus=True)
+    assert rel_err(o.numpy(), g[case[0] + ".out"]) < 2e-5
+    case = cases.INNER_CASES[3]
+    p = cases.inner_inputs(*case)
+    t = {k: P(v, False) for k, v in p.items()}
+    o = ssi.mamba_inner_ref(t["xz"], t["conv_w"], t["conv_b"], t["x_proj_w"], t["dt_proj_w"], t["out_proj_w"], None,
+                            t["A"], None, None, t["D"], delta_bias=t["dt_bias"], delta_softplus=True)
+    assert rel_err(o.numpy(), g[case[0] + ".out"]) < 2e-5
+
+
+def test_mamba_module_contract():
+    """Constructor defaults, parameter names/shapes (checkpoint contract), init attributes (MS:113,123,127)."""
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(0)
+    m = Mamba(192, bimamba_type="v2", if_devide_out=True)
+    sd = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert sd == {
+        "A_log": (384, 16), "D": (384,), "A_b_log": (384, 16), "D_b": (384,), "in_proj.weight": (768, 192),
+        "conv1d.weight": (384, 1, 4), "conv1d.bias": (384,), "x_proj.weight": (44, 384),
+        "dt_proj.weight": (384, 12), "dt_proj.bias": (384,), "conv1d_b.weight": (384, 1, 4),
+        "conv1d_b.bias": (384,), "x_proj_b.weight": (44, 384), "dt_proj_b.weight": (384, 12),
+        "dt_proj_b.bias": (384,), "out_proj.weight": (192, 384)}
+    assert m.dt_proj.bias._no_reinit and m.A_log._no_weight_decay and m.D._no_weight_decay
+    sp = torch.nn.functional.softplus(m.dt_proj.bias)
+    assert sp.min() >= 1e-3 * 0.99 and sp.max() <= 0.1 * 1.01          # MS:104-111
+    assert torch.allclose(m.A_log[7], torch.log(torch.arange(1, 17.0)))
+    assert m.dt_proj.weight.abs().max() <= 12 ** -0.5
+    y = m(torch.randn(2, 17, 192))
+    assert y.shape == (2, 17, 192)
+    with pytest.raises(NotImplementedError):
+        m(torch.randn(2, 17, 192), inference_params=object())
+
+
+@pytest.mark.parametrize("case", cases.MODEL_CASES, ids=lambda c: c[0])
+def test_audio_mamba_vs_reference_model(case):
+    """Whole-model parity with the reference's AudioMamba (run on CPU through its own *_ref functions when the
+    fixture was generated): identical state-dict keys, logits and every parameter gradient."""
+    from aum.model import AudioMamba
+    g = load_golden("model")
+    name, btype, depth, dim, spec, ncls, batch = case
+    model = AudioMamba(spectrogram_size=spec, depth=depth, embed_dim=dim, num_classes=ncls, bimamba_type=btype)
+    sd = model.state_dict()
+    assert sorted(sd.keys()) == list(g[name + ".keys"])
+    vals = cases.model_state({k: tuple(v.shape) for k, v in sd.items()}, name)
+    d = cases.model_inputs(*case)
+    assert np.isclose(cases.checksum(dict(vals, **d)), g[name + ".checksum"], rtol=1e-12)
+    model.load_state_dict({k: torch.tensor(v) for k, v in vals.items()})
+    logits = model(torch.tensor(d["x"]))
+    (logits * torch.tensor(d["dlogits"])).sum().backward()
+    assert rel_err(logits.detach().numpy(), g[name + ".logits"]) < 1e-3          # north_star fp32 bar
+    for k, p_ in model.named_parameters():
+        gn = float(np.sqrt((p_.grad.double().numpy() ** 2).sum()))
+        ref = float(g[f"{name}.gnorm.{k}"])
+        assert abs(gn - ref) <= 2e-3 * max(ref, 1e-6), (k, gn, ref)
+        if f"{name}.grad.{k}" in g:
+            assert rel_err(p_.grad.numpy(), g[f"{name}.grad.{k}"]) < 2e-3, k
+
+
+def test_unfused_path_matches_fused():
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(1)
+    m = Mamba(32, bimamba_type="none")
+    x = torch.randn(2, 70, 32)
+    y1 = m(x)
+    m.use_fast_path = False
+    y2 = m(x)
+    assert rel_err(y2.detach().numpy(), y1.detach().numpy()) < 1e-5
+
+
+def test_bf16_module_runs_and_matches_fp32():
+    """A module converted to bf16 end to end (weights included) runs through the same kernels (fp32 parameter
+    arguments are converted at the ABI boundary) and stays within the bf16 bar of the fp32 run.  The autocast rules
+    (SSI:452-457) need a CUDA autocast context and are tested in test_gpu_model.py."""
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(2)
+    m = Mamba(32, bimamba_type="v1")
+    x = torch.randn(2, 65, 32)
+    y32 = m(x).detach()
+    mb = Mamba(32, bimamba_type="v1")
+    mb.load_state_dict(m.state_dict())
+    mb = mb.to(torch.bfloat16)
+    yb = mb(x.to(torch.bfloat16))
+    yb.float().sum().backward()
+    for n, p_ in mb.named_parameters():
+        assert p_.grad is not None and p_.grad.dtype == torch.bfloat16, n
+    assert rel_err(yb.float().detach().numpy(), y32.numpy()) < 5e-2
