@@ -117,6 +117,41 @@ def _chk(rc, what):
         raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)}")
 
 
+class LaunchTimer:
+    """Optional per-launch timing with HIP events recorded on the stream the kernels are enqueued on (torch's current
+    stream).  bench.py enables it to compute the live roofline numbers; off by default (zero overhead)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}       # name -> list of (start_event, end_event, meta)
+
+    def reset(self):
+        self.records = {}
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / max(len(ms), 1), "meta": evs[-1][2] if evs else None}
+        return out
+
+
+timer = LaunchTimer()
+
+
+def _launch(fn, args, stream_tensor, lib, name, meta=None):
+    if timer.enabled and not lib.host:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(C_byref(args), lib.stream(stream_tensor))
+        b.record()
+        timer.records.setdefault(name, []).append((a, b, meta))
+    else:
+        rc = fn(C_byref(args), lib.stream(stream_tensor))
+    _chk(rc, name)
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -178,7 +213,8 @@ def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     a.out_bs, a.out_ds = out.stride(0), out.stride(1)
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
     a.flags = (SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0)
-    _chk(lib.c.aum_selective_scan_fwd(C_byref(a), lib.stream(u)), "aum_selective_scan_fwd")
+    _launch(lib.c.aum_selective_scan_fwd, a, u, lib, "scan_fwd_bidir" if A_b is not None else "scan_fwd",
+            (batch, dim, length, dstate, u.element_size(), want_out_pre))
     return out, out_pre, last
 
 
@@ -233,7 +269,8 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=
     a.dB_bs, a.dB_ns, a.dC_bs, a.dC_ns = dB.stride(0), dB.stride(1), dC.stride(0), dC.stride(1)
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
     a.flags = (SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0)
-    _chk(lib.c.aum_selective_scan_bwd(C_byref(a), lib.stream(u)), "aum_selective_scan_bwd")
+    _launch(lib.c.aum_selective_scan_bwd, a, u, lib, "scan_bwd_bidir" if A_b is not None else "scan_bwd",
+            (batch, dim, length, dstate, u.element_size(), True))
     return dict(du=du, ddelta=ddelta, dA=dA, dA_b=dA_b, dB=dB, dC=dC, dD=dD, dz=dz, ddelta_bias=dbias)
 
 
@@ -251,7 +288,7 @@ def conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, dmajor=False, lib
     a.x_bs, a.x_ds, a.y_bs, a.y_ds = x.stride(0), x.stride(1), y.stride(0), y.stride(1)
     a.batch, a.dim, a.len, a.width, a.dtype = batch, dim, length, weight.shape[1], _DT[x.dtype]
     a.flags = (CONV_SILU if silu else 0) | (CONV_REVERSE if reverse else 0)
-    _chk(lib.c.aum_causal_conv1d_fwd(C_byref(a), lib.stream(x)), "aum_causal_conv1d_fwd")
+    _launch(lib.c.aum_causal_conv1d_fwd, a, x, lib, "conv_fwd", (batch, dim, length, x.element_size()))
     return y
 
 
@@ -276,7 +313,7 @@ def conv1d_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, lib=N
     a.dx_bs, a.dx_ds = dx.stride(0), dx.stride(1)
     a.batch, a.dim, a.len, a.width, a.dtype = batch, dim, length, weight.shape[1], _DT[x.dtype]
     a.flags = (CONV_SILU if silu else 0) | (CONV_REVERSE if reverse else 0)
-    _chk(lib.c.aum_causal_conv1d_bwd(C_byref(a), lib.stream(x)), "aum_causal_conv1d_bwd")
+    _launch(lib.c.aum_causal_conv1d_bwd, a, x, lib, "conv_bwd", (batch, dim, length, x.element_size()))
     return dx, dw, db
 
 
@@ -305,7 +342,7 @@ def rmsnorm_fwd(x, weight, residual=None, eps=1e-5, residual_dtype=None, lib=Non
     a.eps, a.rows, a.cols = eps, rows, cols
     a.x_dtype = a.y_dtype = _DT[x.dtype]
     a.res_dtype = _DT[residual_dtype] if need_res_out else _DT[x.dtype]
-    _chk(lib.c.aum_rmsnorm_fwd(C_byref(a), lib.stream(x)), "aum_rmsnorm_fwd")
+    _launch(lib.c.aum_rmsnorm_fwd, a, x, lib, "rmsnorm_fwd", (rows, cols, x.element_size()))
     return y, rstd, (res_out if res_out is not None else x)
 
 
@@ -334,7 +371,7 @@ def rmsnorm_bwd(dy, x_saved, weight, rstd, dresidual=None, has_residual=False, x
     a.rows, a.cols = rows, cols
     a.x_dtype = a.y_dtype = _DT[x_dtype]
     a.res_dtype = _DT[x_saved.dtype]
-    _chk(lib.c.aum_rmsnorm_bwd(C_byref(a), lib.stream(dy)), "aum_rmsnorm_bwd")
+    _launch(lib.c.aum_rmsnorm_bwd, a, dy, lib, "rmsnorm_bwd", (rows, cols, dy.element_size()))
     dw = dwp.sum(0)
     if has_residual and dres_in is None:
         dres_in = dx

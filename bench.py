@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- clips/s for AuM-Base (d_model=768, 24 Fo-Bi blocks, d_state=16) forward + backward + Adam step on
+synthetic 128-mel x 1024-frame spectrograms (BASELINE.json metric; configs[2] at N=1, configs[3] per-GPU batch 64 with
+DDP over RCCL at N>1), plus the live roofline of the dominant kernel and the CPU baseline (oracle on the host cores).
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one optimizer step on one per-GPU batch: fwd (bf16 autocast) -> BCE loss -> bwd (+ DDP bucketed all-reduce
+overlapped with backward) -> Adam.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "audio-mamba-aum_amd"))
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def scan_alg_bytes(meta, backward):
+    """Algorithmic bytes of one scan launch (DESIGN.md "scan"): activation tensors read/written once,
+    B/C once, fp32 dB/dC once."""
+    batch, dim, length, dstate, s, extra = meta
+    T = batch * dim * length
+    bc = 2 * batch * dstate * length * s
+    if not backward:
+        return (4 + (1 if extra else 0)) * T * s + bc              # u, delta, z, out (+ out_pre)
+    return 8 * T * s + bc + 2 * batch * dstate * length * 4         # u, delta, z, dout, out_pre, du, ddelta, dz; dB, dC
+
+
+def cpu_baseline(target_seconds=20.0):
+    """The oracle (C restatement of the reference's *_ref arithmetic, oracle/) timed on the host cores: one AuM-Base
+    Fo-Bi block (fused add+RMSNorm, in_proj, conv, x/dt proj, two scans, out_proj) forward + backward on a few clips,
+    scaled by the 24 blocks of the model.  Reported, never a target."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from oracle import oracle as O
+    import cases
+    cores = O.num_threads()
+    Dm, L = 768, 513
+    Bc = max(2, min(cores, 8))
+    r = np.random.default_rng(0)
+    p = cases.inner_params(r, Dm)
+    hidden = r.normal(0, 1, (Bc, L, Dm)).astype(np.float32)
+    resid = r.normal(0, 1, (Bc, L, Dm)).astype(np.float32)
+    w_norm = np.ones(Dm, np.float32)
+    w_in = (r.normal(0, 1, (4 * Dm, Dm)) / np.sqrt(Dm)).astype(np.float32)
+    dout = r.normal(0, 1, (Bc, L, Dm)).astype(np.float32)
+
+    def block():
+        n = O.rmsnorm_fwd(hidden, w_norm, None, resid, 1e-5, "f32")
+        xz = (n["y"].reshape(Bc * L, Dm) @ w_in.T).reshape(Bc, L, 4 * Dm).transpose(0, 2, 1)
+        xz = np.ascontiguousarray(xz)
+        st = O.inner_fwd(xz, p["conv_w"], p["conv_b"], p["x_proj_w"], p["dt_proj_w"], p["out_proj_w"], None, p["A"],
+                         p["D"], p["dt_bias"], p["A_b"], "f32")
+        g = O.inner_full_bwd(st, dout, xz, p["conv_w"], p["conv_b"], p["x_proj_w"], p["dt_proj_w"], p["out_proj_w"],
+                             None, p["A"], p["D"], p["dt_bias"], p["A_b"], "f32")
+        dn = g["dxz"].transpose(0, 2, 1).reshape(Bc * L, 4 * Dm) @ w_in
+        _ = n["y"].reshape(Bc * L, Dm).T @ g["dxz"].transpose(0, 2, 1).reshape(Bc * L, 4 * Dm)
+        O.rmsnorm_bwd(dn.reshape(Bc, L, Dm), n["residual_out"], w_norm, n["rstd"], dout, False, "f32")
+
+    t0 = time.time()
+    block()
+    t1 = time.time() - t0
+    reps = max(1, min(5, int(target_seconds / max(t1, 1e-3)) - 1))
+    ts = []
+    for _ in range(reps):
+        t0 = time.time()
+        block()
+        ts.append(time.time() - t0)
+    t_block = sorted(ts)[len(ts) // 2]
+    return {"value": round(Bc / (24 * t_block), 5), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (C, OpenMP x{cores}, fp32): 1 of 24 AuM-Base Fo-Bi blocks fwd+bwd on {Bc} clips "
+                      f"(L=513), median of {reps} runs = {t_block:.2f} s/block, scaled x24 blocks"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE.json config 3/4: 64)")
+    ap.add_argument("--size", default="base")
+    ap.add_argument("--depth", type=int, default=24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import aum_hip
+    from aum.model import build_aum
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm (xGMI within the node)
+    aum_hip.get()      # fail loudly now if the HIP extension is missing
+
+    torch.manual_seed(3949 + rank)
+    n_class = 527
+    model = build_aum(args.size, depth=args.depth, num_classes=n_class, bimamba_type="v1").to(dev)
+    n_params = sum(p.numel() for p in model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-7, betas=(0.95, 0.999), eps=1e-8,
+                           fused=True)                                         # TT:32-34
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True,
+                                                        bucket_cap_mb=64, broadcast_buffers=False)
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(args.batch, 1024, 128, device=dev, generator=g) * 0.5       # SURVEY 8d synthetic spectrograms
+    y = torch.zeros(args.batch, n_class, device=dev)
+    y.scatter_(1, torch.randint(0, n_class, (args.batch, 2), device=dev, generator=g), 1.0)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits = net(x)
+            loss = loss_fn(logits.float(), y)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    aum_hip.timer.reset()
+    aum_hip.timer.enabled = True
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    aum_hip.timer.enabled = False
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+    ktimes = aum_hip.timer.summary()
+
+    if rank == 0:
+        clips = world * args.batch * args.steps
+        # dominant kernel = largest share of summed launch time among the hand-written kernels
+        tot = {k: v["avg_ms"] * v["launches"] for k, v in ktimes.items()}
+        dom = max(tot, key=tot.get)
+        rec = ktimes[dom]
+        alg = scan_alg_bytes(rec["meta"], "bwd" in dom) if dom.startswith("scan") else None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
+                "traffic": None, "avg_launch_ms": round(rec["avg_ms"], 4), "launches_timed": rec["launches"]}
+        if alg is not None:
+            roof["alg_bytes_per_launch"] = alg
+            roof["achieved"] = round(alg / (rec["avg_ms"] * 1e-3) / 1e9, 1)
+            roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBPS, 4)
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            roof["traffic"] = json.load(open(pmc)).get(dom)
+        out = {
+            "metric": "clips/sec/node AuM-Base 128x1024 fwd+bwd", "value": round(clips / elapsed, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"AuM-{args.size.capitalize()} (d_model={model.embed_dim}, {args.depth} Fo-Bi blocks, "
+                                   f"d_state=16, {n_params / 1e6:.1f}M params) 128-mel x 1024-frame clips, L=513 tokens, "
+                                   "fwd+bwd+Adam, bf16 autocast / fp32 master weights",
+                       "per_gpu_batch": args.batch, "global_batch": world * args.batch,
+                       "parallelism": f"dp{world}" + (" (DDP, RCCL all-reduce overlapped with backward)" if world > 1 else "")},
+            "roofline": roof,
+            "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in sorted(tot.items())},
+            "final_loss": round(final_loss, 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
