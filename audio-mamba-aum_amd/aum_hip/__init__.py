@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libaum_hip.so")
 
 AUM_F32, AUM_BF16, AUM_F16 = 0, 1, 2
-SCAN_SOFTPLUS, SCAN_REVERSE = 1, 2
+SCAN_SOFTPLUS, SCAN_REVERSE, SCAN_GENERIC = 1, 2, 4
 CONV_SILU, CONV_REVERSE = 1, 2
 _DT = {torch.float32: AUM_F32, torch.bfloat16: AUM_BF16, torch.float16: AUM_F16}
 _ERR = {-1: "AUM_E_NULL", -2: "AUM_E_SHAPE", -3: "AUM_E_DTYPE", -4: "AUM_E_UNSUPPORTED", -5: "AUM_E_WORKSPACE",
@@ -183,7 +183,7 @@ def _alloc(batch, dim, length, dtype, device, dmajor):
 
 
 def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, reverse=False, A_b=None,
-             want_out_pre=False, want_last_state=False, dmajor=False, lib=None):
+             want_out_pre=False, want_last_state=False, dmajor=False, generic=False, lib=None):
     """selective_scan_cuda.fwd.  Returns (out, out_pre|None, last_state|None).  A_b != None: fused bidirectional."""
     lib = lib or get()
     B, C = _bc3(B), _bc3(C)
@@ -212,7 +212,8 @@ def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     a.C_bs, a.C_ns = C.stride(0), C.stride(1)
     a.out_bs, a.out_ds = out.stride(0), out.stride(1)
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
-    a.flags = (SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0)
+    a.flags = ((SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0) | (SCAN_GENERIC if generic else 0)
+               | (int(os.environ.get('AUM_ABLATE', '0')) << 16))   # AUM_ABLATE: kernel-ablation bits for tools/kbench.py only
     _launch(lib.c.aum_selective_scan_fwd, a, u, lib, "scan_fwd_bidir" if A_b is not None else "scan_fwd",
             (batch, dim, length, dstate, u.element_size(), want_out_pre))
     return out, out_pre, last
@@ -223,7 +224,7 @@ def C_byref(s):
 
 
 def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=False, reverse=False, A_b=None,
-             dz_out=None, dmajor=False, lib=None):
+             dz_out=None, dmajor=False, generic=False, lib=None):
     """selective_scan_cuda.bwd.  Returns dict(du, ddelta, dA, dA_b, dB, dC, dD, dz, ddelta_bias); dB/dC fp32
     (batch, dstate, len).  dz_out: optional preallocated (possibly strided) tensor written in place (SSI:537-545)."""
     lib = lib or get()
@@ -268,7 +269,8 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=
     a.ddelta_bs, a.ddelta_ds = ddelta.stride(0), ddelta.stride(1)
     a.dB_bs, a.dB_ns, a.dC_bs, a.dC_ns = dB.stride(0), dB.stride(1), dC.stride(0), dC.stride(1)
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
-    a.flags = (SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0)
+    a.flags = ((SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0) | (SCAN_GENERIC if generic else 0)
+               | (int(os.environ.get('AUM_ABLATE', '0')) << 16))   # AUM_ABLATE: kernel-ablation bits for tools/kbench.py only
     _launch(lib.c.aum_selective_scan_bwd, a, u, lib, "scan_bwd_bidir" if A_b is not None else "scan_bwd",
             (batch, dim, length, dstate, u.element_size(), True))
     return dict(du=du, ddelta=ddelta, dA=dA, dA_b=dA_b, dB=dB, dC=dC, dD=dD, dz=dz, ddelta_bias=dbias)

@@ -27,6 +27,11 @@
 #define AUM_DEV __device__ __forceinline__
 #define AUM_UNROLL _Pragma("unroll")
 #endif
+#ifdef AUM_EMU
+#define AUM_HOSTDEV inline
+#else
+#define AUM_HOSTDEV __host__ __device__ __forceinline__
+#endif
 
 namespace aum {
 
@@ -62,7 +67,19 @@ using vf = float;
 using vi = int;
 using vm = bool;
 
-AUM_DEV vi lane_id() { return (int)threadIdx.x; }
+AUM_DEV vi lane_id() { return (int)(threadIdx.x & 63u); }
+// index of this wavefront inside a multi-wave workgroup (wave-uniform, lives in an SGPR)
+AUM_DEV int wave_in_wg() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+// Multi-wave workgroups are written as PHASES: `AUM_FOR_EACH_WAVE(w, NW) { ...phase body for wave w... }
+// AUM_WG_BARRIER();`.  On the device the loop runs once for this thread's own wave and the barrier is s_barrier;
+// the lane-array build steps the NW waves one after another (legal because phases only communicate through LDS
+// across the barrier, or through commutative LDS atomics inside a phase).
+#define AUM_FOR_EACH_WAVE(w, NW) for (int w = aum::wave_in_wg(), aum_once_ = 1; aum_once_; aum_once_ = 0)
+#define AUM_WG_BARRIER() __syncthreads()
+// Barrier issued INSIDE a wave phase (every wave of the workgroup reaches it the same number of times).  The lane-array
+// build runs the waves of a phase one after another, where it is a no-op: sequential execution is one legal schedule,
+// so arithmetic is checked there while race-freedom under concurrency is argued at the call site and checked on the GPU.
+#define AUM_WG_BARRIER_IN_PHASE() __syncthreads()
 AUM_DEV vf splat(float x) { return x; }
 AUM_DEV vi spl_i(int x) { return x; }
 AUM_DEV vf vfma(vf a, vf b, vf c) { return __builtin_fmaf(a, b, c); }
@@ -89,6 +106,9 @@ AUM_DEV void gstore_coherent(float* p, vi idx, vf v, vm m) {
 }
 AUM_DEV vf lds_read(const float* lds, vi idx) { return lds[idx]; }
 AUM_DEV void lds_write(float* lds, vi idx, vf v) { lds[idx] = v; }
+AUM_DEV void lds_atomic_add(float* lds, vi idx, vf v) {   // ds_add_f32 (no return)
+    __hip_atomic_fetch_add(lds + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 AUM_DEV void wave_sync() { __syncthreads(); }  // single-wave workgroup: orders LDS traffic, ~free
 
 template <int CTRL> AUM_DEV vf dpp_mov(vf x, vf old) {
@@ -178,6 +198,10 @@ inline vf gload_coherent(const float* p, const vi& idx, const vm& m) { return gl
 inline void gstore_coherent(float* p, const vi& idx, const vf& v, const vm& m) { gstore(p, idx, v, m); }
 inline vf lds_read(const float* lds, const vi& idx) { vf r; AUM_LANES r.v[l] = lds[idx.v[l]]; return r; }
 inline void lds_write(float* lds, const vi& idx, const vf& v) { AUM_LANES lds[idx.v[l]] = v.v[l]; }
+inline void lds_atomic_add(float* lds, const vi& idx, const vf& v) { AUM_LANES lds[idx.v[l]] += v.v[l]; }
+#define AUM_FOR_EACH_WAVE(w, NW) for (int w = 0; w < (NW); ++w)
+#define AUM_WG_BARRIER() do { } while (0)
+#define AUM_WG_BARRIER_IN_PHASE() do { } while (0)
 inline void wave_sync() {}
 
 template <int N> inline vf dpp_row_shr(const vf& x, const vf& old) {

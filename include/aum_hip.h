@@ -45,6 +45,8 @@ enum {
 #define AUM_SCAN_SOFTPLUS 1u /* delta = softplus(delta + delta_bias)  (delta_softplus=True)                     */
 #define AUM_SCAN_REVERSE 2u  /* run the recurrence from t=len-1 down to 0 (replaces the .flip([-1]) copies of   */
                              /* selective_scan_interface.py:503-507,547-561 and mamba_simple.py:229-246)        */
+#define AUM_SCAN_GENERIC 4u  /* force the generic single-wave kernels (any dstate <= 256); default: 8-wave workgroup */
+                             /* kernels when dstate <= 16                                                        */
 #define AUM_CONV_SILU 1u
 #define AUM_CONV_REVERSE 2u  /* anti-causal: y[l] = act(b + sum_w W[w] x[l+(W-1)-w])                            */
 #define AUM_NORM_PRENORM 1u  /* also return residual_out                                                        */
@@ -57,7 +59,7 @@ enum {
  * (selective_scan_interface.py:499-507): out = scan(A, forward) + scan(A_b, time-reversed), inputs read once, no flip
  * copies.  z == NULL: no gate.  out_pre (optional) receives the pre-gate value y + D*u summed over directions (what
  * the reference saves as `out` / `out_f`,`out_b` for the backward's dz).
- * workspace: needed only when len > aum_scan_max_single_pass_len(); size from aum_selective_scan_workspace_bytes().
+ * workspace: unused by the forward (kept for ABI symmetry).
  */
 typedef struct AumScanFwdArgs {
     const void *u, *delta, *z, *B, *C;
@@ -83,6 +85,9 @@ typedef struct AumScanFwdArgs {
  *   dA, dA_b : (dim, dstate); dD, ddelta_bias : (dim); dB, dC : (batch, dstate, len) -- all fp32, ACCUMULATED INTO
  *   (the caller zero-fills them; the fused bidirectional call adds both directions, selective_scan_interface.py:554-559).
  * out_pre is the tensor saved by the forward (required when z != NULL; it feeds dz).
+ * workspace (required; size from aum_selective_scan_workspace_bytes(..., backward=1)): per-workgroup dB/dC partial
+ * tiles and per-batch dA/dD/ddelta_bias partials that a second kernel of the same call reduces -- the backward issues
+ * no global atomics.
  * The gradient is the mathematically complete one (autograd of bimamba_inner_ref), see DESIGN.md "dz".
  */
 typedef struct AumScanBwdArgs {

@@ -26,7 +26,7 @@ def rq(a, dtype):
     return None if a is None else torch.tensor(np.asarray(a)).to(dtype).float().numpy()
 
 
-def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, tol=None, strided=False):
+def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, tol=None, strided=False, generic=False):
     name, batch, dim, length, dstate, has_z, has_D, has_bias, softplus = case
     d = cases.scan_inputs(*case)
     tol = tol or (TOL_F32 if dtype == torch.float32 else TOL_BF16)
@@ -41,7 +41,7 @@ def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, 
     Bm, Cm = act(d["B"]).unsqueeze(1), act(d["C"]).unsqueeze(1)
     A, D, bias = T(d["A"], dev), T(d["D"], dev), T(d["delta_bias"], dev)
     out, out_pre, last = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, softplus, reverse, T(A_b, dev),
-                                          want_out_pre=True, want_last_state=not bidir, lib=lib)
+                                          want_out_pre=True, want_last_state=not bidir, generic=generic, lib=lib)
     ref = O.scan_fwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], softplus,
                      reverse, "f64")
     ref_out, ref_pre = ref["out"], ref["y_pre"]
@@ -54,7 +54,7 @@ def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, 
     # backward
     dout = act(d["dout"])
     g = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, out_pre if has_z else None, softplus, reverse,
-                         T(A_b, dev), lib=lib)
+                         T(A_b, dev), generic=generic, lib=lib)
     gr = O.scan_bwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus,
                     reverse, "f64")
     if bidir:

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(so_path):
     for n in names:
         assert hasattr(lib, n), n
     assert lib.aum_abi_version() == 1
-    assert lib.aum_scan_max_single_pass_len() == 1024
+    assert lib.aum_scan_max_single_pass_len() == 576
     assert lib.aum_rmsnorm_bwd_partials(32832) == 1024
 
 

@@ -27,10 +27,13 @@ def test_wave_scan_primitive(emu):
 
 @pytest.mark.parametrize("case", cases.SCAN_CASES, ids=lambda c: c[0])
 @pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
-def test_scan(emu, case, mode):
+@pytest.mark.parametrize("path", ["workgroup", "generic"])
+def test_scan(emu, case, mode, path):
+    """path=workgroup: the 8-wave LDS-tiled production kernels (dstate<=16); generic: the single-wave kernels."""
     if mode == "bidir" and case[3] > emu.max_single_pass_len:
         pytest.skip("direction fusion is single-pass only; host composes two reverse-flag calls")
-    KC.check_scan(emu, "cpu", case, torch.float32, reverse=(mode == "rev"), bidir=(mode == "bidir"))
+    KC.check_scan(emu, "cpu", case, torch.float32, reverse=(mode == "rev"), bidir=(mode == "bidir"),
+                  generic=(path == "generic"))
 
 
 @pytest.mark.parametrize("mode", ["fwd", "bidir"])

@@ -22,10 +22,12 @@ def test_wave_scan_primitive(lib):
 
 @pytest.mark.parametrize("case", cases.SCAN_CASES, ids=lambda c: c[0])
 @pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
-def test_scan_f32(lib, case, mode):
+@pytest.mark.parametrize("path", ["workgroup", "generic"])
+def test_scan_f32(lib, case, mode, path):
     if mode == "bidir" and case[3] > lib.max_single_pass_len:
         pytest.skip("direction fusion is single-pass only")
-    KC.check_scan(lib, "cuda", case, torch.float32, reverse=(mode == "rev"), bidir=(mode == "bidir"))
+    KC.check_scan(lib, "cuda", case, torch.float32, reverse=(mode == "rev"), bidir=(mode == "bidir"),
+                  generic=(path == "generic"))
 
 
 @pytest.mark.parametrize("case", ["l65", "l513", "l2049", "l130_n4"])

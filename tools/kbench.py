@@ -90,6 +90,16 @@ def main():
         y, rstd, ro = aum_hip.rmsnorm_fwd(x, wn, r, 1e-5)
         dy = torch.randn(M, C, device=dev).to(dt)
         rec("rmsnorm_bwd", timeit(lambda: aum_hip.rmsnorm_bwd(dy, ro, wn, rstd, r, True, x_dtype=dt)), M * C * (2 * s + 12))
+    if want("ablate"):
+        _, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True)
+        for bits, label in ((0, "full"), (1, "no_states"), (2, "no_lds_atomics"), (4, "no_partials"), (8, "no_epilogue"),
+                            (3, "no_states_no_atomics"), (15, "loads_only")):
+            os.environ["AUM_ABLATE"] = str(bits)
+            rec(f"ablate_bwd_bidir_{label}", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, A_b=A_b), iters=5), 1)
+        for bits, label in ((0, "full"), (1, "no_states")):
+            os.environ["AUM_ABLATE"] = str(bits)
+            rec(f"ablate_fwd_bidir_{label}", timeit(lambda: aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b), iters=5), 1)
+        os.environ["AUM_ABLATE"] = "0"
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"kbench_{a.dtype}_B{a.batch}.json"), "w") as f:
         json.dump(res, f, indent=1)
