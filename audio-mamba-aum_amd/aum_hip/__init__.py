@@ -276,7 +276,7 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=
     return dict(du=du, ddelta=ddelta, dA=dA, dA_b=dA_b, dB=dB, dC=dC, dD=dD, dz=dz, ddelta_bias=dbias)
 
 
-def conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, dmajor=False, lib=None):
+def conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, dmajor=False, generic=False, lib=None):
     """causal_conv1d_cuda.causal_conv1d_fwd(x, weight(dim,width), bias, None, silu) -> y (batch, dim, len) contiguous."""
     lib = lib or get()
     _unit(x, "x")
@@ -289,12 +289,12 @@ def conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, dmajor=False, lib
     a.x, a.weight, a.bias, a.y = _ptr(x), _ptr(weight), _ptr(bias), _ptr(y)
     a.x_bs, a.x_ds, a.y_bs, a.y_ds = x.stride(0), x.stride(1), y.stride(0), y.stride(1)
     a.batch, a.dim, a.len, a.width, a.dtype = batch, dim, length, weight.shape[1], _DT[x.dtype]
-    a.flags = (CONV_SILU if silu else 0) | (CONV_REVERSE if reverse else 0)
+    a.flags = (CONV_SILU if silu else 0) | (CONV_REVERSE if reverse else 0) | (4 if generic else 0)
     _launch(lib.c.aum_causal_conv1d_fwd, a, x, lib, "conv_fwd", (batch, dim, length, x.element_size()))
     return y
 
 
-def conv1d_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, lib=None):
+def conv1d_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, generic=False, lib=None):
     """causal_conv1d_cuda.causal_conv1d_bwd -> (dx, dweight(dim,width) fp32, dbias fp32|None); dx_out may be a
     preallocated strided view written in place (SSI:594-596)."""
     lib = lib or get()
@@ -314,12 +314,12 @@ def conv1d_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, lib=N
     a.x_bs, a.x_ds, a.dy_bs, a.dy_ds = x.stride(0), x.stride(1), dy.stride(0), dy.stride(1)
     a.dx_bs, a.dx_ds = dx.stride(0), dx.stride(1)
     a.batch, a.dim, a.len, a.width, a.dtype = batch, dim, length, weight.shape[1], _DT[x.dtype]
-    a.flags = (CONV_SILU if silu else 0) | (CONV_REVERSE if reverse else 0)
+    a.flags = (CONV_SILU if silu else 0) | (CONV_REVERSE if reverse else 0) | (4 if generic else 0)
     _launch(lib.c.aum_causal_conv1d_bwd, a, x, lib, "conv_bwd", (batch, dim, length, x.element_size()))
     return dx, dw, db
 
 
-def rmsnorm_fwd(x, weight, residual=None, eps=1e-5, residual_dtype=None, lib=None):
+def rmsnorm_fwd(x, weight, residual=None, eps=1e-5, residual_dtype=None, generic=False, lib=None):
     """_layer_norm_fwd(is_rms_norm=True) (LN:123-177).  x: (rows, cols).  Returns (y, rstd, residual_out) where
     residual_out is x itself when no new residual tensor is needed (LN:176-177)."""
     lib = lib or get()
@@ -344,11 +344,12 @@ def rmsnorm_fwd(x, weight, residual=None, eps=1e-5, residual_dtype=None, lib=Non
     a.eps, a.rows, a.cols = eps, rows, cols
     a.x_dtype = a.y_dtype = _DT[x.dtype]
     a.res_dtype = _DT[residual_dtype] if need_res_out else _DT[x.dtype]
+    a.flags = 2 if generic else 0
     _launch(lib.c.aum_rmsnorm_fwd, a, x, lib, "rmsnorm_fwd", (rows, cols, x.element_size()))
     return y, rstd, (res_out if res_out is not None else x)
 
 
-def rmsnorm_bwd(dy, x_saved, weight, rstd, dresidual=None, has_residual=False, x_dtype=None, lib=None):
+def rmsnorm_bwd(dy, x_saved, weight, rstd, dresidual=None, has_residual=False, x_dtype=None, generic=False, lib=None):
     """_layer_norm_bwd(is_rms_norm=True) (LN:293-377).  x_saved = residual_out of the forward.  Returns
     (dx [x_dtype], dweight fp32, dresidual_in | None)."""
     lib = lib or get()
@@ -373,6 +374,7 @@ def rmsnorm_bwd(dy, x_saved, weight, rstd, dresidual=None, has_residual=False, x
     a.rows, a.cols = rows, cols
     a.x_dtype = a.y_dtype = _DT[x_dtype]
     a.res_dtype = _DT[x_saved.dtype]
+    a.flags = 2 if generic else 0
     _launch(lib.c.aum_rmsnorm_bwd, a, dy, lib, "rmsnorm_bwd", (rows, cols, dy.element_size()))
     dw = dwp.sum(0)
     if has_residual and dres_in is None:

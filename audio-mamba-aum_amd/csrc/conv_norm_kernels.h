@@ -186,6 +186,246 @@ template <class TX, class TR> AUM_DEV void rmsnorm_bwd_wave(const AumNormArgs& p
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Width-4 conv (the only width Mamba uses, MS:39): 8 consecutive time steps per lane, one 16-byte access per
+// tensor per lane, halo from the neighbouring lane through DPP.  HBM-bound: 2 (fwd) / 3 (bwd) tensor passes.
+// ------------------------------------------------------------------------------------------------
+// Load this lane's 8 elements [t0, t0+8) of a row (vector load when fully inside the row, masked scalars at the tail).
+template <class T> AUM_DEV void row_load8(const T* rp, vi t0, int len, vf (&x)[8]) {
+    const vm full = (t0 + 8) <= len;
+    gload8(rp, t0, full, x);
+    const vm part = !full && (t0 < len);
+    if (any_lane(part)) {
+        AUM_UNROLL
+        for (int j = 0; j < 8; ++j) x[j] = x[j] + gload(rp, t0 + j, part && ((t0 + j) < len));
+    }
+}
+template <class T> AUM_DEV void row_store8(T* rp, vi t0, int len, const vf (&x)[8]) {
+    const vm full = (t0 + 8) <= len;
+    gstore8(rp, t0, x, full);
+    const vm part = !full && (t0 < len);
+    if (any_lane(part)) {
+        AUM_UNROLL
+        for (int j = 0; j < 8; ++j) gstore(rp, t0 + j, x[j], part && ((t0 + j) < len));
+    }
+}
+
+// xin[0..10]: the 11 inputs that the lane's 8 outputs touch.  causal: x[t0-3 .. t0+7]; REV: x[t0 .. t0+10].
+template <class T, bool REV> AUM_DEV void conv4_inputs(const T* xp, vi t0, int len, vf (&xin)[11]) {
+    const vi lane = lane_id();
+    vf x[8];
+    row_load8(xp, t0, len, x);
+    if (!REV) {
+        AUM_UNROLL
+        for (int i = 0; i < 3; ++i) {
+            const vi th = t0 - 3 + i;
+            const vf edge = gload(xp, th, (lane == 0) && (th >= 0) && (th < len));
+            xin[i] = dpp_wave_shr1(x[5 + i], edge);
+        }
+        AUM_UNROLL
+        for (int j = 0; j < 8; ++j) xin[3 + j] = x[j];
+    } else {
+        AUM_UNROLL
+        for (int j = 0; j < 8; ++j) xin[j] = x[j];
+        AUM_UNROLL
+        for (int i = 0; i < 3; ++i) {
+            const vi th = t0 + 8 + i;
+            const vf edge = gload(xp, th, (lane == WAVE - 1) && (th < len));
+            xin[8 + i] = dpp_wave_shl1(x[i], edge);
+        }
+    }
+}
+
+template <class T, bool REV> AUM_DEV void conv4_fwd_wave(const AumConvArgs& p, int wg) {
+    const int b = wg / p.dim, e = wg % p.dim;
+    const bool silu = (p.flags & AUM_CONV_SILU) != 0;
+    const T* xp = (const T*)p.x + (int64_t)b * p.x_bs + (int64_t)e * p.x_ds;
+    T* yp = (T*)p.y + (int64_t)b * p.y_bs + (int64_t)e * p.y_ds;
+    const float w0 = p.weight[e * 4 + 0], w1 = p.weight[e * 4 + 1], w2 = p.weight[e * 4 + 2], w3 = p.weight[e * 4 + 3];
+    const float bias = p.bias ? p.bias[e] : 0.f;
+    const vi lane = lane_id();
+    for (int blk = 0; blk * 512 < p.len; ++blk) {
+        const vi t0 = lane * 8 + blk * 512;
+        vf xin[11], y[8];
+        conv4_inputs<T, REV>(xp, t0, p.len, xin);
+        AUM_UNROLL
+        for (int j = 0; j < 8; ++j) {
+            // causal: y[l] = b + sum_w W[w] x[l-3+w] -> xin[j+w];  REV: y[l] = b + sum_w W[w] x[l+3-w] -> xin[j+3-w]
+            vf acc = splat(bias);
+            acc = vfma(xin[REV ? j + 3 : j + 0], splat(w0), acc);
+            acc = vfma(xin[REV ? j + 2 : j + 1], splat(w1), acc);
+            acc = vfma(xin[REV ? j + 1 : j + 2], splat(w2), acc);
+            acc = vfma(xin[REV ? j + 0 : j + 3], splat(w3), acc);
+            y[j] = silu ? acc * vsigmoid(acc) : acc;
+        }
+        row_store8(yp, t0, p.len, y);
+    }
+}
+
+template <class T, bool REV> AUM_DEV void conv4_bwd_wave(const AumConvArgs& p, int wg) {
+    const int b = wg / p.dim, e = wg % p.dim;
+    const bool silu = (p.flags & AUM_CONV_SILU) != 0;
+    const T* xp = (const T*)p.x + (int64_t)b * p.x_bs + (int64_t)e * p.x_ds;
+    const T* gp = (const T*)p.dy + (int64_t)b * p.dy_bs + (int64_t)e * p.dy_ds;
+    T* dxp = (T*)p.dx + (int64_t)b * p.dx_bs + (int64_t)e * p.dx_ds;
+    const float w[4] = {p.weight[e * 4 + 0], p.weight[e * 4 + 1], p.weight[e * 4 + 2], p.weight[e * 4 + 3]};
+    const float bias = p.bias ? p.bias[e] : 0.f;
+    const vi lane = lane_id();
+    const int nblk = (p.len + 511) / 512;
+    vf dw[4] = {splat(0.f), splat(0.f), splat(0.f), splat(0.f)};
+    vf db = splat(0.f);
+    // dx needs dpre of the 3 steps AFTER (causal) / BEFORE (REV) the lane's own 8: neighbour lane via DPP, and across
+    // the 512-step blocks a wave-uniform carry -- so blocks are walked against the dependency.
+    float carry[3] = {0.f, 0.f, 0.f};
+    for (int bi = 0; bi < nblk; ++bi) {
+        const int blk = REV ? bi : nblk - 1 - bi;
+        const vi t0 = lane * 8 + blk * 512;
+        vf xin[11], g[8], dpre[8], dxv[8];
+        conv4_inputs<T, REV>(xp, t0, p.len, xin);
+        row_load8(gp, t0, p.len, g);
+        AUM_UNROLL
+        for (int j = 0; j < 8; ++j) {
+            vf acc = splat(bias);
+            AUM_UNROLL
+            for (int k = 0; k < 4; ++k) acc = vfma(xin[REV ? j + 3 - k : j + k], splat(w[k]), acc);
+            vf d = g[j];
+            if (silu) d = d * vsilu_grad(acc);
+            d = vsel((t0 + j) < p.len, d, splat(0.f));
+            dpre[j] = d;
+            db = db + d;
+            AUM_UNROLL
+            for (int k = 0; k < 4; ++k) dw[k] = vfma(xin[REV ? j + 3 - k : j + k], d, dw[k]);
+        }
+        vf dext[11];   // causal: dpre[t0 .. t0+10];  REV: dpre[t0-3 .. t0+7]
+        if (!REV) {
+            AUM_UNROLL
+            for (int j = 0; j < 8; ++j) dext[j] = dpre[j];
+            AUM_UNROLL
+            for (int i = 0; i < 3; ++i) dext[8 + i] = dpp_wave_shl1(dpre[i], splat(carry[i]));
+            AUM_UNROLL
+            for (int i = 0; i < 3; ++i) carry[i] = readlane(dpre[i], 0);
+        } else {
+            AUM_UNROLL
+            for (int i = 0; i < 3; ++i) dext[i] = dpp_wave_shr1(dpre[5 + i], splat(carry[i]));
+            AUM_UNROLL
+            for (int j = 0; j < 8; ++j) dext[3 + j] = dpre[j];
+            AUM_UNROLL
+            for (int i = 0; i < 3; ++i) carry[i] = readlane(dpre[5 + i], WAVE - 1);
+        }
+        AUM_UNROLL
+        for (int j = 0; j < 8; ++j) {
+            // causal: dx[s] = sum_w W[w] dpre[s+3-w] -> dext[j+3-w];  REV: dx[s] = sum_w W[w] dpre[s-3+w] -> dext[j+w]
+            vf acc = splat(0.f);
+            AUM_UNROLL
+            for (int k = 0; k < 4; ++k) acc = vfma(dext[REV ? j + k : j + 3 - k], splat(w[k]), acc);
+            dxv[j] = acc;
+        }
+        row_store8(dxp, t0, p.len, dxv);
+    }
+    AUM_UNROLL
+    for (int k = 0; k < 4; ++k)
+        gatomic_add(p.dweight + (int64_t)e * 4 + k, spl_i(0), splat(wave_sum(dw[k])), lane == 0);
+    if (p.bias && p.dbias) gatomic_add(p.dbias + e, spl_i(0), splat(wave_sum(db)), lane == 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm, vectorised: each lane owns 8 consecutive columns per 512-column chunk, rows cached in registers
+// (cols <= 512*NCH), one pass over memory.
+// ------------------------------------------------------------------------------------------------
+template <class TX, class TR, int NCH> AUM_DEV void rmsnorm_fwd_vec(const AumNormArgs& p, int wg) {
+    const int row = wg;
+    const TX* xp = (const TX*)p.x + (int64_t)row * p.row_stride_x;
+    const TR* rp = p.residual ? (const TR*)p.residual + (int64_t)row * p.row_stride_res : nullptr;
+    TR* rop = p.residual_out ? (TR*)p.residual_out + (int64_t)row * p.row_stride_res_out : nullptr;
+    TX* yp = (TX*)p.y + (int64_t)row * p.row_stride_y;
+    const vi lane = lane_id();
+    vf v[NCH][8];
+    vf ss = splat(0.f);
+    AUM_UNROLL
+    for (int c = 0; c < NCH; ++c) {
+        const vi c0 = lane * 8 + c * 512;
+        row_load8(xp, c0, p.cols, v[c]);
+        if (rp) {
+            vf r[8];
+            row_load8(rp, c0, p.cols, r);
+            AUM_UNROLL
+            for (int j = 0; j < 8; ++j) v[c][j] = v[c][j] + r[j];
+        }
+        if (rop) row_store8(rop, c0, p.cols, v[c]);
+        AUM_UNROLL
+        for (int j = 0; j < 8; ++j) ss = vfma(v[c][j], v[c][j], ss);
+    }
+    const float mean_sq = wave_sum(ss) / (float)p.cols;
+    const float rstd = readlane(vdiv(splat(1.f), vsqrt(splat(mean_sq + p.eps))), 0);
+    if (p.rstd_out) gstore(p.rstd_out + row, spl_i(0), splat(rstd), lane == 0);
+    AUM_UNROLL
+    for (int c = 0; c < NCH; ++c) {
+        const vi c0 = lane * 8 + c * 512;
+        vf wv[8], y[8];
+        row_load8(p.weight, c0, p.cols, wv);
+        AUM_UNROLL
+        for (int j = 0; j < 8; ++j) y[j] = v[c][j] * rstd * wv[j];
+        row_store8(yp, c0, p.cols, y);
+    }
+}
+
+template <class TX, class TR, int NCH> AUM_DEV void rmsnorm_bwd_vec(const AumNormArgs& p, int wg, int n_partials) {
+    const int rows_per = (p.rows + n_partials - 1) / n_partials;
+    const int r0 = wg * rows_per;
+    const int r1 = r0 + rows_per < p.rows ? r0 + rows_per : p.rows;
+    const vi lane = lane_id();
+    vf wv[NCH][8], dwacc[NCH][8];
+    AUM_UNROLL
+    for (int c = 0; c < NCH; ++c) {
+        row_load8(p.weight, lane * 8 + c * 512, p.cols, wv[c]);
+        AUM_UNROLL
+        for (int j = 0; j < 8; ++j) dwacc[c][j] = splat(0.f);
+    }
+    for (int row = r0; row < r1; ++row) {
+        const TR* xp = (const TR*)p.x + (int64_t)row * p.row_stride_x;
+        const TX* gp = (const TX*)p.dy + (int64_t)row * p.row_stride_dy;
+        const TR* drp = p.dresidual_out ? (const TR*)p.dresidual_out + (int64_t)row * p.row_stride_dres_out : nullptr;
+        TX* dxp = (TX*)p.dx + (int64_t)row * p.row_stride_dx;
+        TR* drip = p.dresidual_in ? (TR*)p.dresidual_in + (int64_t)row * p.row_stride_dres_in : nullptr;
+        const float rstd = p.rstd_in[row];
+        vf xh[NCH][8], wdy[NCH][8];
+        vf c1 = splat(0.f);
+        AUM_UNROLL
+        for (int c = 0; c < NCH; ++c) {
+            const vi c0 = lane * 8 + c * 512;
+            vf dyv[8];
+            row_load8(xp, c0, p.cols, xh[c]);
+            row_load8(gp, c0, p.cols, dyv);
+            AUM_UNROLL
+            for (int j = 0; j < 8; ++j) {
+                xh[c][j] = xh[c][j] * rstd;
+                wdy[c][j] = wv[c][j] * dyv[j];
+                c1 = vfma(xh[c][j], wdy[c][j], c1);
+                dwacc[c][j] = vfma(dyv[j], xh[c][j], dwacc[c][j]);
+            }
+        }
+        const float cm = wave_sum(c1) / (float)p.cols;
+        AUM_UNROLL
+        for (int c = 0; c < NCH; ++c) {
+            const vi c0 = lane * 8 + c * 512;
+            vf g[8];
+            AUM_UNROLL
+            for (int j = 0; j < 8; ++j) g[j] = (wdy[c][j] - xh[c][j] * cm) * rstd;
+            if (drp) {
+                vf dr[8];
+                row_load8(drp, c0, p.cols, dr);
+                AUM_UNROLL
+                for (int j = 0; j < 8; ++j) g[j] = g[j] + dr[j];
+            }
+            row_store8(dxp, c0, p.cols, g);
+            if (drip) row_store8(drip, c0, p.cols, g);
+        }
+    }
+    float* out = p.dweight_partial + (int64_t)wg * p.cols;
+    AUM_UNROLL
+    for (int c = 0; c < NCH; ++c) row_store8(out, lane * 8 + c * 512, p.cols, dwacc[c]);
+}
+
 // float4-style streaming copy used to measure the achievable HBM bandwidth on the box.
 #if !defined(AUM_EMU) && (!defined(AUM_API_PART) || AUM_API_PART == 3 || AUM_API_PART == 0)
 __global__ void k_hbm_copy(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {

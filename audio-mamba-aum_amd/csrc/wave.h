@@ -97,6 +97,53 @@ AUM_DEV bool any_lane(vm m) { return __any(m); }
 template <class T> AUM_DEV vf gload(const T* p, vi idx, vm m) { return m ? elem_to_f32(p[idx]) : 0.f; }
 template <class T> AUM_DEV void gstore(T* p, vi idx, vf v, vm m) { if (m) f32_to_elem(v, p[idx]); }
 AUM_DEV void gatomic_add(float* p, vi idx, vf v, vm m) { if (m) atomicAdd(p + idx, v); }
+// 8 consecutive elements per lane as ONE (2-byte types) or TWO (fp32) 16-byte vector accesses.  Rows of the
+// (batch, dim, len) tensors start at arbitrary element offsets (len = 513), so the address is only element-aligned:
+// the packed/aligned(2|4) struct makes hipcc emit global_load/store_dwordx4 in unaligned-access mode (HSA default).
+template <int BYTES> struct __attribute__((packed, aligned(BYTES))) pk16_t { uint8_t b[16]; };
+template <class T> AUM_DEV void gload8(const T* p, vi idx, vm m, vf (&o)[8]) {
+    if (m) {
+        if constexpr (sizeof(T) == 2) {
+            const pk16_t<2> raw = *reinterpret_cast<const pk16_t<2>*>(p + idx);
+            T e[8];
+            __builtin_memcpy(e, &raw, 16);
+            AUM_UNROLL
+            for (int j = 0; j < 8; ++j) o[j] = elem_to_f32(e[j]);
+        } else {
+            const pk16_t<4> r0 = *reinterpret_cast<const pk16_t<4>*>(p + idx);
+            const pk16_t<4> r1 = *reinterpret_cast<const pk16_t<4>*>(p + idx + 4);
+            float e[8];
+            __builtin_memcpy(e, &r0, 16);
+            __builtin_memcpy(e + 4, &r1, 16);
+            AUM_UNROLL
+            for (int j = 0; j < 8; ++j) o[j] = e[j];
+        }
+    } else {
+        AUM_UNROLL
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    }
+}
+template <class T> AUM_DEV void gstore8(T* p, vi idx, const vf (&v)[8], vm m) {
+    if (m) {
+        if constexpr (sizeof(T) == 2) {
+            T e[8];
+            AUM_UNROLL
+            for (int j = 0; j < 8; ++j) f32_to_elem(v[j], e[j]);
+            pk16_t<2> raw;
+            __builtin_memcpy(&raw, e, 16);
+            *reinterpret_cast<pk16_t<2>*>(p + idx) = raw;
+        } else {
+            float e[8];
+            AUM_UNROLL
+            for (int j = 0; j < 8; ++j) e[j] = v[j];
+            pk16_t<4> r0, r1;
+            __builtin_memcpy(&r0, e, 16);
+            __builtin_memcpy(&r1, e + 4, 16);
+            *reinterpret_cast<pk16_t<4>*>(p + idx) = r0;
+            *reinterpret_cast<pk16_t<4>*>(p + idx + 4) = r1;
+        }
+    }
+}
 // L1-bypassing accesses for scratch that this wave wrote earlier in the same launch
 AUM_DEV vf gload_coherent(const float* p, vi idx, vm m) {
     return m ? __hip_atomic_load(p + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
@@ -194,6 +241,12 @@ template <class T> inline void gstore(T* p, const vi& idx, const vf& v, const vm
     AUM_LANES if (m.v[l]) f32_to_elem(v.v[l], p[idx.v[l]]);
 }
 inline void gatomic_add(float* p, const vi& idx, const vf& v, const vm& m) { AUM_LANES if (m.v[l]) p[idx.v[l]] += v.v[l]; }
+template <class T> inline void gload8(const T* p, const vi& idx, const vm& m, vf (&o)[8]) {
+    for (int j = 0; j < 8; ++j) AUM_LANES o[j].v[l] = m.v[l] ? elem_to_f32(p[idx.v[l] + j]) : 0.f;
+}
+template <class T> inline void gstore8(T* p, const vi& idx, const vf (&v)[8], const vm& m) {
+    for (int j = 0; j < 8; ++j) AUM_LANES if (m.v[l]) f32_to_elem(v[j].v[l], p[idx.v[l] + j]);
+}
 inline vf gload_coherent(const float* p, const vi& idx, const vm& m) { return gload(p, idx, m); }
 inline void gstore_coherent(float* p, const vi& idx, const vf& v, const vm& m) { gstore(p, idx, v, m); }
 inline vf lds_read(const float* lds, const vi& idx) { vf r; AUM_LANES r.v[l] = lds[idx.v[l]]; return r; }

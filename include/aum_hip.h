@@ -49,7 +49,9 @@ enum {
                              /* kernels when dstate <= 16                                                        */
 #define AUM_CONV_SILU 1u
 #define AUM_CONV_REVERSE 2u  /* anti-causal: y[l] = act(b + sum_w W[w] x[l+(W-1)-w])                            */
+#define AUM_CONV_GENERIC 4u  /* force the any-width kernel (default: the vectorised width-4 kernel when width == 4)  */
 #define AUM_NORM_PRENORM 1u  /* also return residual_out                                                        */
+#define AUM_NORM_GENERIC 2u  /* force the any-cols kernel (default: register-cached vector kernel, cols <= 2048)  */
 
 /*
  * Selective scan forward (selective_scan_cuda.fwd).

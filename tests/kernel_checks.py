@@ -74,16 +74,16 @@ def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, 
     return errs
 
 
-def check_conv(lib, dev, case, dtype=torch.float32, reverse=False, silu=True):
+def check_conv(lib, dev, case, dtype=torch.float32, reverse=False, silu=True, generic=False):
     name = case[0]
     d = cases.conv_inputs(*case)
     tol = 1e-5 if dtype == torch.float32 else TOL_BF16
     q = {k: rq(d[k], dtype) for k in ("x", "dout")}
     x, dy = T(d["x"], dev, dtype), T(d["dout"], dev, dtype)
     w, b = T(d["weight"], dev), T(d["bias"], dev)
-    y = aum_hip.conv1d_fwd(x, w, b, silu, reverse, lib=lib)
+    y = aum_hip.conv1d_fwd(x, w, b, silu, reverse, generic=generic, lib=lib)
     ry = O.conv1d_fwd(q["x"], d["weight"], d["bias"], silu, reverse, "f64")
-    dx, dw, db = aum_hip.conv1d_bwd(x, w, b, dy, silu, reverse, lib=lib)
+    dx, dw, db = aum_hip.conv1d_bwd(x, w, b, dy, silu, reverse, generic=generic, lib=lib)
     rg = O.conv1d_bwd(q["x"], d["weight"], d["bias"], q["dout"], silu, reverse, "f64")
     errs = {"y": rel_err(N(y), ry), "dx": rel_err(N(dx), rg["dx"]), "dw": rel_err(N(dw), rg["dweight"])}
     if b is not None:
@@ -93,7 +93,7 @@ def check_conv(lib, dev, case, dtype=torch.float32, reverse=False, silu=True):
     return errs
 
 
-def check_norm(lib, dev, case, dtype=torch.float32, res_dtype=torch.float32):
+def check_norm(lib, dev, case, dtype=torch.float32, res_dtype=torch.float32, generic=False):
     name, lead, cols, has_res, prenorm = case
     d = cases.norm_inputs(*case)
     tol = 1e-5 if dtype == torch.float32 else TOL_BF16
@@ -101,7 +101,7 @@ def check_norm(lib, dev, case, dtype=torch.float32, res_dtype=torch.float32):
     res = T(d["residual"], dev, res_dtype)
     res = None if res is None else res.reshape(-1, cols)
     w = T(d["weight"], dev)
-    y, rstd, res_out = aum_hip.rmsnorm_fwd(x, w, res, 1e-5, residual_dtype=res_dtype, lib=lib)
+    y, rstd, res_out = aum_hip.rmsnorm_fwd(x, w, res, 1e-5, residual_dtype=res_dtype, generic=generic, lib=lib)
     qx = rq(d["x"], dtype).reshape(-1, cols)
     qr = None if d["residual"] is None else rq(d["residual"], res_dtype).reshape(-1, cols)
     r = O.rmsnorm_fwd(qx, d["weight"], None, qr, 1e-5, "f64")
@@ -109,7 +109,7 @@ def check_norm(lib, dev, case, dtype=torch.float32, res_dtype=torch.float32):
             "rstd": rel_err(N(rstd), r["rstd"])}
     dy = T(d["dy"], dev, dtype).reshape(-1, cols)
     dres = None if d["dres"] is None else T(d["dres"], dev, res_out.dtype).reshape(-1, cols)
-    dx, dw, dres_in = aum_hip.rmsnorm_bwd(dy, res_out, w, rstd, dres, has_res, x_dtype=dtype, lib=lib)
+    dx, dw, dres_in = aum_hip.rmsnorm_bwd(dy, res_out, w, rstd, dres, has_res, x_dtype=dtype, generic=generic, lib=lib)
     qdres = None if d["dres"] is None else rq(d["dres"], res_out.dtype).reshape(-1, cols)
     rb = O.rmsnorm_bwd(rq(d["dy"], dtype).reshape(-1, cols), N(res_out), d["weight"], N(rstd), qdres, False, "f64")
     errs["dx"] = rel_err(N(dx), rb["dx"])

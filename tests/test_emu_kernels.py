@@ -59,3 +59,12 @@ def test_conv_bf16(emu):
 def test_norm(emu, case):
     KC.check_norm(emu, "cpu", case, torch.float32)
     KC.check_norm(emu, "cpu", case, torch.bfloat16, torch.float32)
+
+
+def test_generic_conv_and_norm_kernels(emu):
+    """the any-width / any-cols kernels stay covered now that width 4 / cols <= 2048 take the vectorised kernels"""
+    for case in cases.CONV_CASES:
+        KC.check_conv(emu, "cpu", case, torch.float32, reverse=False, generic=True)
+        KC.check_conv(emu, "cpu", case, torch.float32, reverse=True, generic=True)
+    for case in cases.NORM_CASES:
+        KC.check_norm(emu, "cpu", case, torch.float32, generic=True)

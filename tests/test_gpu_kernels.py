@@ -93,3 +93,12 @@ def test_scan_full_size_properties(lib):
     out, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, lib=lib)
     ref = pre.float() * torch.nn.functional.silu(z.float())
     assert (out.float() - ref).abs().max() / ref.abs().max() < 1e-2
+
+
+def test_generic_conv_and_norm_kernels(lib):
+    """the any-width / any-cols kernels stay covered now that width 4 / cols <= 2048 take the vectorised kernels"""
+    for case in cases.CONV_CASES:
+        KC.check_conv(lib, "cuda", case, torch.float32, reverse=False, generic=True)
+        KC.check_conv(lib, "cuda", case, torch.float32, reverse=True, generic=True)
+    for case in cases.NORM_CASES:
+        KC.check_norm(lib, "cuda", case, torch.float32, generic=True)
