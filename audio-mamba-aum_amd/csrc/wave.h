@@ -12,8 +12,9 @@
 //     arithmetic, tails, carries and reductions on a machine without a GPU (tests/emu).  It is never
 //     loaded by the product path (aum_hip/_lib.py loads libaum_hip.so or fails).
 //
-// All workgroups in this library are exactly one wavefront (64 threads): cross-lane traffic is DPP /
-// readlane / wave-synchronous LDS, never a multi-wave barrier.
+// Cross-lane traffic inside a wavefront is DPP / readlane / wave-synchronous LDS.  Most kernels use one-wave
+// workgroups; the production scan kernels use 8-wave workgroups written as barrier-separated phases
+// (AUM_FOR_EACH_WAVE below) so the lane-array build can step the waves one after another.
 #pragma once
 #include <stdint.h>
 
@@ -93,9 +94,13 @@ AUM_DEV vf vmax(vf a, vf b) { return __builtin_fmaxf(a, b); }
 AUM_DEV vf vsel(vm m, vf a, vf b) { return m ? a : b; }
 AUM_DEV vi vsel_i(vm m, vi a, vi b) { return m ? a : b; }
 AUM_DEV bool any_lane(vm m) { return __any(m); }
+AUM_DEV vi vmin_i(vi a, int b) { return a < b ? a : b; }
+AUM_DEV vi vmax_i(vi a, int b) { return a > b ? a : b; }
 
 template <class T> AUM_DEV vf gload(const T* p, vi idx, vm m) { return m ? elem_to_f32(p[idx]) : 0.f; }
 template <class T> AUM_DEV void gstore(T* p, vi idx, vf v, vm m) { if (m) f32_to_elem(v, p[idx]); }
+// unconditional load (caller clamps idx into range): no exec-mask branch, so several can be in flight
+template <class T> AUM_DEV vf gload_u(const T* p, vi idx) { return elem_to_f32(p[idx]); }
 AUM_DEV void gatomic_add(float* p, vi idx, vf v, vm m) { if (m) atomicAdd(p + idx, v); }
 // 8 consecutive elements per lane as ONE (2-byte types) or TWO (fp32) 16-byte vector accesses.  Rows of the
 // (batch, dim, len) tensors start at arbitrary element offsets (len = 513), so the address is only element-aligned:
@@ -153,6 +158,7 @@ AUM_DEV void gstore_coherent(float* p, vi idx, vf v, vm m) {
 }
 AUM_DEV vf lds_read(const float* lds, vi idx) { return lds[idx]; }
 AUM_DEV void lds_write(float* lds, vi idx, vf v) { lds[idx] = v; }
+AUM_DEV void lds_write_m(float* lds, vi idx, vf v, vm m) { if (m) lds[idx] = v; }
 AUM_DEV void lds_atomic_add(float* lds, vi idx, vf v) {   // ds_add_f32 (no return)
     __hip_atomic_fetch_add(lds + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -227,6 +233,8 @@ inline vf vsel(const vm& m, const vf& a, float b) { return vsel(m, a, splat(b));
 inline vf vsel(const vm& m, float a, const vf& b) { return vsel(m, splat(a), b); }
 inline vi vsel_i(const vm& m, const vi& a, const vi& b) { vi r; AUM_LANES r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
 inline bool any_lane(const vm& m) { bool r = false; AUM_LANES r = r || m.v[l]; return r; }
+inline vi vmin_i(const vi& a, int b) { vi r; AUM_LANES r.v[l] = a.v[l] < b ? a.v[l] : b; return r; }
+inline vi vmax_i(const vi& a, int b) { vi r; AUM_LANES r.v[l] = a.v[l] > b ? a.v[l] : b; return r; }
 // scalar (wave-uniform) overloads so kernel code can mix uniform floats freely
 inline float vfma(float a, float b, float c) { return std::fmaf(a, b, c); }
 inline float vexp2(float x) { return std::exp2(x); }
@@ -237,6 +245,7 @@ inline float vsel(bool m, float a, float b) { return m ? a : b; }
 template <class T> inline vf gload(const T* p, const vi& idx, const vm& m) {
     vf r; AUM_LANES r.v[l] = m.v[l] ? elem_to_f32(p[idx.v[l]]) : 0.f; return r;
 }
+template <class T> inline vf gload_u(const T* p, const vi& idx) { vf r; AUM_LANES r.v[l] = elem_to_f32(p[idx.v[l]]); return r; }
 template <class T> inline void gstore(T* p, const vi& idx, const vf& v, const vm& m) {
     AUM_LANES if (m.v[l]) f32_to_elem(v.v[l], p[idx.v[l]]);
 }
@@ -251,6 +260,7 @@ inline vf gload_coherent(const float* p, const vi& idx, const vm& m) { return gl
 inline void gstore_coherent(float* p, const vi& idx, const vf& v, const vm& m) { gstore(p, idx, v, m); }
 inline vf lds_read(const float* lds, const vi& idx) { vf r; AUM_LANES r.v[l] = lds[idx.v[l]]; return r; }
 inline void lds_write(float* lds, const vi& idx, const vf& v) { AUM_LANES lds[idx.v[l]] = v.v[l]; }
+inline void lds_write_m(float* lds, const vi& idx, const vf& v, const vm& m) { AUM_LANES if (m.v[l]) lds[idx.v[l]] = v.v[l]; }
 inline void lds_atomic_add(float* lds, const vi& idx, const vf& v) { AUM_LANES lds[idx.v[l]] += v.v[l]; }
 #define AUM_FOR_EACH_WAVE(w, NW) for (int w = 0; w < (NW); ++w)
 #define AUM_WG_BARRIER() do { } while (0)
