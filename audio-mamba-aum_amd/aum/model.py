@@ -30,7 +30,14 @@ class PatchEmbed(nn.Module):
         nn.init.zeros_(self.proj.bias)
 
     def forward(self, x):
-        return F.conv2d(x, self.proj.weight, self.proj.bias, stride=self.proj.stride).flatten(2).transpose(1, 2)
+        # non-overlapping patches: the conv is a [B*N, C*ph*pw] x [C*ph*pw, Dm] GEMM (no MIOpen find/autotune in the loop)
+        Bsz, C, Fd, Td = x.shape
+        ph, pw = self.proj.kernel_size
+        nf, nt = Fd // ph, Td // pw
+        cols = x[:, :, :nf * ph, :nt * pw].reshape(Bsz, C, nf, ph, nt, pw).permute(0, 2, 4, 1, 3, 5)
+        cols = cols.reshape(Bsz * nf * nt, C * ph * pw)
+        out = F.linear(cols, self.proj.weight.reshape(self.proj.out_channels, -1), self.proj.bias)
+        return out.reshape(Bsz, nf * nt, -1)
 
 
 class PosEmbed(nn.Module):
