@@ -27,7 +27,7 @@ constexpr int SCANWG_MAX_ROWS = 64;   // rows per workgroup (8 waves x 4 pairs x
 constexpr int SCANWG_MAX_K = 9;       // <= 577 steps per chunk keeps the backward's 4 fp32 tiles inside 160 KB of LDS
 // debug-only ablation bits (upper half of `flags`; set through AUM_ABLATE in the Python binding, never by the product)
 constexpr uint32_t AUM_DBG_SKIP_STATES = 1u << 16, AUM_DBG_SKIP_LDS_ATOMICS = 1u << 17, AUM_DBG_SKIP_PARTIALS = 1u << 18,
-                   AUM_DBG_SKIP_EPILOGUE = 1u << 19;
+                   AUM_DBG_SKIP_EPILOGUE = 1u << 19, AUM_DBG_NO_STEP_BARRIER = 1u << 20;
 
 template <int K, int TAIL> struct ScanGeo {
     static constexpr int KT = K + TAIL;                    // slots per lane
@@ -587,7 +587,7 @@ AUM_DEV void scanwg_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_pe
                             }
                         }
                     }
-                    if (j & 1) AUM_WG_BARRIER_IN_PHASE();
+                    if ((j & 1) && !(p.flags & AUM_DBG_NO_STEP_BARRIER)) AUM_WG_BARRIER_IN_PHASE();
                 }
                 if (active && !(p.flags & AUM_DBG_SKIP_PARTIALS)) {
                     AUM_UNROLL

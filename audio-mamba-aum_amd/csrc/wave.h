@@ -324,6 +324,7 @@ AUM_DEV float wave_sum(vf x) {
 // Intra-row: 4 Hillis-Steele steps with DPP row_shr / row_shl (identity filled into invalid lanes).
 // Cross-row: the three row totals travel through SGPRs via v_readlane_b32.
 // ------------------------------------------------------------------------------------------------
+#ifdef AUM_EMU
 template <bool REV> AUM_DEV void wave_scan_affine(vf& P, vf& S) {
 #define AUM_SCAN_STEP(N)                                                               \
     {                                                                                  \
@@ -349,5 +350,65 @@ template <bool REV> AUM_DEV void wave_scan_affine(vf& P, vf& S) {
     S = vfma(P, inS, S);
     (void)E1P; (void)E2P;
 }
+#else
+// Device version: every Hillis-Steele step is two DPP-fused VOP2 instructions,
+//     v_fmac_f32_dpp S, S, P <shift>   ; S[l] += S[l-d] * P[l]      (lanes without a source are not written)
+//     v_mul_f32_dpp  P, P, P <shift>   ; P[l] *= P[l-d]
+// instead of {v_mov old, v_mov_dpp} x2 + v_fma + v_mul.  The prefix form finishes across the 16-lane rows with
+// row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3); the suffix form has no broadcast in that direction and keeps
+// the v_readlane cross-row step.  One s_nop per step covers the "VALU write -> DPP read" hazard (2 wait states);
+// the leading s_nop 1 covers operands the compiler may have written just before the statement.
+template <bool REV> AUM_DEV void wave_scan_affine(vf& P, vf& S) {
+    if constexpr (!REV) {
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_fmac_f32_dpp %1, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f32_dpp %1, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f32_dpp %1, %1, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f32_dpp %1, %1, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f32_dpp %1, %1, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f32_dpp %1, %1, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+            "s_nop 0"
+            : "+v"(P), "+v"(S));
+    } else {
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_fmac_f32_dpp %1, %1, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f32_dpp %1, %1, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f32_dpp %1, %1, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f32_dpp %1, %1, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0"
+            : "+v"(P), "+v"(S));
+        // rows in scan order are 3,2,1,0; their totals sit in the first lane of each row
+        const float P0 = readlane(P, 48), S0 = readlane(S, 48);
+        const float P1 = readlane(P, 32), S1 = readlane(S, 32);
+        const float S2 = readlane(S, 16), P2 = readlane(P, 16);
+        const float E2S = vfma(P1, S0, S1);
+        const float E3S = vfma(P2, E2S, S2);
+        const vi ord = 3 - (lane_id() >> 4);
+        const vf inS = vsel(ord == 1, S0, vsel(ord == 2, E2S, vsel(ord == 3, E3S, 0.f)));
+        S = vfma(P, inS, S);
+        (void)P0;
+    }
+}
+#endif
 
 }  // namespace aum

@@ -15,10 +15,12 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "audio-mamba-aum_amd"))
+from aum import tunable  # noqa: E402   (no torch import inside)
+
+tunable.enable(int(os.environ.get("LOCAL_RANK", "0")))     # GEMM solution selection, before torch issues any GEMM
+import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
 

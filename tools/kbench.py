@@ -93,7 +93,7 @@ def main():
     if want("ablate"):
         _, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True)
         for bits, label in ((0, "full"), (1, "no_states"), (2, "no_lds_atomics"), (4, "no_partials"), (8, "no_epilogue"),
-                            (3, "no_states_no_atomics"), (15, "loads_only")):
+                            (3, "no_states_no_atomics"), (15, "loads_only"), (16, "no_step_barrier")):
             os.environ["AUM_ABLATE"] = str(bits)
             rec(f"ablate_bwd_bidir_{label}", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, A_b=A_b), iters=5), 1)
         for bits, label in ((0, "full"), (1, "no_states")):
