@@ -25,14 +25,15 @@ constexpr int SCAN_LDS_FLOATS = 2 * SCAN_R * SCAN_MAX_DSTATE;   // carries: [dir
 // x'[k] = a[k]*x + b[k] over the wave.  Order of steps: lane-major, k ascending (REV=false) or the exact
 // mirror (REV=true).  carry_in/carry_out are wave-uniform (all lanes equal).  x[k] = state after step k,
 // x_in = state entering this lane's first step.
-template <int K, bool REV>
-AUM_DEV void affine_scan_states(const vf (&a)[K], const vf (&b)[K], vf Ptot, vf carry_in, vf (&x)[K], vf& x_in,
-                                vf& carry_out) {
+// Multiplier of slot k is given by an accessor so that the adjoint pass can use "a of the scan successor" without
+// materialising a shifted copy of the array.
+template <int K, bool REV, class AF>
+AUM_DEV void affine_scan_states_f(AF a, const vf (&b)[K], vf Ptot, vf carry_in, vf (&x)[K], vf& x_in, vf& carry_out) {
     vf s = splat(0.f);
     AUM_UNROLL
     for (int kk = 0; kk < K; ++kk) {
         const int k = REV ? K - 1 - kk : kk;
-        s = vfma(a[k], s, b[k]);
+        s = vfma(a(k), s, b[k]);
     }
     const vm first = lane_id() == (REV ? WAVE - 1 : 0);
     vf S = vsel(first, vfma(Ptot, carry_in, s), s);
@@ -44,9 +45,14 @@ AUM_DEV void affine_scan_states(const vf (&a)[K], const vf (&b)[K], vf Ptot, vf 
     AUM_UNROLL
     for (int kk = 0; kk < K; ++kk) {
         const int k = REV ? K - 1 - kk : kk;
-        xx = vfma(a[k], xx, b[k]);
+        xx = vfma(a(k), xx, b[k]);
         x[k] = xx;
     }
+}
+template <int K, bool REV>
+AUM_DEV void affine_scan_states(const vf (&a)[K], const vf (&b)[K], vf Ptot, vf carry_in, vf (&x)[K], vf& x_in,
+                                vf& carry_out) {
+    affine_scan_states_f<K, REV>([&](int k) -> const vf& { return a[k]; }, b, Ptot, carry_in, x, x_in, carry_out);
 }
 
 template <class T> AUM_DEV const T* row_ptr(const void* base, int64_t off) { return (const T*)base + off; }

@@ -150,12 +150,40 @@ AUM_DEV void scan_row_write(T* rp, int base, int len, const vi (&t)[K + TAIL], c
     }
 }
 
-// delta = softplus(delta + bias) (masked to 0 outside the row), delta*u, and the lane sum of delta, for the pair's rows
+// Two-row affine scan on packed pairs: x'[k] = a[k]*x + b[k] for both rows of the wave at once (see
+// affine_scan_states_f in scan_kernels.h for the single-row form and the meaning of the arguments).
+template <int K, bool REV, class AF>
+AUM_DEV void affine_scan_states2_f(AF a, const vf2 (&b)[K], vf2 Ptot, vf2 carry_in, vf2 (&x)[K], vf2& x_in, vf2& carry_out) {
+    vf2 s = spl2(splat(0.f));
+    AUM_UNROLL
+    for (int kk = 0; kk < K; ++kk) {
+        const int k = REV ? K - 1 - kk : kk;
+        s = vfma2(a(k), s, b[k]);
+    }
+    const vm first = lane_id() == (REV ? WAVE - 1 : 0);
+    vf2 S = vsel2(first, vfma2(Ptot, carry_in, s), s);
+    vf2 P = Ptot;
+    wave_scan_affine2<REV>(P, S);
+    x_in = REV ? mk2(dpp_wave_shl1(lo2(S), lo2(carry_in)), dpp_wave_shl1(hi2(S), hi2(carry_in)))
+               : mk2(dpp_wave_shr1(lo2(S), lo2(carry_in)), dpp_wave_shr1(hi2(S), hi2(carry_in)));
+    carry_out = mk2(splat(readlane(lo2(S), REV ? 0 : WAVE - 1)), splat(readlane(hi2(S), REV ? 0 : WAVE - 1)));
+    vf2 xx = x_in;
+    AUM_UNROLL
+    for (int kk = 0; kk < K; ++kk) {
+        const int k = REV ? K - 1 - kk : kk;
+        xx = vfma2(a(k), xx, b[k]);
+        x[k] = xx;
+    }
+}
+
+// delta = softplus(delta + bias) (masked to 0 outside the row), delta*u, and the lane sum of delta, for the pair's
+// two rows, packed (row e0 in .x, row e0+1 in .y)
 template <class T, int K, int TAIL>
 AUM_DEV void scanwg_load_rows(const void* u, int64_t u_bs, int64_t u_ds, const void* delta, int64_t d_bs, int64_t d_ds,
                               const float* delta_bias, bool softplus, int b, int e0, int dim, int base, int len,
-                              const vi (&t)[K + TAIL], const vm (&valid)[K + TAIL], vf (&dl)[SCAN_R][K + TAIL],
-                              vf (&dlu)[SCAN_R][K + TAIL], vf (&sumd)[SCAN_R]) {
+                              const vi (&t)[K + TAIL], const vm (&valid)[K + TAIL], vf2 (&dl)[K + TAIL],
+                              vf2 (&dlu)[K + TAIL], vf2& sumd) {
+    vf dls[SCAN_R][K + TAIL], dlus[SCAN_R][K + TAIL], sds[SCAN_R];
     AUM_UNROLL
     for (int r = 0; r < SCAN_R; ++r) {
         const int e = e0 + r;
@@ -173,12 +201,18 @@ AUM_DEV void scanwg_load_rows(const void* u, int64_t u_bs, int64_t u_ds, const v
             vf d = dd[k] + bias;
             if (softplus) d = vsoftplus(d);
             d = vsel(valid[k] && rowok, d, splat(0.f));
-            dl[r][k] = d;
-            dlu[r][k] = d * uu[k];
+            dls[r][k] = d;
+            dlus[r][k] = d * uu[k];
             sd = sd + d;
         }
-        sumd[r] = sd;
+        sds[r] = sd;
     }
+    AUM_UNROLL
+    for (int k = 0; k < K + TAIL; ++k) {
+        dl[k] = mk2(dls[0][k], dls[1][k]);
+        dlu[k] = mk2(dlus[0][k], dlus[1][k]);
+    }
+    sumd = mk2(sds[0], sds[1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -186,41 +220,36 @@ AUM_DEV void scanwg_load_rows(const void* u, int64_t u_bs, int64_t u_ds, const v
 // ------------------------------------------------------------------------------------------------
 template <class T, int K, int TAIL, bool REV>
 AUM_DEV void scanwg_fwd_dir(const AumScanFwdArgs& p, int b, int e0, int rloc, const float* Aptr, const float* Bt,
-                            const float* Ct, const vi (&pos)[K + TAIL], const vf (&dl)[SCAN_R][K + TAIL],
-                            const vf (&dlu)[SCAN_R][K + TAIL], const vf (&sumd)[SCAN_R], float* carry, bool multi,
-                            bool write_last, vf (&y)[SCAN_R][K + TAIL]) {
+                            const float* Ct, const vi (&pos)[K + TAIL], const vf2 (&dl)[K + TAIL],
+                            const vf2 (&dlu)[K + TAIL], vf2 sumd, float* carry, bool multi, bool write_last,
+                            vf2 (&y)[K + TAIL]) {
     using G = ScanGeo<K, TAIL>;
     constexpr int KT = G::KT;
     const int N = p.dstate;
     const vi lane = lane_id();
+    const int e1 = e0 + 1 < p.dim ? e0 + 1 : e0;           // odd dim: the second row mirrors the first, outputs masked
     for (int n = 0; n < N; ++n) {
-        vf Bn[KT], Cn[KT];
+        vf2 a[KT], bb[KT], x[KT];
+        const vf2 An = mk2(splat(Aptr[(int64_t)e0 * N + n] * LOG2E), splat(Aptr[(int64_t)e1 * N + n] * LOG2E));
         AUM_UNROLL
         for (int k = 0; k < KT; ++k) {
-            Bn[k] = lds_read(Bt, pos[k] + n * G::SP);
-            Cn[k] = lds_read(Ct, pos[k] + n * G::SP);
+            a[k] = vexp2_2(dl[k] * An);
+            bb[k] = dlu[k] * spl2(lds_read(Bt, pos[k] + n * G::SP));
         }
+        const vf2 Ptot = vexp2_2(sumd * An);
+        vf2 cin = spl2(splat(0.f));
+        if (multi) cin = mk2(lds_read(carry, spl_i(rloc * SCANWG_MAX_N + n)), lds_read(carry, spl_i((rloc + 1) * SCANWG_MAX_N + n)));
+        vf2 xin, cout;
+        affine_scan_states2_f<KT, REV>([&](int k) -> const vf2& { return a[k]; }, bb, Ptot, cin, x, xin, cout);
         AUM_UNROLL
-        for (int r = 0; r < SCAN_R; ++r) {
-            const int e = e0 + r;
-            if (e < p.dim) {
-                const float An = Aptr[(int64_t)e * N + n] * LOG2E;
-                vf a[KT], bb[KT], x[KT];
-                AUM_UNROLL
-                for (int k = 0; k < KT; ++k) {
-                    a[k] = vexp2(dl[r][k] * An);
-                    bb[k] = dlu[r][k] * Bn[k];
-                }
-                const vf Ptot = vexp2(sumd[r] * An);
-                vf cin = splat(0.f);
-                if (multi) cin = lds_read(carry, spl_i((rloc + r) * SCANWG_MAX_N + n));
-                vf xin, cout;
-                affine_scan_states<KT, REV>(a, bb, Ptot, cin, x, xin, cout);
-                AUM_UNROLL
-                for (int k = 0; k < KT; ++k) y[r][k] = vfma(Cn[k], x[k], y[r][k]);
-                if (multi) lds_write(carry, spl_i((rloc + r) * SCANWG_MAX_N + n), cout);
-                if (write_last) gstore(p.last_state + ((int64_t)b * p.dim + e) * N + n, spl_i(0), cout, lane == 0);
-            }
+        for (int k = 0; k < KT; ++k) y[k] = vfma2(spl2(lds_read(Ct, pos[k] + n * G::SP)), x[k], y[k]);
+        if (multi) {
+            lds_write(carry, spl_i(rloc * SCANWG_MAX_N + n), lo2(cout));
+            lds_write(carry, spl_i((rloc + 1) * SCANWG_MAX_N + n), hi2(cout));
+        }
+        if (write_last) {
+            gstore(p.last_state + ((int64_t)b * p.dim + e0) * N + n, spl_i(0), lo2(cout), lane == 0);
+            if (e0 + 1 < p.dim) gstore(p.last_state + ((int64_t)b * p.dim + e0 + 1) * N + n, spl_i(0), hi2(cout), lane == 0);
         }
     }
 }
@@ -266,14 +295,11 @@ AUM_DEV void scanwg_fwd(const AumScanFwdArgs& p, int wg, float* lds, int rows_pe
                 vi t[KT], pos[KT];
                 vm valid[KT];
                 scan_slots<K, TAIL>(base, p.len, t, valid, pos);
-                vf dl[SCAN_R][KT], dlu[SCAN_R][KT], y[SCAN_R][KT], sumd[SCAN_R];
+                vf2 dl[KT], dlu[KT], y[KT], sumd;
                 scanwg_load_rows<T, K, TAIL>(p.u, p.u_bs, p.u_ds, p.delta, p.delta_bs, p.delta_ds, p.delta_bias, softplus, b,
                                              e0, p.dim, base, p.len, t, valid, dl, dlu, sumd);
                 AUM_UNROLL
-                for (int r = 0; r < SCAN_R; ++r) {
-                    AUM_UNROLL
-                    for (int k = 0; k < KT; ++k) y[r][k] = splat(0.f);
-                }
+                for (int k = 0; k < KT; ++k) y[k] = spl2(splat(0.f));
                 const bool wl = (ci == nchunks - 1) && p.last_state != nullptr;
                 if (!(p.flags & AUM_DBG_SKIP_STATES)) {
                     if (MODE == 0 || BI)
@@ -297,10 +323,10 @@ AUM_DEV void scanwg_fwd(const AumScanFwdArgs& p, int wg, float* lds, int rows_pe
                             scan_row_read<T, K, TAIL>(row_ptr<T>(p.u, (int64_t)b * p.u_bs + (int64_t)e * p.u_ds), base, p.len, t,
                                                       valid, uu);
                             AUM_UNROLL
-                            for (int k = 0; k < KT; ++k) o[k] = vfma(uu[k], splat(Dn), y[r][k]);
+                            for (int k = 0; k < KT; ++k) o[k] = vfma(uu[k], splat(Dn), r == 0 ? lo2(y[k]) : hi2(y[k]));
                         } else {
                             AUM_UNROLL
-                            for (int k = 0; k < KT; ++k) o[k] = y[r][k];
+                            for (int k = 0; k < KT; ++k) o[k] = r == 0 ? lo2(y[k]) : hi2(y[k]);
                         }
                         if (p.out_pre) scan_row_write<T, K, TAIL>(row_ptr_w<T>(p.out_pre, ooff), base, p.len, t, valid, o);
                         if (p.z) {
@@ -320,65 +346,68 @@ AUM_DEV void scanwg_fwd(const AumScanFwdArgs& p, int wg, float* lds, int rows_pe
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward
+// Backward (two rows per wave, packed)
 // ------------------------------------------------------------------------------------------------
 template <class T, int K, int TAIL, bool REV>
-AUM_DEV void scanwg_bwd_dir_state(const AumScanBwdArgs& p, int n, int b, int e0, int rloc, const float* Aptr,
-                                  const vf (&Bn)[K + TAIL], const vf (&Cn)[K + TAIL],
-                                  const vf (&dl)[SCAN_R][K + TAIL], const vf (&dlu)[SCAN_R][K + TAIL],
-                                  const vf (&dy)[SCAN_R][K + TAIL], const vf (&sumd)[SCAN_R],
-                                  const vf (&sumd_next)[SCAN_R], const vf (&dnf)[SCAN_R], const float* xck,
-                                  int64_t xck_row_stride, int chunk, float* gcarry, bool multi,
-                                  vf (&G)[SCAN_R][K + TAIL], vf (&DA)[SCAN_R][K + TAIL], vf (&dBacc)[K + TAIL],
-                                  vf (&dCacc)[K + TAIL], vf (&dAv)[SCAN_R]) {
+AUM_DEV void scanwg_bwd_dir_state(const AumScanBwdArgs& p, int n, int e0, int rloc, const float* Aptr,
+                                  const vf (&Bn)[K + TAIL], const vf (&Cn)[K + TAIL], const vf2 (&dl)[K + TAIL],
+                                  const vf2 (&dlu)[K + TAIL], const vf2 (&dy)[K + TAIL], vf2 sumd, vf2 sumd_next, vf2 dnf,
+                                  const float* xck, int64_t xck_row_stride, int chunk, float* gcarry, bool multi,
+                                  vf2 (&G)[K + TAIL], vf2 (&DA)[K + TAIL], vf2 (&dBacc)[K + TAIL], vf2 (&dCacc)[K + TAIL],
+                                  vf2& dAv) {
     constexpr int KT = K + TAIL;
     const int N = p.dstate;
+    const int e1 = e0 + 1 < p.dim ? e0 + 1 : e0;
+    const vf2 Araw = mk2(splat(Aptr[(int64_t)e0 * N + n]), splat(Aptr[(int64_t)e1 * N + n]));
+    const vf2 An = Araw * spl2(splat(LOG2E));
+    vf2 a[KT], bb[KT], x[KT];
     AUM_UNROLL
-    for (int r = 0; r < SCAN_R; ++r) {
-        const int e = e0 + r;
-        if (e < p.dim) {
-            const float Araw = Aptr[(int64_t)e * N + n];
-            const float An = Araw * LOG2E;
-            vf a[KT], bb[KT], x[KT];
-            AUM_UNROLL
-            for (int k = 0; k < KT; ++k) {
-                a[k] = vexp2(dl[r][k] * An);
-                bb[k] = dlu[r][k] * Bn[k];
-            }
-            const vf Ptot = vexp2(sumd[r] * An);
-            vf cin = splat(0.f);
-            if (multi) cin = gload_coherent(xck + (rloc + r) * xck_row_stride + (int64_t)chunk * N + n, spl_i(0), lane_id() >= 0);
-            vf xin, cout;
-            affine_scan_states<KT, REV>(a, bb, Ptot, cin, x, xin, cout);
-            vf an[KT], cc[KT], g[KT];
-            const vf a_nf = vexp2(dnf[r] * An);
-            AUM_UNROLL
-            for (int k = 0; k < KT; ++k) {
-                cc[k] = dy[r][k] * Cn[k];
-                if (!REV) an[k] = (k + 1 < KT) ? a[k + 1 < KT ? k + 1 : 0] : dpp_wave_shl1(a[0], a_nf);
-                else      an[k] = (k > 0) ? a[k > 0 ? k - 1 : 0] : dpp_wave_shr1(a[KT - 1], a_nf);
-            }
-            const vf Pn = vexp2(sumd_next[r] * An);
-            vf gin_c = splat(0.f);
-            if (multi) gin_c = lds_read(gcarry, spl_i((rloc + r) * SCANWG_MAX_N + n));
-            vf gin, gout;
-            affine_scan_states<KT, !REV>(an, cc, Pn, gin_c, g, gin, gout);
-            if (multi) lds_write(gcarry, spl_i((rloc + r) * SCANWG_MAX_N + n), gout);
-            vf dAl = splat(0.f);
-            AUM_UNROLL
-            for (int k = 0; k < KT; ++k) {
-                const vf xprev = REV ? ((k == KT - 1) ? xin : x[k + 1 < KT ? k + 1 : 0]) : ((k == 0) ? xin : x[k > 0 ? k - 1 : 0]);
-                const vf h = g[k] * a[k] * xprev;
-                G[r][k] = vfma(g[k], Bn[k], G[r][k]);
-                DA[r][k] = vfma(splat(Araw), h, DA[r][k]);
-                dBacc[k] = vfma(g[k], dlu[r][k], dBacc[k]);
-                dCacc[k] = vfma(dy[r][k], x[k], dCacc[k]);
-                dAl = vfma(dl[r][k], h, dAl);
-            }
-            // dA[e][n] partial of this (batch,row): parked in lane n, written once per row after the state loop
-            if (!(p.flags & AUM_DBG_SKIP_PARTIALS)) dAv[r] = vsel(lane_id() == n, splat(wave_sum(dAl)), dAv[r]);
-        }
+    for (int k = 0; k < KT; ++k) {
+        a[k] = vexp2_2(dl[k] * An);
+        bb[k] = dlu[k] * spl2(Bn[k]);
     }
+    const vf2 Ptot = vexp2_2(sumd * An);
+    vf2 cin = spl2(splat(0.f));
+    if (multi)
+        cin = mk2(gload_coherent(xck + rloc * xck_row_stride + (int64_t)chunk * N + n, spl_i(0), lane_id() >= 0),
+                  gload_coherent(xck + (rloc + 1) * xck_row_stride + (int64_t)chunk * N + n, spl_i(0), lane_id() >= 0));
+    vf2 xin, cout;
+    affine_scan_states2_f<KT, REV>([&](int k) -> const vf2& { return a[k]; }, bb, Ptot, cin, x, xin, cout);
+    // adjoint: g_s = dy_s*C_s + a_{s+1} * g_{s+1}, scanned against the recurrence direction; the multiplier of slot k
+    // is a of the slot's scan successor (neighbour lane at the lane edge, next chunk's first step at the chunk edge)
+    vf2 cc[KT], g[KT];
+    const vf2 a_nf = vexp2_2(dnf * An);
+    AUM_UNROLL
+    for (int k = 0; k < KT; ++k) cc[k] = dy[k] * spl2(Cn[k]);
+    const vf2 a_edge = REV ? mk2(dpp_wave_shr1(lo2(a[KT - 1]), lo2(a_nf)), dpp_wave_shr1(hi2(a[KT - 1]), hi2(a_nf)))
+                           : mk2(dpp_wave_shl1(lo2(a[0]), lo2(a_nf)), dpp_wave_shl1(hi2(a[0]), hi2(a_nf)));
+    auto a_succ = [&](int k) -> const vf2& {
+        if (!REV) return (k + 1 < KT) ? a[k + 1 < KT ? k + 1 : 0] : a_edge;
+        return (k > 0) ? a[k > 0 ? k - 1 : 0] : a_edge;
+    };
+    const vf2 Pn = vexp2_2(sumd_next * An);
+    vf2 gin_c = spl2(splat(0.f));
+    if (multi) gin_c = mk2(lds_read(gcarry, spl_i(rloc * SCANWG_MAX_N + n)), lds_read(gcarry, spl_i((rloc + 1) * SCANWG_MAX_N + n)));
+    vf2 gin, gout;
+    affine_scan_states2_f<KT, !REV>(a_succ, cc, Pn, gin_c, g, gin, gout);
+    if (multi) {
+        lds_write(gcarry, spl_i(rloc * SCANWG_MAX_N + n), lo2(gout));
+        lds_write(gcarry, spl_i((rloc + 1) * SCANWG_MAX_N + n), hi2(gout));
+    }
+    vf2 dAl = spl2(splat(0.f));
+    AUM_UNROLL
+    for (int k = 0; k < KT; ++k) {
+        const vf2 xprev = REV ? ((k == KT - 1) ? xin : x[k + 1 < KT ? k + 1 : 0]) : ((k == 0) ? xin : x[k > 0 ? k - 1 : 0]);
+        const vf2 h = g[k] * a[k] * xprev;
+        G[k] = vfma2(g[k], spl2(Bn[k]), G[k]);
+        DA[k] = vfma2(Araw, h, DA[k]);
+        dBacc[k] = vfma2(g[k], dlu[k], dBacc[k]);
+        dCacc[k] = vfma2(dy[k], x[k], dCacc[k]);
+        dAl = vfma2(dl[k], h, dAl);
+    }
+    // dA[e][n] partials of the two rows: parked in lane n, written once per row after the state loop
+    if (!(p.flags & AUM_DBG_SKIP_PARTIALS))
+        dAv = vsel2(lane_id() == n, mk2(splat(wave_sum(lo2(dAl))), splat(wave_sum(hi2(dAl)))), dAv);
 }
 
 template <class T, int K, int TAIL, bool REV>
@@ -389,30 +418,28 @@ AUM_DEV void scanwg_bwd_prepass_pair(const AumScanBwdArgs& p, int b, int e0, int
     const int N = p.dstate;
     const bool softplus = (p.flags & AUM_SCAN_SOFTPLUS) != 0;
     const vi lane = lane_id();
+    const int e1 = e0 + 1 < p.dim ? e0 + 1 : e0;
     vi t[KT], pos[KT];
     vm valid[KT];
     scan_slots<K, TAIL>(base, p.len, t, valid, pos);
-    vf dl[SCAN_R][KT], dlu[SCAN_R][KT], sumd[SCAN_R];
+    vf2 dl[KT], dlu[KT], sumd;
     scanwg_load_rows<T, K, TAIL>(p.u, p.u_bs, p.u_ds, p.delta, p.delta_bs, p.delta_ds, p.delta_bias, softplus, b, e0, p.dim,
                                  base, p.len, t, valid, dl, dlu, sumd);
     for (int n = 0; n < N; ++n) {
-        vf Bn[KT];
+        const vf2 An = mk2(splat(Aptr[(int64_t)e0 * N + n] * LOG2E), splat(Aptr[(int64_t)e1 * N + n] * LOG2E));
+        vf2 a[KT], bb[KT], x[KT];
         AUM_UNROLL
-        for (int k = 0; k < KT; ++k) Bn[k] = lds_read(Bt, pos[k] + n * G::SP);
-        AUM_UNROLL
-        for (int r = 0; r < SCAN_R; ++r) {
-            if (e0 + r < p.dim) {
-                const float An = Aptr[(int64_t)(e0 + r) * N + n] * LOG2E;
-                vf a[KT], bb[KT], x[KT];
-                AUM_UNROLL
-                for (int k = 0; k < KT; ++k) { a[k] = vexp2(dl[r][k] * An); bb[k] = dlu[r][k] * Bn[k]; }
-                const vf cin = lds_read(xcarry, spl_i((rloc + r) * SCANWG_MAX_N + n));
-                gstore_coherent(xck + (rloc + r) * xck_row_stride + (int64_t)c * N + n, spl_i(0), cin, lane == 0);
-                vf xin, cout;
-                affine_scan_states<KT, REV>(a, bb, vexp2(sumd[r] * An), cin, x, xin, cout);
-                lds_write(xcarry, spl_i((rloc + r) * SCANWG_MAX_N + n), cout);
-            }
+        for (int k = 0; k < KT; ++k) {
+            a[k] = vexp2_2(dl[k] * An);
+            bb[k] = dlu[k] * spl2(lds_read(Bt, pos[k] + n * G::SP));
         }
+        const vf2 cin = mk2(lds_read(xcarry, spl_i(rloc * SCANWG_MAX_N + n)), lds_read(xcarry, spl_i((rloc + 1) * SCANWG_MAX_N + n)));
+        gstore_coherent(xck + rloc * xck_row_stride + (int64_t)c * N + n, spl_i(0), lo2(cin), lane == 0);
+        gstore_coherent(xck + (rloc + 1) * xck_row_stride + (int64_t)c * N + n, spl_i(0), hi2(cin), lane == 0);
+        vf2 xin, cout;
+        affine_scan_states2_f<KT, REV>([&](int k) -> const vf2& { return a[k]; }, bb, vexp2_2(sumd * An), cin, x, xin, cout);
+        lds_write(xcarry, spl_i(rloc * SCANWG_MAX_N + n), lo2(cout));
+        lds_write(xcarry, spl_i((rloc + 1) * SCANWG_MAX_N + n), hi2(cout));
     }
 }
 
@@ -486,13 +513,14 @@ AUM_DEV void scanwg_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_pe
                 const int rloc = 2 * pair;
                 const int e0 = eb + rloc;
                 const bool active = e0 < p.dim;      // wave-uniform; inactive waves still take every barrier below
+                const int e0c = active ? e0 : p.dim - 1;
                 vi t[KT], pos[KT];
                 vm valid[KT];
                 scan_slots<K, TAIL>(base, p.len, t, valid, pos);
-                vf dl[SCAN_R][KT], dlu[SCAN_R][KT], dy[SCAN_R][KT], G[SCAN_R][KT], DA[SCAN_R][KT];
-                vf sumd[SCAN_R], sumd_nf[SCAN_R], sumd_nr[SCAN_R], dnf_f[SCAN_R], dnf_r[SCAN_R];
+                vf2 dl[KT], dlu[KT], dy[KT], G[KT], DA[KT], sumd;
                 scanwg_load_rows<T, K, TAIL>(p.u, p.u_bs, p.u_ds, p.delta, p.delta_bs, p.delta_ds, p.delta_bias, softplus, b,
                                              e0, p.dim, base, p.len, t, valid, dl, dlu, sumd);   // rows >= dim give zeros
+                vf dys[SCAN_R][KT], dfs[SCAN_R], drs[SCAN_R];
                 AUM_UNROLL
                 for (int r = 0; r < SCAN_R; ++r) {
                     const int e = e0 + r;
@@ -520,11 +548,7 @@ AUM_DEV void scanwg_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_pe
                                                        p.len, t, valid, dzv);
                     }
                     AUM_UNROLL
-                    for (int k = 0; k < KT; ++k) {
-                        dy[r][k] = rowok ? go[k] : splat(0.f);
-                        G[r][k] = splat(0.f);
-                        DA[r][k] = splat(0.f);
-                    }
+                    for (int k = 0; k < KT; ++k) dys[r][k] = rowok ? go[k] : splat(0.f);
                     const int tf = base + S, tr = base - 1;
                     vf df = splat(0.f), dr = splat(0.f);
                     if (multi && rowok) {
@@ -537,15 +561,21 @@ AUM_DEV void scanwg_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_pe
                             if (softplus) dr = vsoftplus(dr);
                         }
                     }
-                    dnf_f[r] = df;
-                    dnf_r[r] = dr;
-                    sumd_nf[r] = sumd[r] - dl[r][0] + dpp_wave_shl1(dl[r][0], df);
-                    sumd_nr[r] = sumd[r] - dl[r][KT - 1] + dpp_wave_shr1(dl[r][KT - 1], dr);
+                    dfs[r] = df;
+                    drs[r] = dr;
                 }
-                const bool first_visit = ci == 0;
-                vf dAv0[SCAN_R], dAv1[SCAN_R];      // lane n <- dA (dA_b) partial of state n, per row
                 AUM_UNROLL
-                for (int r = 0; r < SCAN_R; ++r) { dAv0[r] = splat(0.f); dAv1[r] = splat(0.f); }
+                for (int k = 0; k < KT; ++k) {
+                    dy[k] = mk2(dys[0][k], dys[1][k]);
+                    G[k] = spl2(splat(0.f));
+                    DA[k] = spl2(splat(0.f));
+                }
+                const vf2 dnf_f = mk2(dfs[0], dfs[1]), dnf_r = mk2(drs[0], drs[1]);
+                const vf2 sumd_nf = sumd - dl[0] + mk2(dpp_wave_shl1(lo2(dl[0]), dfs[0]), dpp_wave_shl1(hi2(dl[0]), dfs[1]));
+                const vf2 sumd_nr = sumd - dl[KT - 1] +
+                                    mk2(dpp_wave_shr1(lo2(dl[KT - 1]), drs[0]), dpp_wave_shr1(hi2(dl[KT - 1]), drs[1]));
+                const bool first_visit = ci == 0;
+                vf2 dAv0 = spl2(splat(0.f)), dAv1 = spl2(splat(0.f));      // lane n <- dA (dA_b) partial of state n
                 // Rotated state order: at step j wave w works on state (j + 2w) mod 16, so no two of the 8 waves ever
                 // hold the same state row of the dB/dC tiles within a step, nor in adjacent steps (j+1+2w = j+2w' has no
                 // solution); a barrier after every SECOND step therefore keeps any two waves at most one step apart and
@@ -553,25 +583,26 @@ AUM_DEV void scanwg_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_pe
                 for (int j = 0; j < SCANWG_MAX_N; ++j) {
                     const int n = (j + 2 * w) & (SCANWG_MAX_N - 1);
                     if (active && n < N) {
-                        vf Bn[KT], Cn[KT], dBacc[KT], dCacc[KT];
+                        vf Bn[KT], Cn[KT];
+                        vf2 dBacc[KT], dCacc[KT];
                         AUM_UNROLL
                         for (int k = 0; k < KT; ++k) {
                             Bn[k] = lds_read(Bt, pos[k] + n * GE::SP);
                             Cn[k] = lds_read(Ct, pos[k] + n * GE::SP);
-                            dBacc[k] = splat(0.f);
-                            dCacc[k] = splat(0.f);
+                            dBacc[k] = spl2(splat(0.f));
+                            dCacc[k] = spl2(splat(0.f));
                         }
                         if (!(p.flags & AUM_DBG_SKIP_STATES)) {
                             if (MODE == 0 || BI)
-                                scanwg_bwd_dir_state<T, K, TAIL, false>(p, n, b, e0, rloc, p.A, Bn, Cn, dl, dlu, dy, sumd, sumd_nf,
+                                scanwg_bwd_dir_state<T, K, TAIL, false>(p, n, e0c, rloc, p.A, Bn, Cn, dl, dlu, dy, sumd, sumd_nf,
                                                                         dnf_f, xck, xck_row_stride, c, gcarry, multi, G, DA,
                                                                         dBacc, dCacc, dAv0);
                             if (MODE == 1)
-                                scanwg_bwd_dir_state<T, K, TAIL, true>(p, n, b, e0, rloc, p.A, Bn, Cn, dl, dlu, dy, sumd, sumd_nr,
+                                scanwg_bwd_dir_state<T, K, TAIL, true>(p, n, e0c, rloc, p.A, Bn, Cn, dl, dlu, dy, sumd, sumd_nr,
                                                                        dnf_r, xck, xck_row_stride, c, gcarry, multi, G, DA,
                                                                        dBacc, dCacc, dAv0);
                             if (BI)
-                                scanwg_bwd_dir_state<T, K, TAIL, true>(p, n, b, e0, rloc, p.A_b, Bn, Cn, dl, dlu, dy, sumd, sumd_nr,
+                                scanwg_bwd_dir_state<T, K, TAIL, true>(p, n, e0c, rloc, p.A_b, Bn, Cn, dl, dlu, dy, sumd, sumd_nr,
                                                                        dnf_r, nullptr, 0, c,
                                                                        gcarry + SCANWG_MAX_ROWS * SCANWG_MAX_N, false, G, DA,
                                                                        dBacc, dCacc, dAv1);
@@ -582,8 +613,8 @@ AUM_DEV void scanwg_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_pe
                                 const vi at = pos[k] + n * GE::SP;
                                 // tail slots are shared by all lanes but owned by the last one
                                 const vm own = k < K ? (lane >= 0) : (lane == WAVE - 1);
-                                lds_write_m(dBt, at, lds_read(dBt, at) + dBacc[k], own);
-                                lds_write_m(dCt, at, lds_read(dCt, at) + dCacc[k], own);
+                                lds_write_m(dBt, at, lds_read(dBt, at) + (lo2(dBacc[k]) + hi2(dBacc[k])), own);
+                                lds_write_m(dCt, at, lds_read(dCt, at) + (lo2(dCacc[k]) + hi2(dCacc[k])), own);
                             }
                         }
                     }
@@ -598,14 +629,16 @@ AUM_DEV void scanwg_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_pe
                             float* sAb = ws + L.pAb + ((int64_t)b * p.dim + e) * N;
                             const vm mn = lane < N;
                             const vi ln = vmin_i(lane, N - 1);
+                            vf v0 = r == 0 ? lo2(dAv0) : hi2(dAv0);
+                            const vf v1 = r == 0 ? lo2(dAv1) : hi2(dAv1);
                             if (!first_visit) {     // later chunks of a multi-chunk row accumulate (same wave wrote it)
-                                dAv0[r] = dAv0[r] + gload_coherent(sA, ln, mn);
-                                gstore_coherent(sA, ln, dAv0[r], mn);
+                                v0 = v0 + gload_coherent(sA, ln, mn);
+                                gstore_coherent(sA, ln, v0, mn);
                             } else if (multi) {
-                                gstore_coherent(sA, ln, dAv0[r], mn);
+                                gstore_coherent(sA, ln, v0, mn);
                             } else {
-                                gstore(sA, ln, dAv0[r], mn);
-                                if (BI) gstore(sAb, ln, dAv1[r], mn);
+                                gstore(sA, ln, v0, mn);
+                                if (BI) gstore(sAb, ln, v1, mn);
                             }
                         }
                     }
@@ -625,15 +658,19 @@ AUM_DEV void scanwg_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_pe
                             vf dDl = splat(0.f), dbl = splat(0.f);
                             AUM_UNROLL
                             for (int k = 0; k < KT; ++k) {
-                                duv[k] = vfma(dl[r][k], G[r][k], dy[r][k] * Dn);
-                                vf dd = vfma(uu[k], G[r][k], DA[r][k]);
+                                const vf dlk = r == 0 ? lo2(dl[k]) : hi2(dl[k]);
+                                const vf Gk = r == 0 ? lo2(G[k]) : hi2(G[k]);
+                                const vf DAk = r == 0 ? lo2(DA[k]) : hi2(DA[k]);
+                                const vf dyk = r == 0 ? lo2(dy[k]) : hi2(dy[k]);
+                                duv[k] = vfma(dlk, Gk, dyk * Dn);
+                                vf dd = vfma(uu[k], Gk, DAk);
                                 if (softplus) {
                                     const vf rw = raw[k] + bias;
                                     dd = vsel(rw > 20.f, dd, dd * vsigmoid(rw));
                                 }
                                 dd = vsel(valid[k], dd, splat(0.f));
                                 ddv[k] = dd;
-                                dDl = vfma(dy[r][k], uu[k], dDl);
+                                dDl = vfma(dyk, uu[k], dDl);
                                 dbl = dbl + dd;
                             }
                             scan_row_write<T, K, TAIL>(row_ptr_w<T>(p.du, (int64_t)b * p.du_bs + (int64_t)e * p.du_ds), base, p.len,

@@ -97,6 +97,19 @@ AUM_DEV bool any_lane(vm m) { return __any(m); }
 AUM_DEV vi vmin_i(vi a, int b) { return a < b ? a : b; }
 AUM_DEV vi vmax_i(vi a, int b) { return a > b ? a : b; }
 
+// Packed pair of fp32 lanes-values: the VALU of gfx950 executes a wave64 fp32 instruction in 4 cycles (measured:
+// SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.2-4.5 on the scan kernels) and the packed forms v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 do TWO fp32 per lane in the same 4 cycles -- the 157 TFLOP/s vector peak is a packed-math number.
+// The scan kernels therefore carry their two rows per wave as one vf2.
+typedef float vf2 __attribute__((ext_vector_type(2)));
+AUM_DEV vf2 mk2(vf a, vf b) { return vf2{a, b}; }
+AUM_DEV vf2 spl2(vf a) { return vf2{a, a}; }
+AUM_DEV vf lo2(vf2 v) { return v.x; }
+AUM_DEV vf hi2(vf2 v) { return v.y; }
+AUM_DEV vf2 vfma2(vf2 a, vf2 b, vf2 c) { return __builtin_elementwise_fma(a, b, c); }
+AUM_DEV vf2 vexp2_2(vf2 x) { return vf2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+AUM_DEV vf2 vsel2(vm m, vf2 a, vf2 b) { return m ? a : b; }
+
 template <class T> AUM_DEV vf gload(const T* p, vi idx, vm m) { return m ? elem_to_f32(p[idx]) : 0.f; }
 template <class T> AUM_DEV void gstore(T* p, vi idx, vf v, vm m) { if (m) f32_to_elem(v, p[idx]); }
 // unconditional load (caller clamps idx into range): no exec-mask branch, so several can be in flight
@@ -241,6 +254,19 @@ inline float vexp2(float x) { return std::exp2(x); }
 inline float vlog2(float x) { return std::log2(x); }
 inline float vrcp(float x) { return 1.0f / x; }
 inline float vsel(bool m, float a, float b) { return m ? a : b; }
+
+struct vf2 { vf x, y; };
+inline vf2 mk2(const vf& a, const vf& b) { return vf2{a, b}; }
+inline vf2 spl2(const vf& a) { return vf2{a, a}; }
+inline vf2 spl2(float a) { return vf2{splat(a), splat(a)}; }
+inline vf lo2(const vf2& v) { return v.x; }
+inline vf hi2(const vf2& v) { return v.y; }
+inline vf2 operator*(const vf2& a, const vf2& b) { return vf2{a.x * b.x, a.y * b.y}; }
+inline vf2 operator+(const vf2& a, const vf2& b) { return vf2{a.x + b.x, a.y + b.y}; }
+inline vf2 operator-(const vf2& a, const vf2& b) { return vf2{a.x - b.x, a.y - b.y}; }
+inline vf2 vfma2(const vf2& a, const vf2& b, const vf2& c) { return vf2{vfma(a.x, b.x, c.x), vfma(a.y, b.y, c.y)}; }
+inline vf2 vexp2_2(const vf2& v) { return vf2{vexp2(v.x), vexp2(v.y)}; }
+inline vf2 vsel2(const vm& m, const vf2& a, const vf2& b) { return vf2{vsel(m, a.x, b.x), vsel(m, a.y, b.y)}; }
 
 template <class T> inline vf gload(const T* p, const vi& idx, const vm& m) {
     vf r; AUM_LANES r.v[l] = m.v[l] ? elem_to_f32(p[idx.v[l]]) : 0.f; return r;
@@ -409,6 +435,57 @@ template <bool REV> AUM_DEV void wave_scan_affine(vf& P, vf& S) {
         (void)P0;
     }
 }
+#endif
+
+// Two independent scans at once (the two rows a wave carries).  On the device the two chains are interleaved in one
+// statement, which also fills the DPP wait states that the single-chain version pads with s_nop.
+#ifdef AUM_EMU
+template <bool REV> inline void wave_scan_affine2(vf2& P, vf2& S) {
+    wave_scan_affine<REV>(P.x, S.x);
+    wave_scan_affine<REV>(P.y, S.y);
+}
+#else
+#define AUM_SCAN2_STEP(ctrl)                                              \
+    "v_fmac_f32_dpp %2, %2, %0 " ctrl "\n\t"                              \
+    "v_mul_f32_dpp %0, %0, %0 " ctrl "\n\t"                               \
+    "v_fmac_f32_dpp %3, %3, %1 " ctrl "\n\t"                              \
+    "v_mul_f32_dpp %1, %1, %1 " ctrl "\n\t"
+template <bool REV> AUM_DEV void wave_scan_affine2(vf2& P, vf2& S) {
+    float p0 = P.x, p1 = P.y, s0 = S.x, s1 = S.y;
+    if constexpr (!REV) {
+        asm volatile("s_nop 1\n\t"
+                     AUM_SCAN2_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+                     AUM_SCAN2_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                     AUM_SCAN2_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+                     AUM_SCAN2_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                     AUM_SCAN2_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                     AUM_SCAN2_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                     "s_nop 0"
+                     : "+v"(p0), "+v"(p1), "+v"(s0), "+v"(s1));
+    } else {
+        asm volatile("s_nop 1\n\t"
+                     AUM_SCAN2_STEP("row_shl:1 row_mask:0xf bank_mask:0xf")
+                     AUM_SCAN2_STEP("row_shl:2 row_mask:0xf bank_mask:0xf")
+                     AUM_SCAN2_STEP("row_shl:4 row_mask:0xf bank_mask:0xf")
+                     AUM_SCAN2_STEP("row_shl:8 row_mask:0xf bank_mask:0xf")
+                     "s_nop 0"
+                     : "+v"(p0), "+v"(p1), "+v"(s0), "+v"(s1));
+        const vi ord = 3 - (lane_id() >> 4);
+        {
+            const float S0 = readlane(s0, 48), P1 = readlane(p0, 32), S1 = readlane(s0, 32), P2 = readlane(p0, 16), S2 = readlane(s0, 16);
+            const float E2S = vfma(P1, S0, S1), E3S = vfma(P2, E2S, S2);
+            s0 = vfma(p0, vsel(ord == 1, S0, vsel(ord == 2, E2S, vsel(ord == 3, E3S, 0.f))), s0);
+        }
+        {
+            const float S0 = readlane(s1, 48), P1 = readlane(p1, 32), S1 = readlane(s1, 32), P2 = readlane(p1, 16), S2 = readlane(s1, 16);
+            const float E2S = vfma(P1, S0, S1), E3S = vfma(P2, E2S, S2);
+            s1 = vfma(p1, vsel(ord == 1, S0, vsel(ord == 2, E2S, vsel(ord == 3, E3S, 0.f))), s1);
+        }
+    }
+    P = vf2{p0, p1};
+    S = vf2{s0, s1};
+}
+#undef AUM_SCAN2_STEP
 #endif
 
 }  // namespace aum
