@@ -59,7 +59,15 @@ class NormArgs(C.Structure):
                 + [("flags", _u32)])
 
 
-EXPORTS = ["aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
+class FbankArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("wave", "window", "twiddle", "mel_start_f", "mel_count_f", "mel_w", "out")]
+                + [(n, _i64) for n in ("wave_bs", "out_bs")]
+                + [(n, _i32) for n in ("batch", "n_samples", "win", "shift", "padded", "num_frames", "target_length",
+                                       "num_mel", "mel_wstride")]
+                + [(n, C.c_float) for n in ("preemph", "norm_mean", "norm_inv2std", "log_floor")])
+
+
+EXPORTS = ["aum_fbank_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
            "aum_selective_scan_workspace_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy"]
 
@@ -81,6 +89,7 @@ class Lib:
         for n in ("aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd",
                   "aum_rmsnorm_fwd", "aum_rmsnorm_bwd"):
             getattr(self.c, n).argtypes = [_vp, _vp]
+        self.c.aum_fbank_fwd.argtypes = [_vp, _vp]
         self.c.aum_selftest_wave_scan.argtypes = [_vp, _vp, C.c_int, _vp]
         self.c.aum_hbm_copy.argtypes = [_vp, _vp, _i64, _vp]
         assert self.c.aum_abi_version() == 1
@@ -380,6 +389,30 @@ def rmsnorm_bwd(dy, x_saved, weight, rstd, dresidual=None, has_residual=False, x
     if has_residual and dres_in is None:
         dres_in = dx
     return dx, dw, dres_in
+
+
+def fbank_fwd(wave, tables, target_length, norm_mean, norm_std, preemph=0.97, lib=None):
+    """Log-mel frontend.  wave: (batch, n_samples) fp32 mean-removed; tables: dict(window, twiddle, mel_start_f,
+    mel_count_f, mel_w [num_mel, stride], win, shift, padded) of device tensors built by aum.frontend.FbankTables."""
+    lib = lib or get()
+    lib.check_tensor(wave)
+    assert wave.dtype == torch.float32 and wave.stride(1) == 1
+    batch, n = wave.shape
+    win, shift, padded = tables["win"], tables["shift"], tables["padded"]
+    num_frames = 0 if n < win else min(target_length, 1 + (n - win) // shift)
+    num_mel, stride = tables["mel_w"].shape
+    out = torch.empty((batch, target_length, num_mel), dtype=torch.float32, device=wave.device)
+    a = FbankArgs()
+    a.wave, a.out = _ptr(wave), _ptr(out)
+    a.window, a.twiddle = _ptr(tables["window"]), _ptr(tables["twiddle"])
+    a.mel_start_f, a.mel_count_f, a.mel_w = _ptr(tables["mel_start_f"]), _ptr(tables["mel_count_f"]), _ptr(tables["mel_w"])
+    a.wave_bs, a.out_bs = wave.stride(0), out.stride(0)
+    a.batch, a.n_samples, a.win, a.shift, a.padded = batch, n, win, shift, padded
+    a.num_frames, a.target_length, a.num_mel, a.mel_wstride = num_frames, target_length, num_mel, stride
+    a.preemph, a.norm_mean, a.norm_inv2std = preemph, norm_mean, 1.0 / (2.0 * norm_std)
+    a.log_floor = 1.1920928955078125e-07
+    _launch(lib.c.aum_fbank_fwd, a, wave, lib, "fbank_fwd", (batch, target_length, num_mel))
+    return out
 
 
 def selftest_wave_scan(P, S, rev=False, lib=None):

@@ -94,6 +94,7 @@ AUM_DEV vf vmax(vf a, vf b) { return __builtin_fmaxf(a, b); }
 AUM_DEV vf vsel(vm m, vf a, vf b) { return m ? a : b; }
 AUM_DEV vi vsel_i(vm m, vi a, vi b) { return m ? a : b; }
 AUM_DEV bool any_lane(vm m) { return __any(m); }
+AUM_DEV vi vcvt_i(vf x) { return (int)x; }
 AUM_DEV vi vmin_i(vi a, int b) { return a < b ? a : b; }
 AUM_DEV vi vmax_i(vi a, int b) { return a > b ? a : b; }
 
@@ -220,7 +221,7 @@ AUM_CMP_F(<) AUM_CMP_F(>) AUM_CMP_F(<=) AUM_CMP_F(>=) AUM_CMP_F(==)
     inline vi operator op(const vi& a, const vi& b) { vi r; AUM_LANES r.v[l] = a.v[l] op b.v[l]; return r; } \
     inline vi operator op(const vi& a, int b) { vi r; AUM_LANES r.v[l] = a.v[l] op b; return r; }            \
     inline vi operator op(int a, const vi& b) { vi r; AUM_LANES r.v[l] = a op b.v[l]; return r; }
-AUM_BINOP_I(+) AUM_BINOP_I(-) AUM_BINOP_I(*) AUM_BINOP_I(/) AUM_BINOP_I(%) AUM_BINOP_I(&) AUM_BINOP_I(>>)
+AUM_BINOP_I(+) AUM_BINOP_I(-) AUM_BINOP_I(*) AUM_BINOP_I(/) AUM_BINOP_I(%) AUM_BINOP_I(&) AUM_BINOP_I(>>) AUM_BINOP_I(<<)
 #define AUM_CMP_I(op)                                                                          \
     inline vm operator op(const vi& a, const vi& b) { vm r; AUM_LANES r.v[l] = a.v[l] op b.v[l]; return r; } \
     inline vm operator op(const vi& a, int b) { vm r; AUM_LANES r.v[l] = a.v[l] op b; return r; }
@@ -246,6 +247,7 @@ inline vf vsel(const vm& m, const vf& a, float b) { return vsel(m, a, splat(b));
 inline vf vsel(const vm& m, float a, const vf& b) { return vsel(m, splat(a), b); }
 inline vi vsel_i(const vm& m, const vi& a, const vi& b) { vi r; AUM_LANES r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
 inline bool any_lane(const vm& m) { bool r = false; AUM_LANES r = r || m.v[l]; return r; }
+inline vi vcvt_i(const vf& x) { vi r; AUM_LANES r.v[l] = (int)x.v[l]; return r; }
 inline vi vmin_i(const vi& a, int b) { vi r; AUM_LANES r.v[l] = a.v[l] < b ? a.v[l] : b; return r; }
 inline vi vmax_i(const vi& a, int b) { vi r; AUM_LANES r.v[l] = a.v[l] > b ? a.v[l] : b; return r; }
 // scalar (wave-uniform) overloads so kernel code can mix uniform floats freely

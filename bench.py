@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--size", default="base")
     ap.add_argument("--depth", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frontend", action="store_true", help="start from spectrograms instead of waveforms")
     args = ap.parse_args()
 
     import aum_hip
@@ -123,13 +124,21 @@ def main():
                                                         bucket_cap_mb=64, broadcast_buffers=False)
     loss_fn = torch.nn.BCEWithLogitsLoss()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.randn(args.batch, 1024, 128, device=dev, generator=g) * 0.5       # SURVEY 8d synthetic spectrograms
+    if args.no_frontend:
+        x = torch.randn(args.batch, 1024, 128, device=dev, generator=g) * 0.5   # SURVEY 8d synthetic spectrograms
+        spec = lambda: x
+    else:   # 10 s / 16 kHz synthetic waveforms; the fused log-mel frontend runs inside the timed step (config 2)
+        from aum.frontend import FbankTables, wav2fbank
+        tabs = FbankTables(dev)
+        wave = (torch.randn(args.batch, 160000, device=dev, generator=g) * 0.1).clamp_(-1, 1)
+        spec = lambda: wav2fbank(wave, tabs, target_length=1024)
     y = torch.zeros(args.batch, n_class, device=dev)
     y.scatter_(1, torch.randint(0, n_class, (args.batch, 2), device=dev, generator=g), 1.0)
 
     def step():
+        xin = spec()
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            logits = net(x)
+            logits = net(xin)
             loss = loss_fn(logits.float(), y)
         loss.backward()
         opt.step()
@@ -181,7 +190,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"AuM-{args.size.capitalize()} (d_model={model.embed_dim}, {args.depth} Fo-Bi blocks, "
                                    f"d_state=16, {n_params / 1e6:.1f}M params) 128-mel x 1024-frame clips, L=513 tokens, "
-                                   "fwd+bwd+Adam, bf16 autocast / fp32 master weights",
+                                   "fwd+bwd+Adam, bf16 autocast / fp32 master weights"
+                                   + ("" if args.no_frontend else ", input = 160000-sample waveforms through the HIP log-mel frontend"),
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}" + (" (DDP, RCCL all-reduce overlapped with backward)" if world > 1 else "")},
             "roofline": roof,

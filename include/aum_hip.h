@@ -161,6 +161,23 @@ int aum_rmsnorm_fwd(const AumNormArgs* args, void* stream);
 int aum_rmsnorm_bwd(const AumNormArgs* args, void* stream);
 int aum_rmsnorm_bwd_partials(int32_t rows);
 
+/*
+ * Log-mel filterbank frontend (replaces torchaudio.compliance.kaldi.fbank + pad + normalise on the CPU DataLoader
+ * workers, src/dataloader.py:134-147, 220-221).
+ *   wave : (batch, n_samples) fp32, already mean-removed (dataloader.py:101);  out : (batch, target_length, num_mel) fp32
+ *   window (win), twiddle (padded/2 complex pairs exp(-2 pi i k / padded)), mel_start_f / mel_count_f (num_mel, small
+ *   integers stored as fp32), mel_w (num_mel, mel_wstride): tables built by the host (aum/frontend.py).
+ *   frames >= num_frames are written as the reference's zero padding after normalisation.
+ */
+typedef struct AumFbankArgs {
+    const float *wave, *window, *twiddle, *mel_start_f, *mel_count_f, *mel_w;
+    float *out;
+    int64_t wave_bs, out_bs;
+    int32_t batch, n_samples, win, shift, padded, num_frames, target_length, num_mel, mel_wstride;
+    float preemph, norm_mean, norm_inv2std, log_floor;
+} AumFbankArgs;
+int aum_fbank_fwd(const AumFbankArgs* args, void* stream);
+
 /* Self-tests and calibration (used by tests/ and bench.py; not part of the reference's surface). */
 int aum_abi_version(void);
 /* runs wave_scan_affine<rev> on 64 (P,S) pairs: in/out are device arrays of 128 floats (P[0..63], S[0..63]) */
