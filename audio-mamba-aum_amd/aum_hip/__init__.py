@@ -252,12 +252,17 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=
         dz = dz_out if dz_out is not None else _alloc(batch, dim, length, u.dtype, dev, dmajor)
         _unit(dz, "dz")
     f32 = dict(dtype=torch.float32, device=dev)
-    dA = torch.zeros((dim, dstate), **f32)
-    dA_b = torch.zeros((dim, dstate), **f32) if A_b is not None else None
-    dB = torch.zeros((batch, dstate, length), **f32)
-    dC = torch.zeros((batch, dstate, length), **f32)
-    dD = torch.zeros((dim,), **f32) if D is not None else None
-    dbias = torch.zeros((dim,), **f32) if delta_bias is not None else None
+    # one zero-fill for all accumulate-into outputs (dA, dA_b, dD, ddelta_bias, dB, dC) instead of six
+    nA, nBC = dim * dstate, batch * dstate * length
+    sizes = [nA, nA if A_b is not None else 0, dim if D is not None else 0, dim if delta_bias is not None else 0, nBC, nBC]
+    zbuf = torch.zeros((sum(sizes),), **f32)
+    parts = torch.split(zbuf, sizes)
+    dA = parts[0].view(dim, dstate)
+    dA_b = parts[1].view(dim, dstate) if A_b is not None else None
+    dD = parts[2] if D is not None else None
+    dbias = parts[3] if delta_bias is not None else None
+    dB = parts[4].view(batch, dstate, length)
+    dC = parts[5].view(batch, dstate, length)
     ws_bytes = int(lib.c.aum_selective_scan_workspace_bytes(batch, dim, length, dstate, int(A_b is not None), 1))
     ws = torch.empty((max(ws_bytes, 4) // 4,), **f32) if ws_bytes else None
     a = ScanBwdArgs()
