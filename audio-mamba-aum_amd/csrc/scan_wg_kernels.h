@@ -92,10 +92,35 @@ template <int K, int TAIL> AUM_DEV vi scan_tile_pos(vi tt) {
 }
 
 // Cooperative load of one [N][S] tile of B (or C) into LDS as fp32; t outside [0,len) -> 0.
+// K == 8 with the main part inside the row: 16-byte loads of 8 consecutive steps (= one lane's main slots), so a tile is
+// 2 load instructions per thread instead of 36 dependent 2-byte gathers; otherwise element-wise.
 template <class T, int K, int TAIL>
 AUM_DEV void scanwg_load_tile(const T* src, int64_t n_stride, int N, int base, int len, float* tile, int w) {
     using G = ScanGeo<K, TAIL>;
     const vi lane = lane_id();
+    if constexpr (K == 8) {
+        if (base + WAVE * K <= len) {
+            for (int i0 = w * WAVE; i0 < N * WAVE; i0 += SCANWG_NW * WAVE) {      // (state n, lane-block j) pairs
+                const vi idx = lane + i0;
+                const vm in = idx < N * WAVE;
+                const vi n = vmin_i(idx >> 6, N - 1);
+                const vi j = idx & (WAVE - 1);
+                vf v[8];
+                gload8(src, n * (int)n_stride + j * 8 + base, in, v);
+                AUM_UNROLL
+                for (int k = 0; k < 8; ++k) lds_write_m(tile, n * G::SP + j * G::LK + k, v[k], in);
+            }
+            if (TAIL > 0) {       // tail columns: N x TAIL scalars
+                const vi n = vmin_i(lane / (TAIL > 0 ? TAIL : 1), N - 1);
+                const vi jt = lane - (lane / (TAIL > 0 ? TAIL : 1)) * (TAIL > 0 ? TAIL : 1);
+                const vm in = (lane < N * TAIL) && (spl_i(w) == 0);
+                const vi t = jt + (base + WAVE * K);
+                const vf v = vsel(t < len, gload_u(src, n * (int)n_stride + vmin_i(t, len - 1)), splat(0.f));
+                lds_write_m(tile, n * G::SP + WAVE * G::LK + jt, v, in);
+            }
+            return;
+        }
+    }
     for (int i0 = w * WAVE; i0 < N * G::S; i0 += SCANWG_NW * WAVE) {
         const vi idx = lane + i0;
         const vm in = idx < N * G::S;
@@ -104,6 +129,43 @@ AUM_DEV void scanwg_load_tile(const T* src, int64_t n_stride, int N, int base, i
         const vi t = tt + base;
         const vf v = vsel(t < len, gload_u(src, n * (int)n_stride + vmin_i(t, len - 1)), splat(0.f));
         lds_write_m(tile, n * G::SP + scan_tile_pos<K, TAIL>(tt), v, in);
+    }
+}
+
+// Write one [N][S] fp32 LDS tile to a dense (N, len) fp32 global partial (t >= len skipped); vectorised like the load.
+template <int K, int TAIL>
+AUM_DEV void scanwg_store_tile(const float* tile, float* dst, int N, int base, int len, int w) {
+    using G = ScanGeo<K, TAIL>;
+    const vi lane = lane_id();
+    if constexpr (K == 8) {
+        if (base + WAVE * K <= len) {
+            for (int i0 = w * WAVE; i0 < N * WAVE; i0 += SCANWG_NW * WAVE) {
+                const vi idx = lane + i0;
+                const vm in = idx < N * WAVE;
+                const vi n = vmin_i(idx >> 6, N - 1);
+                const vi j = idx & (WAVE - 1);
+                vf v[8];
+                AUM_UNROLL
+                for (int k = 0; k < 8; ++k) v[k] = lds_read(tile, n * G::SP + j * G::LK + k);
+                gstore8(dst, n * len + j * 8 + base, v, in);
+            }
+            if (TAIL > 0) {
+                const vi n = vmin_i(lane / (TAIL > 0 ? TAIL : 1), N - 1);
+                const vi jt = lane - (lane / (TAIL > 0 ? TAIL : 1)) * (TAIL > 0 ? TAIL : 1);
+                const vi t = jt + (base + WAVE * K);
+                const vm in = (lane < N * TAIL) && (spl_i(w) == 0) && (t < len);
+                gstore(dst, n * len + t, lds_read(tile, n * G::SP + WAVE * G::LK + jt), in);
+            }
+            return;
+        }
+    }
+    for (int i0 = w * WAVE; i0 < N * G::S; i0 += SCANWG_NW * WAVE) {
+        const vi idx = lane + i0;
+        const vi n = vmin_i(idx / G::S, N - 1);
+        const vi tt = vmin_i(idx - (idx / G::S) * G::S, G::S - 1);
+        const vi tg = tt + base;
+        const vm m = (idx < N * G::S) && (tg < len);
+        gstore(dst, n * len + tg, lds_read(tile, n * G::SP + scan_tile_pos<K, TAIL>(tt)), m);
     }
 }
 
@@ -699,19 +761,8 @@ AUM_DEV void scanwg_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_pe
         AUM_WG_BARRIER();
         // flush this chunk's dB/dC tile: one partial per workgroup, every (g,b,n,t) written exactly once
         AUM_FOR_EACH_WAVE(w, SCANWG_NW) {
-            const vi lane = lane_id();
-            float* oB = ws + L.pB + ((int64_t)g_idx * p.batch + b) * N * p.len;
-            float* oC = ws + L.pC + ((int64_t)g_idx * p.batch + b) * N * p.len;
-            for (int i0 = w * WAVE; i0 < N * S; i0 += SCANWG_NW * WAVE) {
-                const vi idx = lane + i0;
-                const vi n = vmin_i(idx / S, N - 1);
-                const vi tt = vmin_i(idx - (idx / S) * S, S - 1);
-                const vi tg = tt + base;
-                const vm m = (idx < N * S) && (tg < p.len);
-                const vi at = n * GE::SP + scan_tile_pos<K, TAIL>(tt);
-                gstore(oB, n * p.len + tg, lds_read(dBt, at), m);
-                gstore(oC, n * p.len + tg, lds_read(dCt, at), m);
-            }
+            scanwg_store_tile<K, TAIL>(dBt, ws + L.pB + ((int64_t)g_idx * p.batch + b) * N * p.len, N, base, p.len, w);
+            scanwg_store_tile<K, TAIL>(dCt, ws + L.pC + ((int64_t)g_idx * p.batch + b) * N * p.len, N, base, p.len, w);
         }
         AUM_WG_BARRIER();
     }

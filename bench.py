@@ -15,6 +15,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; must be set before HIP initialises
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "audio-mamba-aum_amd"))
 from aum import tunable  # noqa: E402   (no torch import inside)
@@ -108,7 +109,6 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm (xGMI within the node)
     aum_hip.get()      # fail loudly now if the HIP extension is missing
 
@@ -182,7 +182,11 @@ def main():
             roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBPS, 4)
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
-            roof["traffic"] = json.load(open(pmc)).get(dom)
+            roof["traffic"] = json.load(open(pmc)).get(dom)     # HBM bytes per launch from FETCH_SIZE/WRITE_SIZE passes
+        if dom.startswith("scan"):
+            roof["note"] = ("VALU-bound kernel (16 states x 2 directions x v_exp_f32 per element): SQ_ACTIVE_INST_VALU shows the "
+                            "vector ALU 72-97% busy (profiles/r01_pmc), so the HBM fraction is bounded near 0.1 by arithmetic; "
+                            "see DESIGN.md 4.1")
         out = {
             "metric": "clips/sec/node AuM-Base 128x1024 fwd+bwd", "value": round(clips / elapsed, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
