@@ -58,3 +58,20 @@ def wav2fbank(wave, tables, target_length=1024, norm_mean=AUDIOSET_MEAN, norm_st
     AudiosetDataset.__getitem__ returns per clip (without SpecAug / mixup)."""
     wave = wave - wave.mean(dim=1, keepdim=True)                # dataloader.py:101
     return aum_hip.fbank_fwd(wave.contiguous(), tables.tables, target_length, norm_mean, norm_std)
+
+
+def pad_fill(norm_mean=AUDIOSET_MEAN, norm_std=AUDIOSET_STD):
+    """what a zero-padded (or SpecAug-masked) fbank frame becomes after (x - mean) / (2 std) (dataloader.py:141-144, 220)"""
+    return (0.0 - norm_mean) / (2.0 * norm_std)
+
+
+def wav2fbank_ragged(wave, n_valid, tables, target_length=1024, norm_mean=AUDIOSET_MEAN, norm_std=AUDIOSET_STD):
+    """Clips of different lengths in one launch: wave (batch, max_samples) zero-padded, n_valid (batch,) samples.
+    Kaldi's snip_edges framing only emits frames that lie inside the clip, so frames past 1 + (n - win)//shift are
+    the reference's ZeroPad2d rows (dataloader.py:139-145)."""
+    out = wav2fbank(wave, tables, target_length, norm_mean, norm_std)
+    win, shift = tables.tables["win"], tables.tables["shift"]
+    n_valid = torch.as_tensor(n_valid, device=out.device)
+    frames = torch.where(n_valid >= win, 1 + (n_valid - win) // shift, torch.zeros_like(n_valid))
+    pad = torch.arange(target_length, device=out.device)[None, :] >= frames[:, None]
+    return out.masked_fill(pad[:, :, None], pad_fill(norm_mean, norm_std))

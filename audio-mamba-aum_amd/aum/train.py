@@ -1,0 +1,431 @@
+"""Training / evaluation launcher with the reference's command line (/root/reference/src/run.py = "RUN":36-132 and
+/root/reference/src/traintest.py = "TT"), re-hosted for one-process-per-GPU `torch.distributed` over RCCL:
+
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m aum.train \
+        --model aum --model_type base --aum_type Fo-Bi --dataset audioset --data-train train.json \
+        --data-val eval.json --label-csv class_labels_indices.csv --n_class 527 --lr 1e-4 -b 64 --n-epochs 5 \
+        --freqm 48 --timem 192 --mixup 0.5 --loss BCE --metrics mAP --warmup True --exp-dir exp/base
+
+What is the same: the flags and their defaults, Adam with the batch-scaled betas/eps (TT:25-33), the 1000-step
+linear warm-up in 50-step stairs (TT:119-123), MultiStepLR (TT:72), BCE/CE, nan_to_num and skip-on-inf (TT:153-164),
+per-epoch validation with mAP/AUC/d' (TT:188-218), and every file an experiment directory holds afterwards
+(args.pkl, result.csv, progress.pkl, stats_*.pickle, predictions/*.csv, models/{best,latest}_*.pth).
+
+What is MI355X-first: DataLoader workers only decode waveforms; mel + SpecAug + normalisation + noise run on the
+GPU; bf16 autocast (no GradScaler needed) around the HIP mixer; DDP with a static graph and gradient-as-bucket-view.
+Out of scope here (rejected with an error): --model ast, epic_sounds, flexible patch training, ImageNet init.
+"""
+import argparse
+import ast as _ast
+import datetime
+import math
+import os
+import pickle
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+_lit = _ast.literal_eval
+EXP_SEED = 3949                                                           # RUN:28-30
+
+
+def build_parser():
+    p = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    a = p.add_argument
+    a("--exp-dir", type=str, default="")
+    a("--exp-name", type=str, default="")
+    a("-w", "--num-workers", default=4, type=int)
+    a("--n-print-steps", type=int, default=100)
+    a("--run_type", type=str, default="train", choices=["train", "eval"])
+    a("--data-train", type=str, default="")
+    a("--data-val", type=str, default="")
+    a("--data-eval", type=str, default="")
+    a("--label-csv", type=str, default="")
+    a("--n_class", type=int, default=527)
+    a("--dataset", type=str, default="audioset")
+    a("--freqm", type=int, default=0)
+    a("--timem", type=int, default=0)
+    a("--mixup", type=float, default=0)
+    a("--dataset_mean", type=float, default=-4.2677393)
+    a("--dataset_std", type=float, default=4.5689974)
+    a("--audio_length", type=int, default=1024)
+    a("--noise", type=_lit, default="False")
+    a("--melbins", type=int, default=128)
+    a("--fshift", type=int, default=10)
+    a("--sample_rate", type=int, default=16000, help="(new) all clips must have this rate; the mel tables are built for it")
+    a("--model", type=str, default="aum")
+    a("--model_type", type=str, default="base")
+    a("--fpatch_size", type=int, default=16)
+    a("--tpatch_size", type=int, default=16)
+    a("--fstride", type=int, default=16)
+    a("--tstride", type=int, default=16)
+    a("--imagenet_pretrain", type=_lit, default="False")
+    a("--aum_pretrain", type=_lit, default="False")
+    a("--aum_pretrain_path", type=str, default=None)
+    a("--aum_pretrain_fstride", type=int, default=16)
+    a("--aum_pretrain_tstride", type=int, default=16)
+    a("--if_continue_inf", type=_lit, default="True")
+    a("--if_nan2num", type=_lit, default="True")
+    a("--aum_drop_path", type=float, default=0)
+    a("--if_cls_token", type=_lit, default="True")
+    a("--use_middle_cls_token", type=_lit, default="True")
+    a("--aum_type", type=str, default="Fo-Bi")
+    a("--lr", "--learning-rate", default=0.001, type=float)
+    a("--optim", type=str, default="adam", choices=["sgd", "adam"])
+    a("-b", "--batch-size", default=12, type=int)
+    a("--n-epochs", type=int, default=1)
+    a("--save_model", type=_lit, default="True")
+    a("--bal", type=str, default=None)
+    a("--metrics", type=str, default="mAP", choices=["acc", "mAP"])
+    a("--loss", type=str, default="BCE", choices=["BCE", "CE"])
+    a("--warmup", type=_lit, default="False")
+    a("--lrscheduler_start", type=int, default=2)
+    a("--lrscheduler_step", type=int, default=1)
+    a("--lrscheduler_decay", type=float, default=0.5)
+    a("--bs_scale_factor", type=int, default=1)
+    a("--weight_decay", type=float, default=5e-7)
+    a("--optim_path", type=str, default=None)
+    a("--flexible_training", type=_lit, default="False")
+    a("--mixed_precision", type=str, default="bf16", choices=["no", "bf16", "fp16"],
+      help="(new) what `accelerate launch --mixed_precision` selects for the reference")
+    a("--depth", type=int, default=24, help="(new) number of blocks; every published AuM size uses 24 (RUN:227-237)")
+    a("--max-steps", type=int, default=0, help="(new) stop each epoch after this many steps (smoke runs)")
+    return p
+
+
+def check_scope(args):
+    if args.model != "aum":
+        raise NotImplementedError("--model ast (the transformer baseline) is outside the accelerated path")
+    if args.dataset == "epic_sounds" or args.flexible_training or args.imagenet_pretrain or args.aum_drop_path:
+        raise NotImplementedError("epic_sounds / flexible training / ImageNet init / drop-path are out of scope")
+    if not args.if_cls_token:
+        raise NotImplementedError("--if_cls_token False is off the default path")
+
+
+class Dist:
+    """the few things the reference uses `accelerator` for"""
+
+    def __init__(self):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.cuda = torch.cuda.is_available()
+        self.device = torch.device("cuda", self.local_rank) if self.cuda else torch.device("cpu")
+        if self.cuda:
+            torch.cuda.set_device(self.device)
+        if self.world > 1 and not dist.is_initialized():
+            dist.init_process_group("nccl" if self.cuda else "gloo")
+        self.main = self.rank == 0
+
+    def print(self, *a):
+        if self.main:
+            print(*a, flush=True)
+
+    def gather(self, t):
+        if self.world == 1:
+            return t if t.dim() else t[None]
+        t = t.contiguous() if t.dim() else t[None].contiguous()
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return torch.cat(out)
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+
+def build_model(args):
+    from .model import AudioMamba, AUM_SIZES
+    size = next((s for s in AUM_SIZES if s in args.model_type), None)
+    if size is None:
+        raise ValueError("unknown model type, model type should be one of [base, small, tiny] for aum")
+    bimamba = {"Fo-Fo": "none", "Fo-Bi": "v1", "Bi-Bi": "v2"}.get(args.aum_type)
+    if bimamba is None:
+        raise ValueError("unknown aum type, aum type should be one of [Fo-Fo, Fo-Bi, Bi-Bi] for aum")
+    model = AudioMamba(spectrogram_size=(args.melbins, args.audio_length), patch_size=(args.fpatch_size, args.tpatch_size),
+                       strides=(args.fstride, args.tstride), depth=args.depth, embed_dim=AUM_SIZES[size], num_classes=args.n_class,
+                       bimamba_type=bimamba, use_middle_cls_token=args.use_middle_cls_token)
+    if args.aum_pretrain:
+        from .checkpoint import load_aum_checkpoint
+        print(load_aum_checkpoint(model, args.aum_pretrain_path, args.aum_pretrain_fstride, args.aum_pretrain_tstride))
+    return model
+
+
+class Frontend:
+    """waveform batch on the device -> augmented, normalised (B, T, F) log-mel"""
+
+    def __init__(self, args, device, train):
+        from .frontend import FbankTables, pad_fill
+        self.args, self.train = args, train
+        self.tables = FbankTables(device, sample_rate=args.sample_rate, num_mel_bins=args.melbins,
+                                  frame_shift_ms=float(args.fshift))
+        self.fill = pad_fill(args.dataset_mean, args.dataset_std)
+
+    def __call__(self, wave, n_valid):
+        from .frontend import wav2fbank_ragged
+        from .augment import spec_augment, noise_roll
+        a = self.args
+        x = wav2fbank_ragged(wave, n_valid, self.tables, a.audio_length, a.dataset_mean, a.dataset_std)
+        if self.train:
+            x = spec_augment(x, a.freqm, a.timem, self.fill)
+            if a.noise:
+                x = noise_roll(x)
+        return x
+
+
+def make_loader(args, path, train, D):
+    from .data import WaveformDataset
+    win = int(args.sample_rate * 0.025)
+    shift = int(args.sample_rate * args.fshift * 0.001)
+    max_samples = win + (args.audio_length - 1) * shift              # exactly audio_length frames
+    ds = WaveformDataset(path, args.label_csv, max_samples, mixup=args.mixup if train else 0.0, sample_rate=args.sample_rate)
+    bs = args.batch_size if train else args.batch_size * 2                 # RUN:190
+    sampler = None
+    if train and args.bal == "bal":                                        # RUN:173-181
+        w = np.loadtxt(path[:-5] + "_weight.csv", delimiter=",")
+        g = torch.Generator().manual_seed(EXP_SEED + D.rank)
+        sampler = torch.utils.data.WeightedRandomSampler(w, len(w) // D.world, replacement=True, generator=g)
+    elif D.world > 1:
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, D.world, D.rank, shuffle=train, drop_last=False)
+    return torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=(train and sampler is None), sampler=sampler,
+                                       num_workers=args.num_workers, pin_memory=D.cuda, drop_last=False)
+
+
+def _autocast(args, D):
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.mixed_precision)
+    return torch.autocast("cuda", dtype=dt, enabled=(dt is not None and D.cuda))
+
+
+def _loss_fn(args):
+    if args.loss == "BCE":
+        return nn.BCEWithLogitsLoss()
+    if args.loss == "CE":
+        return nn.CrossEntropyLoss()
+    raise ValueError("loss function not defined")
+
+
+def _loss(loss_fn, out, labels):
+    if isinstance(loss_fn, nn.CrossEntropyLoss):
+        return loss_fn(out, torch.argmax(labels.long(), dim=1))
+    return loss_fn(out, labels)
+
+
+def validate(model, loader, frontend, args, D, epoch, save_pred=True):
+    """TT:238-307.  NOTE the reference feeds SIGMOID outputs to the loss here (TT:266-274); kept, so valid_loss is
+    comparable with its logs."""
+    from .stats import calculate_stats
+    model.eval()
+    loss_fn = _loss_fn(args)
+    preds, tgts, losses = [], [], []
+    with torch.no_grad():
+        for wave, n_valid, labels, _ in loader:
+            wave, labels = wave.to(D.device, non_blocking=True), labels.to(D.device, non_blocking=True)
+            with _autocast(args, D):
+                out = model(frontend(wave, n_valid.to(D.device)))
+            out = out.float()
+            if args.if_nan2num:
+                out = torch.nan_to_num(out)
+            out = torch.sigmoid(out)
+            loss = _loss(loss_fn, out, labels)
+            # ragged last batches: pad to the loader's batch size so all_gather shapes agree, mark real rows
+            bs = loader.batch_size
+            keep = torch.zeros(bs, dtype=torch.bool, device=D.device)
+            keep[:out.shape[0]] = True
+            pad = lambda t: torch.cat([t, t.new_zeros((bs - t.shape[0],) + t.shape[1:])])
+            k = D.gather(keep)
+            preds.append(D.gather(pad(out))[k].cpu())
+            tgts.append(D.gather(pad(labels))[k].cpu())
+            losses.append(D.gather(loss.detach()).cpu())
+    D.barrier()
+    if not D.main:
+        return None, None
+    output, target = torch.cat(preds).numpy(), torch.cat(tgts).numpy()
+    stats = calculate_stats(output, target)
+    if save_pred:
+        pdir = os.path.join(args.exp_dir, "predictions")
+        if not os.path.exists(pdir):
+            os.mkdir(pdir)
+            np.savetxt(os.path.join(pdir, "target.csv"), target, delimiter=",")
+        np.savetxt(os.path.join(pdir, f"predictions_{epoch}.csv"), output, delimiter=",")
+    return stats, float(torch.cat(losses).mean())
+
+
+def train(model, train_loader, val_loader, args, D):
+    """TT:15-236"""
+    from .stats import summarize
+    model = model.to(D.device)
+    trainables = [p for p in model.parameters() if p.requires_grad]
+    D.print("Total parameter number is : {:.3f} million".format(sum(p.numel() for p in model.parameters()) / 1e6))
+    D.print("Total trainable parameter number is : {:.3f} million".format(sum(p.numel() for p in trainables) / 1e6))
+    k = args.bs_scale_factor
+    if args.optim == "adam":
+        optimizer = torch.optim.Adam(trainables, args.lr, weight_decay=args.weight_decay,
+                                     betas=(1 - (1 - 0.95) * k, 1 - (1 - 0.999) * k), eps=1e-8 / (k ** 0.5))
+    else:
+        optimizer = torch.optim.SGD(trainables, args.lr, momentum=0.9, weight_decay=args.weight_decay)
+    if args.optim_path:
+        optimizer.load_state_dict(torch.load(args.optim_path, map_location="cpu"))
+    net = model
+    if D.world > 1:
+        net = nn.parallel.DistributedDataParallel(model, device_ids=[D.local_rank] if D.cuda else None,
+                                                  gradient_as_bucket_view=True, static_graph=True, bucket_cap_mb=100)
+    scaler = torch.amp.GradScaler("cuda", enabled=(args.mixed_precision == "fp16" and D.cuda))
+    scheduler = torch.optim.lr_scheduler.MultiStepLR(
+        optimizer, list(range(args.lrscheduler_start, 1000, args.lrscheduler_step)), gamma=args.lrscheduler_decay)
+    loss_fn = _loss_fn(args)
+    fe_train, fe_val = Frontend(args, D.device, True), Frontend(args, D.device, False)
+    D.print("now training with {:s}, main metrics: {:s}, loss function: {:s}, learning rate scheduler: {:s}".format(
+        str(args.dataset), str(args.metrics), str(loss_fn), str(scheduler)))
+
+    progress, result = [], np.zeros([args.n_epochs, 8])
+    best_epoch, best_mAP, best_acc = 0, -np.inf, -np.inf
+    loss_sum, loss_cnt = 0.0, 0
+    global_step, epoch = 0, 1
+    warm_steps, warm_every = 1000 // k, max(1, 50 // k)
+    while epoch < args.n_epochs + 1:
+        net.train()
+        D.print("---------------")
+        D.print(datetime.datetime.now())
+        D.print("current #epochs=%s, #steps=%s" % (epoch, global_step))
+        if hasattr(train_loader.sampler, "set_epoch"):
+            train_loader.sampler.set_epoch(epoch)
+        t0 = time.time()
+        for i, (wave, n_valid, labels, _) in enumerate(train_loader):
+            if args.max_steps and i >= args.max_steps:
+                break
+            wave, labels = wave.to(D.device, non_blocking=True), labels.to(D.device, non_blocking=True)
+            if args.warmup and global_step <= warm_steps and global_step % warm_every == 0:
+                warm_lr = (global_step / warm_steps) * args.lr
+                for g in optimizer.param_groups:
+                    g["lr"] = warm_lr
+                D.print("warm-up learning rate is {:f}".format(warm_lr))
+            with torch.no_grad():
+                x = fe_train(wave, n_valid.to(D.device))
+            with _autocast(args, D):
+                out = net(x)
+            loss = _loss(loss_fn, out.float(), labels)
+            if args.if_nan2num:
+                loss = torch.nan_to_num(loss)
+            loss_value = loss.item()
+            if not math.isfinite(loss_value):
+                if args.if_continue_inf:
+                    print("Loss is {}, continuing training".format(loss_value))
+                    optimizer.zero_grad()
+                    continue
+                print("Loss is {}, stopping training".format(loss_value))
+                sys.exit(1)
+            optimizer.zero_grad(set_to_none=True)
+            scaler.scale(loss).backward()
+            scaler.step(optimizer)
+            scaler.update()
+            stat = D.gather(torch.tensor([loss_value * wave.shape[0], wave.shape[0]], device=D.device)[None]).sum(0)
+            loss_sum += float(stat[0])
+            loss_cnt += int(stat[1])
+            global_step += 1
+            if global_step % args.n_print_steps == 0:
+                D.print("Epoch {} step {} T_Loss {:.5f} ({:.1f} clips/s)".format(
+                    epoch, global_step, loss_sum / max(1, loss_cnt), loss_cnt / (time.time() - t0)))
+
+        D.print("start validation")
+        stats, valid_loss = validate(net, val_loader, fe_val, args, D, epoch)
+        if D.main:
+            s = summarize(stats, args.metrics)
+            train_loss = loss_sum / max(1, loss_cnt)
+            lr_now = optimizer.param_groups[0]["lr"]
+            D.print(("mAP: {:.6f}" if args.metrics == "mAP" else "acc: {:.6f}").format(s["main"]))
+            for name, key in (("AUC", "mAUC"), ("Avg Precision", "precision"), ("Avg Recall", "recall"), ("d_prime", "d_prime")):
+                D.print("{}: {:.6f}".format(name, s[key]))
+            D.print("train_loss: {:.6f}".format(train_loss))
+            D.print("valid_loss: {:.6f}".format(valid_loss))
+            result[epoch - 1, :] = [s["main"], s["mAUC"], s["precision"], s["recall"], s["d_prime"], train_loss, valid_loss, lr_now]
+            np.savetxt(args.exp_dir + "/result.csv", result, delimiter=",")
+            if s["mAP"] > best_mAP:
+                best_mAP = s["mAP"]
+                if args.metrics == "mAP":
+                    best_epoch = epoch
+            if s["acc"] > best_acc:
+                best_acc = s["acc"]
+                if args.metrics == "acc":
+                    best_epoch = epoch
+            sd = net.state_dict()                                     # with the `module.` prefix under DDP, as the reference saves
+            if best_epoch == epoch:
+                torch.save(sd, "%s/models/best_audio_model.pth" % args.exp_dir)
+                torch.save(optimizer.state_dict(), "%s/models/best_optim_state.pth" % args.exp_dir)
+            if args.save_model:
+                torch.save(sd, "%s/models/latest_audio_model.%d.pth" % (args.exp_dir, epoch))
+                torch.save(optimizer.state_dict(), "%s/models/latest_optim_state.%d.pth" % (args.exp_dir, epoch))
+            D.print("Epoch-{0} lr: {1}".format(epoch, lr_now))
+            with open(args.exp_dir + "/stats_" + str(epoch) + ".pickle", "wb") as h:
+                pickle.dump(stats, h, protocol=pickle.HIGHEST_PROTOCOL)
+            progress.append([epoch, global_step, best_epoch, best_mAP, best_acc])
+            with open("%s/progress.pkl" % args.exp_dir, "wb") as f:
+                pickle.dump(progress, f)
+        loss_sum, loss_cnt = 0.0, 0
+        D.barrier()
+        scheduler.step()
+        epoch += 1
+    return model
+
+
+def evaluate(model, val_loader, args, D, tag):
+    """RUN:283-324"""
+    from .stats import summarize
+    stats, loss = validate(model.to(D.device), val_loader, Frontend(args, D.device, False), args, D, tag)
+    if not D.main:
+        return None
+    s = summarize(stats, args.metrics)
+    D.print(("mAP: {:.6f}" if args.metrics == "mAP" else "acc: {:.6f}").format(s["main"]))
+    D.print("AUC: {:.6f}".format(s["mAUC"]))
+    D.print("d_prime: {:.6f}".format(s["d_prime"]))
+    D.print("valid_loss: {:.6f}".format(loss))
+    res = [s["main"], s["mAUC"], s["precision"], s["recall"], s["d_prime"], loss]
+    np.savetxt(args.exp_dir + f"/result_{tag}.csv", res, delimiter=",")
+    with open(args.exp_dir + f"/stats_{tag}.pickle", "wb") as h:
+        pickle.dump(stats, h, protocol=pickle.HIGHEST_PROTOCOL)
+    return s
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    check_scope(args)
+    random.seed(EXP_SEED), np.random.seed(EXP_SEED), torch.manual_seed(EXP_SEED)
+    D = Dist()
+    if D.cuda:
+        from . import tunable
+        tunable.enable(D.local_rank)
+    print("I am process %s, running on %s: starting (%s)" % (os.getpid(), os.uname()[1], time.asctime()))
+    model = build_model(args)
+    val_loader = make_loader(args, args.data_val, False, D)
+    if args.run_type == "train":
+        train_loader = make_loader(args, args.data_train, True, D)
+        D.print("\nCreating experiment directory: %s" % args.exp_dir)
+        if D.main:
+            os.makedirs("%s/models" % args.exp_dir, exist_ok=True)
+            with open("%s/args.pkl" % args.exp_dir, "wb") as f:
+                pickle.dump(args, f)
+        D.barrier()
+        D.print("Now starting training for {:d} epochs".format(args.n_epochs))
+        train(model, train_loader, val_loader, args, D)
+        if args.dataset == "speechcommands" and args.data_eval:           # RUN:326-375
+            D.barrier()
+            sd = torch.load(args.exp_dir + "/models/best_audio_model.pth", map_location="cpu")
+            model.load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
+            v = evaluate(model, val_loader, args, D, "valid_set")
+            e = evaluate(model, make_loader(args, args.data_eval, False, D), args, D, "eval_set")
+            if D.main:
+                np.savetxt(args.exp_dir + "/eval_result.csv", [v["acc"], v["mAUC"], e["acc"], e["mAUC"]])
+    else:
+        D.print(f"Now starting evaluation on {args.dataset} dataset!")
+        os.makedirs(args.exp_dir, exist_ok=True)
+        evaluate(model, val_loader, args, D, "eval")
+    if D.world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
