@@ -1,5 +1,7 @@
 """GPU: the host package on the real libaum_hip.so -- whole-model parity with the reference's AudioMamba (golden
 fixtures), autocast rules, and size-independent checks at the AuM-Base block size."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -105,3 +107,27 @@ def test_base_block_full_size_gradient_consistency():
     fd = ((fp - fm) / (2 * eps)).item()
     an = (x.grad.double() * v.double()).sum().item()
     assert abs(fd - an) <= 2e-2 * max(abs(an), 1e-3), (fd, an)
+
+
+def test_launcher_end_to_end_on_gpu(tmp_path):
+    """aum.train on the real library: waveform workers -> GPU mel/SpecAug -> bf16 autocast model -> Adam -> validation."""
+    import json
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = str(tmp_path / "toy")
+    subprocess.run([sys.executable, os.path.join(root, "tools", "make_toy_audioset.py"), data, "--clips", "24",
+                    "--val-clips", "8", "--seconds", "2.0", "--classes", "6"], check=True)
+    exp = str(tmp_path / "exp")
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "audio-mamba-aum_amd") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "aum.train", "--model_type", "small", "--depth", "4", "--n_class", "6",
+           "--label-csv", data + "/class_labels_indices.csv", "--data-train", data + "/train.json",
+           "--data-val", data + "/val.json", "--audio_length", "256", "--num-workers", "2", "-b", "8", "--lr", "1e-3",
+           "--n-epochs", "2", "--freqm", "24", "--timem", "48", "--mixup", "0.5", "--exp-dir", exp]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = np.loadtxt(exp + "/result.csv", delimiter=",")
+    assert res.shape == (2, 8) and np.isfinite(res).all()
+    assert res[1, 5] < res[0, 5], res[:, 5]                       # training loss goes down
+    assert json.load(open(data + "/val.json"))["data"] and os.path.exists(exp + "/models/best_audio_model.pth")
