@@ -67,7 +67,18 @@ class FbankArgs(C.Structure):
                 + [(n, C.c_float) for n in ("preemph", "norm_mean", "norm_inv2std", "log_floor")])
 
 
-EXPORTS = ["aum_fbank_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
+class ProjArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("act", "w_x", "w_dt", "x_dbl", "out_act", "dB", "dC")]
+                + [(n, _i64) for n in ("dB_bs", "dB_ns", "dC_bs", "dC_ns", "ntok")]
+                + [(n, _i32) for n in ("dim", "dt_rank", "dstate", "len", "dtype", "w_ld")])
+
+
+class ProjWArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("x", "y", "out")] + [("ntok", _i64)]
+                + [(n, _i32) for n in ("dim", "nrows", "nsplit", "transpose_out", "dtype")])
+
+
+EXPORTS = ["aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
            "aum_selective_scan_workspace_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy"]
 
@@ -90,6 +101,9 @@ class Lib:
                   "aum_rmsnorm_fwd", "aum_rmsnorm_bwd"):
             getattr(self.c, n).argtypes = [_vp, _vp]
         self.c.aum_fbank_fwd.argtypes = [_vp, _vp]
+        for n in ("aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight"):
+            getattr(self.c, n).argtypes = [_vp, _vp]
+        self.c.aum_proj_bwd_weight_splits.argtypes = [_i32, _i64]
         self.c.aum_selftest_wave_scan.argtypes = [_vp, _vp, C.c_int, _vp]
         self.c.aum_hbm_copy.argtypes = [_vp, _vp, _i64, _vp]
         assert self.c.aum_abi_version() == 1
@@ -418,6 +432,86 @@ def fbank_fwd(wave, tables, target_length, norm_mean, norm_std, preemph=0.97, li
     a.log_floor = 1.1920928955078125e-07
     _launch(lib.c.aum_fbank_fwd, a, wave, lib, "fbank_fwd", (batch, target_length, num_mel))
     return out
+
+
+def proj_supported(dim, dt_rank, dstate, ntok, dtype):
+    """the limits of include/aum_hip.h for the MFMA projection kernels; outside them callers use library GEMMs"""
+    return (dtype in (torch.bfloat16, torch.float16) and dim % 64 == 0 and dt_rank <= 64 and dt_rank + 2 * dstate <= 80
+            and ntok * 80 < 2 ** 31)
+
+
+def _proj_common(a, ntok, dim, dt_rank, dstate, dtype):
+    a.ntok, a.dim, a.dt_rank, a.dstate, a.dtype = ntok, dim, dt_rank, dstate, _DT[dtype]
+
+
+def _pad_cols8(w):
+    """[rows][cols] -> [rows][ceil8(cols)] zero-padded (the kernels read the short k dimension in groups of 8)"""
+    pad = (-w.shape[1]) % 8
+    return w.contiguous() if pad == 0 else torch.nn.functional.pad(w, (0, pad)).contiguous()
+
+
+def proj_fwd(conv_out2d, w_x, w_dt, dstate, lib=None):
+    """conv_out2d [dim][ntok], w_x [dt_rank+2*dstate][dim], w_dt [dim][dt_rank] (all one 16-bit dtype, contiguous)
+    -> x_dbl [dt_rank+2*dstate][ntok] (rows dt | B | C) and delta [dim][ntok] = w_dt @ dt   (SSI:467-468)."""
+    lib = lib or get()
+    for t in (conv_out2d, w_x, w_dt):
+        lib.check_tensor(t)
+        assert t.is_contiguous() and t.dtype == conv_out2d.dtype
+    dim, ntok = conv_out2d.shape
+    rt, dt_rank = w_x.shape[0], w_dt.shape[1]
+    assert w_x.shape == (dt_rank + 2 * dstate, dim) and w_dt.shape == (dim, dt_rank)
+    w_dt = _pad_cols8(w_dt)
+    x_dbl = torch.empty((rt, ntok), dtype=conv_out2d.dtype, device=conv_out2d.device)
+    delta = torch.empty_like(conv_out2d)
+    a = ProjArgs()
+    a.act, a.w_x, a.w_dt, a.x_dbl, a.out_act = _ptr(conv_out2d), _ptr(w_x), _ptr(w_dt), _ptr(x_dbl), _ptr(delta)
+    _proj_common(a, ntok, dim, dt_rank, dstate, conv_out2d.dtype)
+    a.len, a.w_ld = ntok, w_dt.shape[1]
+    _launch(lib.c.aum_proj_fwd, a, conv_out2d, lib, "proj_fwd", (dim, ntok, rt))
+    return x_dbl, delta
+
+
+def proj_bwd_data(ddelta2d, w_dt_t, w_x_t, dB, dC, dconv2d, length, lib=None):
+    """ddelta2d [dim][ntok], w_dt_t = W_dt^T [dt_rank][dim], w_x_t = W_x^T [dim][rt], dB/dC fp32 (batch, dstate, len)
+    -> dx_dbl [rt][ntok]; dconv2d [dim][ntok] += W_x^T dx_dbl in place   (SSI:570-574, 587, 590)."""
+    lib = lib or get()
+    for t in (ddelta2d, w_dt_t, w_x_t, dconv2d):
+        lib.check_tensor(t)
+        assert t.is_contiguous() and t.dtype == ddelta2d.dtype
+    lib.check_tensor(dB), lib.check_tensor(dC)
+    assert dB.dtype == torch.float32 and dC.dtype == torch.float32 and dB.stride(2) == 1 and dC.stride(2) == 1
+    dim, ntok = ddelta2d.shape
+    dt_rank, rt = w_dt_t.shape[0], w_x_t.shape[1]
+    dstate = dB.shape[1]
+    assert rt == dt_rank + 2 * dstate and dB.shape[0] * length == ntok and dB.shape[2] == length
+    w_x_t = _pad_cols8(w_x_t)
+    dx_dbl = torch.empty((rt, ntok), dtype=ddelta2d.dtype, device=ddelta2d.device)
+    a = ProjArgs()
+    a.act, a.w_x, a.w_dt, a.x_dbl, a.out_act = _ptr(ddelta2d), _ptr(w_x_t), _ptr(w_dt_t), _ptr(dx_dbl), _ptr(dconv2d)
+    a.dB, a.dC = _ptr(dB), _ptr(dC)
+    a.dB_bs, a.dB_ns, a.dC_bs, a.dC_ns = dB.stride(0), dB.stride(1), dC.stride(0), dC.stride(1)
+    _proj_common(a, ntok, dim, dt_rank, dstate, ddelta2d.dtype)
+    a.len, a.w_ld = length, w_x_t.shape[1]
+    _launch(lib.c.aum_proj_bwd_data, a, ddelta2d, lib, "proj_bwd_data", (dim, ntok, rt))
+    return dx_dbl
+
+
+def proj_bwd_weight(x2d, y2d, transpose_out, lib=None):
+    """sum_t x[e][t] * y[r][t] -> [dim][nrows] (or [nrows][dim] with transpose_out) fp32   (SSI:586, 589)."""
+    lib = lib or get()
+    lib.check_tensor(x2d), lib.check_tensor(y2d)
+    assert x2d.is_contiguous() and y2d.stride(1) == 1 and y2d.stride(0) == x2d.shape[1] and x2d.dtype == y2d.dtype
+    dim, ntok = x2d.shape
+    nrows = y2d.shape[0]
+    nsplit = int(lib.c.aum_proj_bwd_weight_splits(dim, ntok))
+    if nsplit <= 0:
+        raise RuntimeError("aum_proj_bwd_weight: unsupported shape")
+    part = torch.empty((nsplit, nrows, dim) if transpose_out else (nsplit, dim, nrows), dtype=torch.float32, device=x2d.device)
+    a = ProjWArgs()
+    a.x, a.y, a.out, a.ntok = _ptr(x2d), _ptr(y2d), _ptr(part), ntok
+    a.dim, a.nrows, a.nsplit, a.transpose_out, a.dtype = dim, nrows, nsplit, int(transpose_out), _DT[x2d.dtype]
+    _launch(lib.c.aum_proj_bwd_weight, a, x2d, lib, "proj_bwd_weight", (dim, ntok, nrows))
+    return part.sum(0) if nsplit > 1 else part[0]
 
 
 def selftest_wave_scan(P, S, rev=False, lib=None):

@@ -81,6 +81,10 @@ AUM_DEV int wave_in_wg() { return __builtin_amdgcn_readfirstlane((int)(threadIdx
 // build runs the waves of a phase one after another, where it is a no-op: sequential execution is one legal schedule,
 // so arithmetic is checked there while race-freedom under concurrency is argued at the call site and checked on the GPU.
 #define AUM_WG_BARRIER_IN_PHASE() __syncthreads()
+// Per-wave state that must survive from one phase to the next (registers on the device): declare `T name[AUM_PER_WAVE(NW)]...`
+// and index it with AUM_W(w).  One slot on the device; the lane-array build keeps a slot per wave it steps through.
+#define AUM_PER_WAVE(NW) 1
+#define AUM_W(w) 0
 AUM_DEV vf splat(float x) { return x; }
 AUM_DEV vi spl_i(int x) { return x; }
 AUM_DEV vf vfma(vf a, vf b, vf c) { return __builtin_fmaf(a, b, c); }
@@ -177,6 +181,13 @@ AUM_DEV void lds_atomic_add(float* lds, vi idx, vf v) {   // ds_add_f32 (no retu
     __hip_atomic_fetch_add(lds + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 AUM_DEV void wave_sync() { __syncthreads(); }  // single-wave workgroup: orders LDS traffic, ~free
+// Orders one wave's own LDS traffic inside a multi-wave workgroup (lane A's ds_write seen by lane B's later ds_read of
+// the same wave).  The LDS executes a wave's instructions in order, so only the compiler has to be held: a wavefront-scope
+// fence + scheduling barrier, no s_barrier.
+AUM_DEV void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 template <int CTRL> AUM_DEV vf dpp_mov(vf x, vf old) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
@@ -293,7 +304,10 @@ inline void lds_atomic_add(float* lds, const vi& idx, const vf& v) { AUM_LANES l
 #define AUM_FOR_EACH_WAVE(w, NW) for (int w = 0; w < (NW); ++w)
 #define AUM_WG_BARRIER() do { } while (0)
 #define AUM_WG_BARRIER_IN_PHASE() do { } while (0)
+#define AUM_PER_WAVE(NW) (NW)
+#define AUM_W(w) (w)
 inline void wave_sync() {}
+inline void wave_lds_fence() {}
 
 template <int N> inline vf dpp_row_shr(const vf& x, const vf& old) {
     vf r; AUM_LANES r.v[l] = ((l & 15) >= N) ? x.v[l - N] : old.v[l]; return r;

@@ -150,17 +150,28 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     conv_w = conv1d_weight.reshape(E, -1)
     conv_out = aum_hip.conv1d_fwd(x, conv_w, conv1d_bias, True, reverse, dmajor=True)        # SSI:463
     conv2d = _dm2d(conv_out)                                                                 # [E, BL]
-    x_dbl = torch.matmul(conv2d.t(), x_proj_weight.t().to(conv2d.dtype))                     # SSI:467  (BL, R+2N)
-    delta = torch.matmul(delta_proj_weight.to(x_dbl.dtype), x_dbl[:, :R].t())                # SSI:468  [E, BL]
-    delta = delta.reshape(E, Bsz, L).permute(1, 0, 2)
-    Bm = x_dbl[:, R:R + N]
-    Cm = x_dbl[:, R + N:R + 2 * N]
-    if B_proj_bias is not None:
-        Bm = Bm + B_proj_bias.to(Bm.dtype)
-    if C_proj_bias is not None:
-        Cm = Cm + C_proj_bias.to(Cm.dtype)
-    Bm = Bm.reshape(Bsz, L, N).transpose(1, 2).contiguous()                                  # SSI:479  (B, N, L)
-    Cm = Cm.reshape(Bsz, L, N).transpose(1, 2).contiguous()
+    # the MFMA projection kernels (16-bit activations, no B/C projection bias -- the only form Mamba uses): x_dbl stays
+    # channel-major [R+2N][BL], so B and C are row blocks of it (batch stride L, state stride BL) -- no slicing copies
+    ctx.proj_kernels = (B_proj_bias is None and C_proj_bias is None and x_proj_weight.dtype == conv2d.dtype
+                        and delta_proj_weight.dtype == conv2d.dtype and conv2d.is_contiguous()
+                        and aum_hip.proj_supported(E, R, N, Bsz * L, conv2d.dtype))
+    if ctx.proj_kernels:
+        x_dbl, delta = aum_hip.proj_fwd(conv2d, x_proj_weight.contiguous(), delta_proj_weight.contiguous(), N)   # SSI:467-468
+        delta = delta.view(E, Bsz, L).permute(1, 0, 2)
+        Bm = x_dbl[R:R + N].view(N, Bsz, L).permute(1, 0, 2)                                 # SSI:479  (B, N, L) view
+        Cm = x_dbl[R + N:].view(N, Bsz, L).permute(1, 0, 2)
+    else:
+        x_dbl = torch.matmul(conv2d.t(), x_proj_weight.t().to(conv2d.dtype))                 # SSI:467  (BL, R+2N)
+        delta = torch.matmul(delta_proj_weight.to(x_dbl.dtype), x_dbl[:, :R].t())            # SSI:468  [E, BL]
+        delta = delta.reshape(E, Bsz, L).permute(1, 0, 2)
+        Bm = x_dbl[:, R:R + N]
+        Cm = x_dbl[:, R + N:R + 2 * N]
+        if B_proj_bias is not None:
+            Bm = Bm + B_proj_bias.to(Bm.dtype)
+        if C_proj_bias is not None:
+            Cm = Cm + C_proj_bias.to(Cm.dtype)
+        Bm = Bm.reshape(Bsz, L, N).transpose(1, 2).contiguous()                              # SSI:479  (B, N, L)
+        Cm = Cm.reshape(Bsz, L, N).transpose(1, 2).contiguous()
     bidir_fused = A_b is not None and L <= aum_hip.get().max_single_pass_len
     if A_b is None or bidir_fused:
         out_z, out_pre, _ = aum_hip.scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, reverse,
@@ -227,6 +238,17 @@ def _inner_backward(ctx, dout):
                               ctx.delta_softplus, False, dz_out=dz, dmajor=True)
         del gf
     dconv_out, ddelta = g["du"], g["ddelta"]
+    if ctx.proj_kernels:
+        ddelta2, dconv2 = _dm2d(ddelta), _dm2d(dconv_out)
+        dx_dbl = aum_hip.proj_bwd_data(ddelta2, delta_proj_weight.t().contiguous(), x_proj_weight.t().contiguous(),
+                                       g["dB"], g["dC"], dconv2, L)                          # SSI:570-574, 587, 590
+        ddelta_proj_weight = aum_hip.proj_bwd_weight(ddelta2, x_dbl[:R], False)              # SSI:586
+        dx_proj_weight = aum_hip.proj_bwd_weight(_dm2d(conv_out), dx_dbl, True)              # SSI:589
+        _, dconv_w, dconv_b = aum_hip.conv1d_bwd(x, conv_w, conv1d_bias, dconv_out, True, ctx.reverse, dx_out=dx)  # SSI:594
+        return dict(dxz=dxz, dconv_w=dconv_w.reshape(E, 1, -1), dconv_b=dconv_b, dx_proj_w=dx_proj_weight,
+                    ddt_proj_w=ddelta_proj_weight, dout_proj_w=dout_proj_weight, dout_proj_b=dout_proj_bias,
+                    dA=g["dA"], dA_b=g.get("dA_b"), dD=g["dD"], ddelta_bias=g["ddelta_bias"],
+                    dB_proj_bias=None, dC_proj_bias=None)
     dx_dbl = torch.empty_like(x_dbl)
     dx_dbl3 = dx_dbl.view(Bsz, L, -1)
     dx_dbl3[:, :, R:R + N].copy_(g["dB"].transpose(1, 2))                                    # SSI:570-574

@@ -178,6 +178,49 @@ typedef struct AumFbankArgs {
 } AumFbankArgs;
 int aum_fbank_fwd(const AumFbankArgs* args, void* stream);
 
+/*
+ * The skinny projections around the scan on CHANNEL-MAJOR activations (token t = b*len + l contiguous):
+ *   conv_out / delta / ddelta / dconv : [dim][ntok]     x_dbl / dx_dbl : [dt_rank + 2*dstate][ntok], rows = dt | B | C
+ * 16-bit activations only (AUM_BF16 / AUM_F16, fp32 accumulation on the MFMA units); weights in the same dtype.
+ * Limits: dim % 64 == 0, dt_rank <= 64, dt_rank + 2*dstate <= 80, ntok * 80 < 2^31; otherwise AUM_E_UNSUPPORTED and the
+ * caller uses its library GEMMs.
+ *
+ * aum_proj_fwd       replaces SSI:467-468 (F.linear x_proj, delta_proj matmul) and the B/C slicing + transposes of
+ *                    SSI:471-493:   act = conv_out (in), w_x [dt_rank+2*dstate][dim], w_dt [dim][dt_rank],
+ *                    x_dbl (out), out_act = delta (out, no bias / softplus: the scan applies them).
+ * aum_proj_bwd_data  replaces SSI:570-574 (dB/dC scatter into dx_dbl), SSI:587 and SSI:590:
+ *                    act = ddelta (in), w_dt = W_dt^T [dt_rank][dim], w_x = W_x^T [dim][dt_rank+2*dstate],
+ *                    dB/dC fp32 (batch, dstate, len) with element strides, x_dbl = dx_dbl (out),
+ *                    out_act = dconv, ACCUMULATED in place on top of the scan's du.
+ */
+typedef struct AumProjArgs {
+    const void *act, *w_x, *w_dt;
+    void *x_dbl, *out_act;
+    const float *dB, *dC;
+    int64_t dB_bs, dB_ns, dC_bs, dC_ns;
+    int64_t ntok;
+    int32_t dim, dt_rank, dstate, len, dtype;
+    int32_t w_ld;   /* row pitch (elements, multiple of 8) of the matrix whose rows run along the SHORT k dimension:
+                       forward: w_dt [dim][w_ld >= dt_rank]; backward: w_x = W_x^T [dim][w_ld >= dt_rank + 2*dstate].
+                       Pad columns are never multiplied in (the other operand is zero there) but must be readable. */
+} AumProjArgs;
+int aum_proj_fwd(const AumProjArgs* args, void* stream);
+int aum_proj_bwd_data(const AumProjArgs* args, void* stream);
+/*
+ * aum_proj_bwd_weight  replaces SSI:586 and SSI:589: partial[s][...] = sum over the s-th token range of
+ *                    x[e][t] * y[r][t]  (x: [dim][ntok] 16-bit, y: [nrows][ntok] 16-bit, nrows <= 80), written as
+ *                    [dim][nrows] (transpose_out = 0) or [nrows][dim] (transpose_out = 1) fp32 per split; the caller
+ *                    sums the nsplit partials.  nsplit = aum_proj_bwd_weight_splits(dim, ntok).
+ */
+typedef struct AumProjWArgs {
+    const void *x, *y;
+    float* out;                 /* [nsplit][dim * nrows] */
+    int64_t ntok;
+    int32_t dim, nrows, nsplit, transpose_out, dtype;
+} AumProjWArgs;
+int aum_proj_bwd_weight(const AumProjWArgs* args, void* stream);
+int aum_proj_bwd_weight_splits(int32_t dim, int64_t ntok);
+
 /* Self-tests and calibration (used by tests/ and bench.py; not part of the reference's surface). */
 int aum_abi_version(void);
 /* runs wave_scan_affine<rev> on 64 (P,S) pairs: in/out are device arrays of 128 floats (P[0..63], S[0..63]) */

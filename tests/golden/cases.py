@@ -196,3 +196,11 @@ def model_inputs(name, bimamba_type, depth, embed_dim, spec, num_classes, batch)
     f = np.float32
     return dict(x=(0.5 * r.normal(0, 1, (batch, spec[1], spec[0]))).astype(f),
                 dlogits=r.normal(0, 1, (batch, num_classes)).astype(f))
+
+# (name, d_inner, dt_rank, d_state, batch, len): the MFMA projection kernels (dim % 64 == 0, dt_rank + 2 d_state <= 80)
+PROJ_CASES = [
+    ("base_ranks", 128, 48, 16, 3, 70),      # R + 2N = 80: all 5 column blocks, 2 dt k-chunks, ragged last token tile
+    ("small_ranks", 192, 24, 16, 1, 129),    # AuM-Small: R = 24 (dt rows share a 16-block with B rows)
+    ("tiny_ranks", 64, 12, 16, 2, 33),       # AuM-Tiny: R = 12 (k-groups straddle R), one staging step pair
+    ("n8", 64, 8, 8, 5, 13),                 # d_state 8, ntok = 65 (one full tile + 1 token)
+]

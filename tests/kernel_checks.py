@@ -132,3 +132,39 @@ def check_wave_scan(lib, dev):
             x = float(P[l]) * x + float(S[l])
             ref[l] = x
         assert rel_err(N(So), ref) < 1e-5, ("wave scan", rev)
+
+
+def check_proj(lib, dev, case, dtype=torch.bfloat16):
+    """aum_proj_fwd / _bwd_data / _bwd_weight against fp64 matmuls of the same (rounded) operands: SSI:467-468 and
+    SSI:570-590 restated on channel-major operands.  Second-stage references take the kernel's own 16-bit x_dbl /
+    dx_dbl as input so a 1-ulp rounding difference in stage one is not amplified into a false stage-two error."""
+    name, dim, R, Nst, batch, length = case
+    ntok, rt = batch * length, R + 2 * Nst
+    rng = np.random.default_rng(11)
+    tol = TOL_BF16 if dtype == torch.bfloat16 else 2e-3
+    conv = rq(rng.normal(size=(dim, ntok)), dtype)
+    w_x = rq(rng.normal(size=(rt, dim)) / np.sqrt(dim), dtype)
+    w_dt = rq(rng.normal(size=(dim, R)) / np.sqrt(R), dtype)
+    act = lambda a: T(a, dev, dtype).contiguous()
+    x_dbl, delta = aum_hip.proj_fwd(act(conv), act(w_x), act(w_dt), Nst, lib=lib)
+    errs = {"x_dbl": rel_err(N(x_dbl), w_x.astype(np.float64) @ conv),
+            "delta": rel_err(N(delta), w_dt.astype(np.float64) @ N(x_dbl)[:R].astype(np.float64))}
+    ddelta = rq(rng.normal(size=(dim, ntok)), dtype)
+    du = rq(rng.normal(size=(dim, ntok)), dtype)
+    dB = rng.normal(size=(batch, Nst, length)).astype(np.float32)
+    dC = rng.normal(size=(batch, Nst, length)).astype(np.float32)
+    dconv = act(du)
+    dx_dbl = aum_hip.proj_bwd_data(act(ddelta), act(w_dt.T.copy()), act(w_x.T.copy()), T(dB, dev), T(dC, dev), dconv,
+                                   length, lib=lib)
+    flat = lambda g: g.transpose(1, 0, 2).reshape(Nst, ntok)
+    ref_dx = np.concatenate([w_dt.T.astype(np.float64) @ ddelta, flat(dB), flat(dC)], axis=0)
+    errs["dx_dbl"] = rel_err(N(dx_dbl), ref_dx)
+    errs["dconv"] = rel_err(N(dconv), du + w_x.T.astype(np.float64) @ N(dx_dbl).astype(np.float64))
+    dw_x = aum_hip.proj_bwd_weight(act(conv), dx_dbl, True, lib=lib)
+    dw_dt = aum_hip.proj_bwd_weight(act(ddelta), x_dbl[:R], False, lib=lib)
+    assert dw_x.shape == (rt, dim) and dw_dt.shape == (dim, R)
+    errs["dw_x"] = rel_err(N(dw_x), N(dx_dbl).astype(np.float64) @ conv.T)
+    errs["dw_dt"] = rel_err(N(dw_dt), ddelta.astype(np.float64) @ N(x_dbl)[:R].astype(np.float64).T)
+    for k, e in errs.items():
+        assert e < (1e-4 if k.startswith("dw") else tol), (name, k, e, errs)
+    return errs

@@ -68,3 +68,20 @@ def test_generic_conv_and_norm_kernels(emu):
         KC.check_conv(emu, "cpu", case, torch.float32, reverse=True, generic=True)
     for case in cases.NORM_CASES:
         KC.check_norm(emu, "cpu", case, torch.float32, generic=True)
+
+
+@pytest.mark.parametrize("case", cases.PROJ_CASES, ids=lambda c: c[0])
+def test_proj(emu, case):
+    KC.check_proj(emu, "cpu", case, torch.bfloat16)
+    KC.check_proj(emu, "cpu", case, torch.float16)
+
+
+def test_proj_limits(emu):
+    import numpy as np
+    x = torch.zeros(64, 8, dtype=torch.float32)
+    assert not aum_hip.proj_supported(64, 48, 16, 8, torch.float32)
+    assert not aum_hip.proj_supported(96, 48, 16, 8, torch.bfloat16)
+    assert not aum_hip.proj_supported(64, 48, 32, 8, torch.bfloat16)
+    assert aum_hip.proj_supported(1536, 48, 16, 64 * 513, torch.bfloat16)
+    with pytest.raises(RuntimeError, match="UNSUPPORTED|unsupported"):
+        aum_hip.proj_fwd(x, torch.zeros(80, 64), torch.zeros(64, 48), 16, lib=emu)

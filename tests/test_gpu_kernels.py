@@ -102,3 +102,15 @@ def test_generic_conv_and_norm_kernels(lib):
         KC.check_conv(lib, "cuda", case, torch.float32, reverse=True, generic=True)
     for case in cases.NORM_CASES:
         KC.check_norm(lib, "cuda", case, torch.float32, generic=True)
+
+
+@pytest.mark.parametrize("case", cases.PROJ_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_proj(lib, case, dtype):
+    KC.check_proj(lib, "cuda", case, dtype)
+
+
+def test_proj_full_size(lib):
+    """AuM-Base block: d_inner 1536, dt_rank 48, d_state 16, 64 clips x 513 tokens (513 token tiles, 11 token splits)"""
+    KC.check_proj(lib, "cuda", ("base_full", 1536, 48, 16, 64, 513), torch.bfloat16)
+    KC.check_proj(lib, "cuda", ("base_b3", 1536, 48, 16, 3, 513), torch.bfloat16)        # ntok = 1539: ragged everything

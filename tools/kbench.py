@@ -90,6 +90,30 @@ def main():
         y, rstd, ro = aum_hip.rmsnorm_fwd(x, wn, r, 1e-5)
         dy = torch.randn(M, C, device=dev).to(dt)
         rec("rmsnorm_bwd", timeit(lambda: aum_hip.rmsnorm_bwd(dy, ro, wn, rstd, r, True, x_dtype=dt)), M * C * (2 * s + 12))
+    if want("proj") and dt != torch.float32:
+        R, rt, ntok = a.dmodel // 16, a.dmodel // 16 + 2 * N, Bsz * L
+        conv2 = torch.randn(E, ntok, device=dev).to(dt)
+        dd2 = torch.randn(E, ntok, device=dev).to(dt)
+        w_x = (torch.randn(rt, E, device=dev) / E ** 0.5).to(dt)
+        w_dt = (torch.randn(E, R, device=dev) / R ** 0.5).to(dt)
+        w_xT, w_dtT = w_x.t().contiguous(), w_dt.t().contiguous()
+        dBf, dCf = torch.randn(Bsz, N, L, device=dev), torch.randn(Bsz, N, L, device=dev)
+        dconv = torch.zeros(E, ntok, device=dev).to(dt)
+        act = E * ntok * s
+        rec("proj_fwd", timeit(lambda: aum_hip.proj_fwd(conv2, w_x, w_dt, N)), 2 * act + rt * ntok * s)
+        xd, _ = aum_hip.proj_fwd(conv2, w_x, w_dt, N)
+        rec("proj_bwd_data", timeit(lambda: aum_hip.proj_bwd_data(dd2, w_dtT, w_xT, dBf, dCf, dconv, L)), 3 * act + rt * ntok * s)
+        dxd = aum_hip.proj_bwd_data(dd2, w_dtT, w_xT, dBf, dCf, dconv, L)
+        rec("proj_bwd_weight_x", timeit(lambda: aum_hip.proj_bwd_weight(conv2, dxd, True)), act + rt * ntok * s)
+        rec("proj_bwd_weight_dt", timeit(lambda: aum_hip.proj_bwd_weight(dd2, xd[:R], False)), act + R * ntok * s)
+        # the library GEMMs they replace (same operands, hipBLASLt through torch)
+        rec("lib_x_proj_fwd", timeit(lambda: torch.matmul(conv2.t(), w_x.t())), act)
+        xtm = torch.matmul(conv2.t(), w_x.t())
+        rec("lib_dt_proj_fwd", timeit(lambda: torch.matmul(w_dt, xtm[:, :R].t())), act)
+        rec("lib_dt_proj_dgrad", timeit(lambda: torch.matmul(dd2.t(), w_dt)), act)
+        rec("lib_x_proj_dgrad", timeit(lambda: dconv.addmm_(w_x.t(), xtm.t())), 2 * act)
+        rec("lib_x_proj_wgrad", timeit(lambda: torch.matmul(xtm.t(), conv2.t())), act)
+        rec("lib_dt_proj_wgrad", timeit(lambda: torch.matmul(dd2, xtm[:, :R])), act)
     if want("ablate"):
         _, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True)
         for bits, label in ((0, "full"), (1, "no_states"), (2, "no_lds_atomics"), (4, "no_partials"), (8, "no_epilogue"),
