@@ -46,6 +46,9 @@ def test_struct_layouts_match_header(tmp_path):
         "AumScanBwdArgs": (aum_hip.ScanBwdArgs, ["u", "dout", "A", "du", "dA", "workspace_bytes", "dC_ns", "batch", "flags"]),
         "AumConvArgs": (aum_hip.ConvArgs, ["x", "weight", "y", "dweight", "x_bs", "dx_ds", "batch", "flags"]),
         "AumNormArgs": (aum_hip.NormArgs, ["x", "weight", "y", "rstd_out", "row_stride_x", "eps", "rows", "flags"]),
+        "AumFbankArgs": (aum_hip.FbankArgs, ["wave", "mel_w", "out", "wave_bs", "batch", "mel_wstride", "preemph", "log_floor"]),
+        "AumProjArgs": (aum_hip.ProjArgs, ["act", "w_dt", "out_act", "dB", "dC_ns", "ntok", "dim", "dtype", "w_ld"]),
+        "AumProjWArgs": (aum_hip.ProjWArgs, ["x", "y", "out", "ntok", "dim", "nsplit", "dtype"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']
     for cname, (_, fields) in probes.items():
