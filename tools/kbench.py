@@ -59,7 +59,7 @@ def main():
         res.append(r)
         print(json.dumps(r), flush=True)
 
-    want = lambda n: (not a.only) or a.only in n
+    want = lambda n: (not a.only) or any(o in n for o in a.only.split(","))
     if want("hbm_copy"):
         src = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255)
         dst = torch.empty_like(src)
