@@ -4,8 +4,9 @@
 Mirrors the default configuration of the reference's AudioMamba (/root/reference/src/models/mamba_models.py = "MM":
 forward_features MM:509-667, Block.forward MM:58-99, defaults MM:191-242) and produces the SAME state-dict keys
 (patch_embed.proj.*, cls_token, pos_embed.pos_embed, layers.{i}.mixer.*, layers.{i}.norm.weight, norm_f.weight,
-head.*) so published checkpoints load.  Options off the default path (rope, double cls, flexible patch sizes,
-drop-path > 0, if_bidirectional layer pairing) are out of scope and rejected.
+head.*) so published checkpoints load.  Also mirrored: the cls-token placements of RUN's flags (middle / end / head,
+MM:528-535), `transpose_token_sequence` (time-major token order, MM:545-566) and `if_bidirectional` layer pairing
+(MM:623-638).  Options off that surface (rope, double cls, flexible patch sizes, drop-path > 0) are rejected.
 """
 import math
 
@@ -66,13 +67,24 @@ class Block(nn.Module):
 class AudioMamba(nn.Module):
     def __init__(self, spectrogram_size=(128, 1024), patch_size=(16, 16), strides=(16, 16), depth=24, embed_dim=768,
                  channels=1, num_classes=527, norm_epsilon=1e-5, bimamba_type="v1", if_devide_out=True,
-                 use_middle_cls_token=True, ssm_cfg=None, device=None, dtype=None):
+                 use_middle_cls_token=True, use_end_cls_token=False, transpose_token_sequence=False,
+                 if_bidirectional=False, ssm_cfg=None, device=None, dtype=None, **unsupported):
         super().__init__()
+        on = {k: v for k, v in unsupported.items() if v not in (None, False, 0, 0.0, -1.0)
+              and k not in ("if_cls_token", "rms_norm", "fused_add_norm", "residual_in_fp32", "if_abs_pos_embed", "final_pool_type",
+                            "imagenet_load_middle_cls_token", "use_PI_for_patch_embed", "imagenet_pretrain_modelkey")}
+        if on:
+            raise NotImplementedError(f"AudioMamba options outside the accelerated path: {sorted(on)}")
         if tuple(patch_size) != tuple(strides):
             raise NotImplementedError("overlapping patches are off the default path")
         self.embed_dim = self.d_model = embed_dim
         self.num_classes = num_classes
         self.use_middle_cls_token = use_middle_cls_token
+        self.use_end_cls_token = use_end_cls_token
+        self.transpose_token_sequence = transpose_token_sequence
+        self.if_bidirectional = if_bidirectional
+        if if_bidirectional and depth % 2:
+            raise ValueError("if_bidirectional pairs the layers: depth must be even")
         fdim = (spectrogram_size[0] - patch_size[0]) // strides[0] + 1
         tdim = (spectrogram_size[1] - patch_size[1]) // strides[1] + 1
         self.patch_grid_size = (fdim, tdim)
@@ -104,16 +116,25 @@ class AudioMamba(nn.Module):
         x = self.patch_embed(x)                                    # token index = f * n_t + t
         Bsz, Np, _ = x.shape
         pe = self.pos_embed.pos_embed
-        pos = Np // 2 if self.use_middle_cls_token else 0
+        pos = Np // 2 if self.use_middle_cls_token else (Np if self.use_end_cls_token else 0)      # MM:528-535
         cls = (self.cls_token + pe[:, :1]).expand(Bsz, -1, -1)
-        x = x + pe[:, 1:]
+        x = x + pe[:, 1:]                                          # position embedding belongs to the (f, t) cell
+        if self.transpose_token_sequence:                          # MM:545-566: patches in time-major order, cls stays put
+            nf, nt = self.patch_grid_size
+            x = x.reshape(Bsz, nf, nt, -1).transpose(1, 2).reshape(Bsz, nt * nf, -1)
         return torch.cat((x[:, :pos], cls.to(x.dtype), x[:, pos:]), dim=1), pos
 
     def forward_features(self, x):
         hidden, pos = self.tokens(x)
         residual = None
-        for layer in self.layers:
-            hidden, residual = layer(hidden, residual)
+        if not self.if_bidirectional:
+            for layer in self.layers:
+                hidden, residual = layer(hidden, residual)
+        else:                                                      # MM:623-638: layer 2i forward, layer 2i+1 on the flipped sequence
+            for i in range(len(self.layers) // 2):
+                hf, rf = self.layers[2 * i](hidden, residual)
+                hb, rb = self.layers[2 * i + 1](hidden.flip([1]), None if residual is None else residual.flip([1]))
+                hidden, residual = hf + hb.flip([1]), rf + rb.flip([1])
         hidden = rms_norm_fn(hidden, self.norm_f.weight, self.norm_f.bias, eps=self.norm_f.eps, residual=residual,
                              prenorm=False, residual_in_fp32=True)                            # MM:646-657
         return hidden[:, pos]

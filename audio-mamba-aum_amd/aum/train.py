@@ -74,6 +74,11 @@ def build_parser():
     a("--aum_drop_path", type=float, default=0)
     a("--if_cls_token", type=_lit, default="True")
     a("--use_middle_cls_token", type=_lit, default="True")
+    a("--use_double_cls_token", type=_lit, default="False")
+    a("--use_end_cls_token", type=_lit, default="False")
+    a("--transpose_token_sequence", type=_lit, default="False")
+    a("--if_random_cls_token_position", type=_lit, default="False")
+    a("--if_random_token_rank", type=_lit, default="False")
     a("--aum_type", type=str, default="Fo-Bi")
     a("--lr", "--learning-rate", default=0.001, type=float)
     a("--optim", type=str, default="adam", choices=["sgd", "adam"])
@@ -103,8 +108,8 @@ def check_scope(args):
         raise NotImplementedError("--model ast (the transformer baseline) is outside the accelerated path")
     if args.dataset == "epic_sounds" or args.flexible_training or args.imagenet_pretrain or args.aum_drop_path:
         raise NotImplementedError("epic_sounds / flexible training / ImageNet init / drop-path are out of scope")
-    if not args.if_cls_token:
-        raise NotImplementedError("--if_cls_token False is off the default path")
+    if not args.if_cls_token or args.use_double_cls_token or args.if_random_cls_token_position or args.if_random_token_rank:
+        raise NotImplementedError("no / double / randomly placed cls tokens are off the accelerated path")
 
 
 class Dist:
@@ -149,7 +154,8 @@ def build_model(args):
         raise ValueError("unknown aum type, aum type should be one of [Fo-Fo, Fo-Bi, Bi-Bi] for aum")
     model = AudioMamba(spectrogram_size=(args.melbins, args.audio_length), patch_size=(args.fpatch_size, args.tpatch_size),
                        strides=(args.fstride, args.tstride), depth=args.depth, embed_dim=AUM_SIZES[size], num_classes=args.n_class,
-                       bimamba_type=bimamba, use_middle_cls_token=args.use_middle_cls_token)
+                       bimamba_type=bimamba, use_middle_cls_token=args.use_middle_cls_token,
+                       use_end_cls_token=args.use_end_cls_token, transpose_token_sequence=args.transpose_token_sequence)
     if args.aum_pretrain:
         from .checkpoint import load_aum_checkpoint
         print(load_aum_checkpoint(model, args.aum_pretrain_path, args.aum_pretrain_fstride, args.aum_pretrain_tstride))

@@ -161,7 +161,16 @@ MODEL_CASES = [
     ("tiny_v2_d2", "v2", 2, 192, (128, 128), 35, 2),
     ("tiny_none_d2", "none", 2, 192, (128, 128), 35, 2),
     ("d64_v1_d3_t256", "v1", 3, 64, (128, 256), 10, 2),
+    # off-default flags of run.py: layer pairing on flipped sequences, end cls token, time-major token order
+    ("d64_none_pairs_d4", "none", 4, 64, (128, 128), 10, 2, {"if_bidirectional": True}),
+    ("d64_v1_endcls_tr", "v1", 2, 64, (128, 128), 10, 2, {"use_middle_cls_token": False, "use_end_cls_token": True,
+                                                           "transpose_token_sequence": True}),
+    ("d64_v2_headcls", "v2", 2, 64, (128, 128), 10, 2, {"use_middle_cls_token": False}),
 ]
+
+
+def model_kwargs(case):
+    return case[7] if len(case) > 7 else {}
 
 
 def model_state(shapes, tag):
@@ -191,7 +200,7 @@ def model_state(shapes, tag):
     return out
 
 
-def model_inputs(name, bimamba_type, depth, embed_dim, spec, num_classes, batch):
+def model_inputs(name, bimamba_type, depth, embed_dim, spec, num_classes, batch, extra=None):
     r = _rng("modelin_" + name)
     f = np.float32
     return dict(x=(0.5 * r.normal(0, 1, (batch, spec[1], spec[0]))).astype(f),

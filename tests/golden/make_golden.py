@@ -242,10 +242,10 @@ def model_goldens(torch, ssi, ln):
     mm = import_reference_model(torch, ssi, ln)
     out = {}
     for case in cases.MODEL_CASES:
-        name, btype, depth, dim, spec, ncls, batch = case
+        name, btype, depth, dim, spec, ncls, batch = case[:7]
         with contextlib.redirect_stdout(io.StringIO()):
             model = mm.AudioMamba(spectrogram_size=spec, depth=depth, embed_dim=dim, num_classes=ncls,
-                                  bimamba_type=btype)
+                                  bimamba_type=btype, **cases.model_kwargs(case))
         sd = model.state_dict()
         vals = cases.model_state({k: tuple(v.shape) for k, v in sd.items()}, name)
         model.load_state_dict({k: torch.tensor(v) for k, v in vals.items()})

@@ -17,8 +17,9 @@ DEV = "cuda"
 def test_audio_mamba_vs_reference_model(case):
     from aum.model import AudioMamba
     g = load_golden("model")
-    name, btype, depth, dim, spec, ncls, batch = case
-    model = AudioMamba(spectrogram_size=spec, depth=depth, embed_dim=dim, num_classes=ncls, bimamba_type=btype)
+    name, btype, depth, dim, spec, ncls, batch = case[:7]
+    model = AudioMamba(spectrogram_size=spec, depth=depth, embed_dim=dim, num_classes=ncls, bimamba_type=btype,
+                       **cases.model_kwargs(case))
     sd = model.state_dict()
     assert sorted(sd.keys()) == list(g[name + ".keys"])
     vals = cases.model_state({k: tuple(v.shape) for k, v in sd.items()}, name)
