@@ -146,6 +146,7 @@ class LaunchTimer:
 
     def __init__(self):
         self.enabled = False
+        self.only = None        # optional set of kernel names to time (two events per launch cost ~8 us of host time)
         self.records = {}       # name -> list of (start_event, end_event, meta)
 
     def reset(self):
@@ -164,7 +165,7 @@ timer = LaunchTimer()
 
 
 def _launch(fn, args, stream_tensor, lib, name, meta=None):
-    if timer.enabled and not lib.host:
+    if timer.enabled and not lib.host and (timer.only is None or name in timer.only):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         rc = fn(C_byref(args), lib.stream(stream_tensor))

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Throughput of the configurations around the headline one (NOT the bench line): AuM sizes, block types, inference.
+Same step as bench.py (bf16 autocast, BCE, fused Adam, GPU log-mel frontend), per-GPU batch 64 unless noted."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "audio-mamba-aum_amd"))
+from aum import tunable  # noqa: E402
+tunable.enable(0)
+import torch  # noqa: E402
+from aum.model import build_aum  # noqa: E402
+from aum.frontend import FbankTables, wav2fbank  # noqa: E402
+
+
+def run(size, btype, train, batch=64, steps=6, warm=3):
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    model = build_aum(size, depth=24, num_classes=527, bimamba_type=btype).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    tabs = FbankTables(dev)
+    wave = (torch.randn(batch, 160000, device=dev) * 0.1).clamp_(-1, 1)
+    y = torch.zeros(batch, 527, device=dev)
+    y[:, :2] = 1
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+
+    def step():
+        x = wav2fbank(wave, tabs, target_length=1024)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if train:
+                loss = loss_fn(model(x).float(), y)
+            else:
+                with torch.no_grad():
+                    return model(x)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    model.train(train)
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    r = {"size": size, "block": {"v1": "Fo-Bi", "v2": "Bi-Bi", "none": "Fo-Fo"}[btype], "mode": "train" if train else "inference",
+         "batch": batch, "ms_per_step": round(dt * 1e3, 2), "clips_per_s": round(batch / dt, 1),
+         "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    print(json.dumps(r), flush=True)
+    del model, opt
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    return r
+
+
+if __name__ == "__main__":
+    out = [run("base", "v1", True), run("base", "v1", False), run("base", "v2", True), run("base", "none", True),
+           run("small", "v1", True), run("tiny", "v1", True), run("base", "v1", True, batch=256, steps=3, warm=2)]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "variants_bench.json"), "w"), indent=1)
