@@ -29,6 +29,10 @@ CONV_CASES = [
     ("l513", 1, 16, 513, 4, True),
     ("l65_nobias", 2, 8, 65, 4, False),
     ("l70_w3", 1, 4, 70, 3, True),
+    # the AuM row shape 512 + tail (several rows of one channel per wave, tail steps wave-uniform): batch not a multiple of 8
+    ("l513_b11", 11, 3, 513, 4, True),
+    ("l520_b3", 3, 4, 520, 4, False),
+    ("l512_b9", 9, 2, 512, 4, True),
 ]
 
 # (name, rows(list shape), cols, has_residual, prenorm)

@@ -55,6 +55,14 @@ def test_conv_bf16(emu):
     KC.check_conv(emu, "cpu", cases.CONV_CASES[2], torch.bfloat16)
 
 
+@pytest.mark.parametrize("case", [c for c in cases.CONV_CASES if 512 <= c[3] <= 520], ids=lambda c: c[0])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_conv_rows_kernels_16bit(emu, case, reverse):
+    """len = 512 + tail, 16-bit: conv_rows_kernels.h (8 rows of a channel per wave, wave-uniform tail steps)"""
+    KC.check_conv(emu, "cpu", case, torch.bfloat16, reverse=reverse)
+    KC.check_conv(emu, "cpu", case, torch.float16, reverse=reverse, silu=False)
+
+
 @pytest.mark.parametrize("case", cases.NORM_CASES, ids=lambda c: c[0])
 def test_norm(emu, case):
     KC.check_norm(emu, "cpu", case, torch.float32)
