@@ -21,7 +21,10 @@
 
 namespace aum {
 
-constexpr int SCANWG_NW = 8;          // waves per workgroup
+#ifndef AUM_SCANWG_NW
+#define AUM_SCANWG_NW 8
+#endif
+constexpr int SCANWG_NW = AUM_SCANWG_NW;          // waves per workgroup
 constexpr int SCANWG_MAX_N = 16;      // dstate limit of this path (LDS tile height)
 constexpr int SCANWG_MAX_ROWS = 64;   // rows per workgroup (8 waves x 4 pairs x 2 rows)
 constexpr int SCANWG_MAX_K = 9;       // <= 577 steps per chunk keeps the backward's 4 fp32 tiles inside 160 KB of LDS
@@ -643,7 +646,7 @@ AUM_DEV void scanwg_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_pe
                 // solution); a barrier after every SECOND step therefore keeps any two waves at most one step apart and
                 // the tile update below can be a plain LDS read-add-write.
                 for (int j = 0; j < SCANWG_MAX_N; ++j) {
-                    const int n = (j + 2 * w) & (SCANWG_MAX_N - 1);
+                    const int n = (j + (SCANWG_MAX_N / SCANWG_NW) * w) & (SCANWG_MAX_N - 1);
                     if (active && n < N) {
                         vf Bn[KT], Cn[KT];
                         vf2 dBacc[KT], dCacc[KT];
