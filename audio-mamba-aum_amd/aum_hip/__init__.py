@@ -248,7 +248,7 @@ def C_byref(s):
 
 
 def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=False, reverse=False, A_b=None,
-             dz_out=None, dmajor=False, generic=False, lib=None):
+             dz_out=None, dmajor=False, generic=False, rowpair=False, lib=None):
     """selective_scan_cuda.bwd.  Returns dict(du, ddelta, dA, dA_b, dB, dC, dD, dz, ddelta_bias); dB/dC fp32
     (batch, dstate, len).  dz_out: optional preallocated (possibly strided) tensor written in place (SSI:537-545)."""
     lib = lib or get()
@@ -299,6 +299,7 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=
     a.dB_bs, a.dB_ns, a.dC_bs, a.dC_ns = dB.stride(0), dB.stride(1), dC.stride(0), dC.stride(1)
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
     a.flags = ((SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0) | (SCAN_GENERIC if generic else 0)
+               | (8 if rowpair or os.environ.get('AUM_SCAN_ROWPAIR') == '1' else 0)
                | (int(os.environ.get('AUM_ABLATE', '0')) << 16))   # AUM_ABLATE: kernel-ablation bits for tools/kbench.py only
     _launch(lib.c.aum_selective_scan_bwd, a, u, lib, "scan_bwd_bidir" if A_b is not None else "scan_bwd",
             (batch, dim, length, dstate, u.element_size(), True))

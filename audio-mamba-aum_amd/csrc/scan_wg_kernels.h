@@ -97,13 +97,13 @@ template <int K, int TAIL> AUM_DEV vi scan_tile_pos(vi tt) {
 // Cooperative load of one [N][S] tile of B (or C) into LDS as fp32; t outside [0,len) -> 0.
 // K == 8 with the main part inside the row: 16-byte loads of 8 consecutive steps (= one lane's main slots), so a tile is
 // 2 load instructions per thread instead of 36 dependent 2-byte gathers; otherwise element-wise.
-template <class T, int K, int TAIL>
+template <class T, int K, int TAIL, int NW = SCANWG_NW>
 AUM_DEV void scanwg_load_tile(const T* src, int64_t n_stride, int N, int base, int len, float* tile, int w) {
     using G = ScanGeo<K, TAIL>;
     const vi lane = lane_id();
     if constexpr (K == 8) {
         if (base + WAVE * K <= len) {
-            for (int i0 = w * WAVE; i0 < N * WAVE; i0 += SCANWG_NW * WAVE) {      // (state n, lane-block j) pairs
+            for (int i0 = w * WAVE; i0 < N * WAVE; i0 += NW * WAVE) {      // (state n, lane-block j) pairs
                 const vi idx = lane + i0;
                 const vm in = idx < N * WAVE;
                 const vi n = vmin_i(idx >> 6, N - 1);
@@ -124,7 +124,7 @@ AUM_DEV void scanwg_load_tile(const T* src, int64_t n_stride, int N, int base, i
             return;
         }
     }
-    for (int i0 = w * WAVE; i0 < N * G::S; i0 += SCANWG_NW * WAVE) {
+    for (int i0 = w * WAVE; i0 < N * G::S; i0 += NW * WAVE) {
         const vi idx = lane + i0;
         const vm in = idx < N * G::S;
         const vi n = vmin_i(idx / G::S, N - 1);
@@ -136,13 +136,13 @@ AUM_DEV void scanwg_load_tile(const T* src, int64_t n_stride, int N, int base, i
 }
 
 // Write one [N][S] fp32 LDS tile to a dense (N, len) fp32 global partial (t >= len skipped); vectorised like the load.
-template <int K, int TAIL>
+template <int K, int TAIL, int NW = SCANWG_NW>
 AUM_DEV void scanwg_store_tile(const float* tile, float* dst, int N, int base, int len, int w) {
     using G = ScanGeo<K, TAIL>;
     const vi lane = lane_id();
     if constexpr (K == 8) {
         if (base + WAVE * K <= len) {
-            for (int i0 = w * WAVE; i0 < N * WAVE; i0 += SCANWG_NW * WAVE) {
+            for (int i0 = w * WAVE; i0 < N * WAVE; i0 += NW * WAVE) {
                 const vi idx = lane + i0;
                 const vm in = idx < N * WAVE;
                 const vi n = vmin_i(idx >> 6, N - 1);
@@ -162,7 +162,7 @@ AUM_DEV void scanwg_store_tile(const float* tile, float* dst, int N, int base, i
             return;
         }
     }
-    for (int i0 = w * WAVE; i0 < N * G::S; i0 += SCANWG_NW * WAVE) {
+    for (int i0 = w * WAVE; i0 < N * G::S; i0 += NW * WAVE) {
         const vi idx = lane + i0;
         const vi n = vmin_i(idx / G::S, N - 1);
         const vi tt = vmin_i(idx - (idx / G::S) * G::S, G::S - 1);

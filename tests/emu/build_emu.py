@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "audio-mamba-aum_amd", "csrc")
 CXX = os.environ.get("AUM_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 DEPS = [os.path.join(HERE, "aum_emu.cpp")] + [os.path.join(CSRC, f) for f in
-        ("aum_api.inc", "wave.h", "scan_kernels.h", "scan_wg_kernels.h", "fbank_kernels.h", "proj_kernels.h", "conv_rows_kernels.h", "conv_norm_kernels.h")] + [os.path.join(ROOT, "include", "aum_hip.h")]
+        ("aum_api.inc", "wave.h", "scan_kernels.h", "scan_wg_kernels.h", "scan_half_kernels.h", "fbank_kernels.h", "proj_kernels.h", "conv_rows_kernels.h", "conv_norm_kernels.h")] + [os.path.join(ROOT, "include", "aum_hip.h")]
 
 
 def build():
@@ -18,13 +18,15 @@ def build():
     h = hashlib.sha256()
     for d in DEPS:
         h.update(open(d, "rb").read())
+    extra = os.environ.get("AUM_EXTRA_CXXFLAGS", "").split()
+    h.update(" ".join(extra).encode())
     dig = h.hexdigest()
     stamp = os.path.join(out_dir, "digest")
     if os.path.exists(so) and os.path.exists(stamp) and open(stamp).read() == dig:
         return so
     subprocess.check_call([CXX, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                           "-Wno-unused-variable", "-Wno-unused-function",
-                           os.path.join(HERE, "aum_emu.cpp"), "-o", so])
+                           "-Wno-unused-variable", "-Wno-unused-function"] + extra +
+                          [os.path.join(HERE, "aum_emu.cpp"), "-o", so])
     open(stamp, "w").write(dig)
     return so
 

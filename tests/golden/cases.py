@@ -21,6 +21,12 @@ SCAN_CASES = [
     ("l577_n8", 1, 6, 577, 8, True, True, True, True),
 ]
 
+# checked against the live oracle only (no fixture): several row groups per batch entry, a ragged last group, idle waves
+SCAN_WIDE_CASES = [
+    ("l513_d100", 2, 100, 513, 16, True, True, True, True),
+    ("l513_d70_n8_noz", 1, 70, 513, 8, False, True, False, True),
+]
+
 # (name, batch, dim, len, width, has_bias)
 CONV_CASES = [
     ("l1", 2, 8, 1, 4, True),

@@ -26,7 +26,8 @@ def rq(a, dtype):
     return None if a is None else torch.tensor(np.asarray(a)).to(dtype).float().numpy()
 
 
-def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, tol=None, strided=False, generic=False):
+def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, tol=None, strided=False, generic=False,
+               rowpair=False):
     name, batch, dim, length, dstate, has_z, has_D, has_bias, softplus = case
     d = cases.scan_inputs(*case)
     tol = tol or (TOL_F32 if dtype == torch.float32 else TOL_BF16)
@@ -54,7 +55,7 @@ def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, 
     # backward
     dout = act(d["dout"])
     g = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, out_pre if has_z else None, softplus, reverse,
-                         T(A_b, dev), generic=generic, lib=lib)
+                         T(A_b, dev), generic=generic, rowpair=rowpair, lib=lib)
     gr = O.scan_bwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus,
                     reverse, "f64")
     if bidir:

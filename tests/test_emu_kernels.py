@@ -36,6 +36,16 @@ def test_scan(emu, case, mode, path):
                   generic=(path == "generic"))
 
 
+@pytest.mark.parametrize("case", cases.SCAN_WIDE_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+def test_scan_one_row_backward_vs_row_pair(emu, case, mode):
+    """L = 513: the backward is scan_half_kernels.h (one row per wave, 12/16-wave workgroups of 96/64 rows); both it and
+    the row-pair kernel it replaces must match the oracle on shapes with several, partly idle row groups"""
+    for rowpair in (False, True):
+        KC.check_scan(emu, "cpu", case, torch.float32, reverse=(mode == "rev"), bidir=(mode == "bidir"), rowpair=rowpair)
+    KC.check_scan(emu, "cpu", case, torch.bfloat16, reverse=(mode == "rev"), bidir=(mode == "bidir"))
+
+
 @pytest.mark.parametrize("mode", ["fwd", "bidir"])
 def test_scan_bf16_and_strided(emu, mode):
     case = [c for c in cases.SCAN_CASES if c[0] == "l65"][0]

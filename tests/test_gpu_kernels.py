@@ -41,6 +41,14 @@ def test_scan_16bit(lib, case, mode, dtype):
                   tol=1e-2 if dtype == torch.bfloat16 else 2e-3)
 
 
+@pytest.mark.parametrize("case", cases.SCAN_WIDE_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_one_row_backward_vs_row_pair(lib, case, mode, dtype):
+    for rowpair in (False, True):
+        KC.check_scan(lib, "cuda", case, dtype, reverse=(mode == "rev"), bidir=(mode == "bidir"), rowpair=rowpair)
+
+
 def test_scan_strided_layout(lib):
     c = [x for x in cases.SCAN_CASES if x[0] == "l65"][0]
     KC.check_scan(lib, "cuda", c, torch.float32, bidir=True, strided=True)
