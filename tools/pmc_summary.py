@@ -8,8 +8,10 @@ import re
 import sys
 from collections import defaultdict
 
-NAMES = [("k_scanwg_bwd<aum::bf16_t, 8, 1, 2>", "scan_bwd_bidir"), ("k_scanwg_fwd<aum::bf16_t, 8, 1, 2>", "scan_fwd_bidir"),
-         ("k_scanwg_bwd<aum::bf16_t, 8, 1, 0>", "scan_bwd"), ("k_scanwg_fwd<aum::bf16_t, 8, 1, 0>", "scan_fwd"),
+NAMES = [("k_scanh_bwd<aum::bf16_t, 1, 2>", "scan_bwd_bidir"), ("k_scanh_bwd<aum::bf16_t, 1, 0>", "scan_bwd"),
+         ("k_conv4_rows_fwd<", "conv_fwd"), ("k_conv4_rows_bwd<", "conv_bwd"),
+         ("k_scanwg_bwd<aum::bf16_t, 8, 1, 2>", "scan_bwd_bidir_rowpair"), ("k_scanwg_fwd<aum::bf16_t, 8, 1, 2>", "scan_fwd_bidir"),
+         ("k_scanwg_bwd<aum::bf16_t, 8, 1, 0>", "scan_bwd_rowpair"), ("k_scanwg_fwd<aum::bf16_t, 8, 1, 0>", "scan_fwd"),
          ("k_proj_fwd<", "proj_fwd"), ("k_proj_bwd_data<", "proj_bwd_data"), ("k_proj_bwd_weight<", "proj_bwd_weight"),
          ("k_conv4_fwd<", "conv_fwd"), ("k_conv4_bwd<", "conv_bwd"), ("k_norm_fwd_vec<", "rmsnorm_fwd"), ("k_norm_bwd_vec<", "rmsnorm_bwd"),
          ("k_hbm_copy", "hbm_copy")]
