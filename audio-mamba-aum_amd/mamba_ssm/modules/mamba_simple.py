@@ -4,8 +4,9 @@ parameter / sub-module names (the checkpoint contract: in_proj, conv1d, x_proj, 
 and for v2 conv1d_b, x_proj_b, dt_proj_b, D_b), initialisation (MS:94-127) and forward dispatch (MS:169-311).
 
 Differences: the kernels underneath are libaum_hip.so; Bi-Bi (v2) passes reverse=True instead of flipping xz and the
-result (MS:229-246); single-token decoding (`step`, inference caches, MS:313-458) is out of scope -- AuM never
-passes inference_params (MM:620-622).
+result (MS:229-246); single-token decoding (`step`, inference caches, MS:313-400) exists for the causal block
+(bimamba_type="none") as the reference's element-wise composition -- AuM itself never passes inference_params
+(MM:620-622).
 """
 import math
 
@@ -81,8 +82,14 @@ class Mamba(nn.Module):
 
     # ---- forward (MS:169-311) ---------------------------------------------------------------------
     def forward(self, hidden_states, inference_params=None):
-        if inference_params is not None:
-            raise NotImplementedError("inference caches / step() are out of scope (AuM passes None, MM:620-622)")
+        conv_state = ssm_state = None
+        if inference_params is not None:                                   # streaming inference, MS:176-182
+            if self.bimamba_type != "none":
+                raise NotImplementedError("inference caches only make sense for the causal (bimamba_type='none') block")
+            conv_state, ssm_state = self._get_states_from_cache(inference_params, hidden_states.shape[0])
+            if inference_params.seqlen_offset > 0:
+                out, _, _ = self.step(hidden_states, conv_state, ssm_state)    # states updated in place
+                return out
         batch, seqlen, _ = hidden_states.shape
         # matmul + transpose in one GEMM: xz is (B, 2E, L) stored channel-major, like MS:185-189
         xz = torch.matmul(self.in_proj.weight, hidden_states.reshape(batch * seqlen, -1).t())
@@ -90,7 +97,7 @@ class Mamba(nn.Module):
         if self.in_proj.bias is not None:
             xz = xz + self.in_proj.bias.to(xz.dtype)[None, :, None]
         A = -torch.exp(self.A_log.float())
-        if self.use_fast_path:
+        if self.use_fast_path and inference_params is None:                # MS:190
             if self.bimamba_type == "v1":
                 A_b = -torch.exp(self.A_b_log.float())
                 out = bimamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
@@ -121,6 +128,8 @@ class Mamba(nn.Module):
                                      self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
         else:       # un-fused composition of the same ops (MS:264-308)
             x, z = xz.chunk(2, dim=1)
+            if conv_state is not None:                                     # MS:268-271: the last d_conv inputs
+                conv_state.copy_(F.pad(x, (self.d_conv - x.shape[-1], 0)))
             x = causal_conv1d_fn(x, self.conv1d.weight.reshape(self.d_inner, -1), self.conv1d.bias, self.activation)
             x_dbl = self.x_proj(x.transpose(1, 2).reshape(batch * seqlen, -1))
             dt, Bm, Cm = torch.split(x_dbl, [self.dt_rank, self.d_state, self.d_state], dim=-1)
@@ -128,14 +137,60 @@ class Mamba(nn.Module):
             Bm = Bm.reshape(batch, seqlen, -1).transpose(1, 2).contiguous()
             Cm = Cm.reshape(batch, seqlen, -1).transpose(1, 2).contiguous()
             y = selective_scan_fn(x, dt.to(x.dtype), A, Bm.to(x.dtype), Cm.to(x.dtype), self.D.float(),
-                                  z=z.to(x.dtype), delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
+                                  z=z.to(x.dtype), delta_bias=self.dt_proj.bias.float(), delta_softplus=True,
+                                  return_last_state=ssm_state is not None)
+            if ssm_state is not None:                                      # MS:300-302
+                y, last_state = y
+                ssm_state.copy_(last_state)
             out = self.out_proj(y.transpose(1, 2))
         if self.init_layer_scale is not None:
             out = out * self.gamma
         return out
 
-    def step(self, *args, **kwargs):
-        raise NotImplementedError("autoregressive decode is out of scope for the AuM hot path (SURVEY 2.1 #2)")
+    def step(self, hidden_states, conv_state, ssm_state):
+        """One token of streaming inference (MS:313-358): conv window roll + one SSM update, states in place.  The
+        reference's optional fused update kernels (causal_conv1d_update, selective_state_update) are absent from its own
+        environment too; this is its element-wise composition, a handful of (batch, d_inner[, d_state]) ops per token."""
+        dtype = hidden_states.dtype
+        assert hidden_states.shape[1] == 1, "Only support decoding with 1 token at a time for now"
+        xz = self.in_proj(hidden_states.squeeze(1))                        # (B, 2E)
+        x, z = xz.chunk(2, dim=-1)
+        conv_state.copy_(torch.roll(conv_state, shifts=-1, dims=-1))       # (B, E, W)
+        conv_state[:, :, -1] = x
+        x = torch.sum(conv_state * self.conv1d.weight.reshape(self.d_inner, -1), dim=-1)
+        if self.conv1d.bias is not None:
+            x = x + self.conv1d.bias
+        x = F.silu(x).to(dtype=dtype)
+        x_db = self.x_proj(x)
+        dt, Bm, Cm = torch.split(x_db, [self.dt_rank, self.d_state, self.d_state], dim=-1)
+        dt = F.linear(dt, self.dt_proj.weight)                             # bias added below, inside the softplus
+        A = -torch.exp(self.A_log.float())
+        dt = F.softplus(dt + self.dt_proj.bias.to(dtype=dt.dtype))
+        dA = torch.exp(torch.einsum("bd,dn->bdn", dt, A))
+        dB = torch.einsum("bd,bn->bdn", dt, Bm)
+        ssm_state.copy_(ssm_state * dA + x.unsqueeze(-1) * dB)
+        y = torch.einsum("bdn,bn->bd", ssm_state.to(dtype), Cm)
+        y = y + self.D.to(dtype) * x
+        y = y * F.silu(z)
+        out = self.out_proj(y)
+        return out.unsqueeze(1), conv_state, ssm_state
 
-    def allocate_inference_cache(self, *args, **kwargs):
-        raise NotImplementedError("autoregressive decode is out of scope for the AuM hot path (SURVEY 2.1 #2)")
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        """MS:360-373"""
+        device = self.out_proj.weight.device
+        conv_state = torch.zeros(batch_size, self.d_inner, self.d_conv, device=device,
+                                 dtype=self.conv1d.weight.dtype if dtype is None else dtype)
+        ssm_state = torch.zeros(batch_size, self.d_inner, self.d_state, device=device,
+                                dtype=self.dt_proj.weight.dtype if dtype is None else dtype)
+        return conv_state, ssm_state
+
+    def _get_states_from_cache(self, inference_params, batch_size, initialize_states=False):
+        """MS:375-400"""
+        assert self.layer_idx is not None
+        if self.layer_idx not in inference_params.key_value_memory_dict:
+            inference_params.key_value_memory_dict[self.layer_idx] = self.allocate_inference_cache(batch_size, 0)
+        conv_state, ssm_state = inference_params.key_value_memory_dict[self.layer_idx]
+        if initialize_states:
+            conv_state.zero_()
+            ssm_state.zero_()
+        return conv_state, ssm_state

@@ -244,3 +244,28 @@ def test_mfma_projection_path_matches_library_gemm_path(btype, monkeypatch):
     assert rel_err(y1.float().detach().numpy(), y2.float().detach().numpy()) < 2e-2
     for n, p in m.named_parameters():
         assert rel_err(g1[n].numpy(), p.grad.float().numpy()) < 4e-2, n
+
+
+def test_streaming_inference_matches_full_sequence():
+    """MS:176-182, 313-400: prefill with an inference cache, then token-by-token step() -- must reproduce the causal
+    block's output on the whole sequence (conv window and SSM state carried in place)."""
+    from types import SimpleNamespace
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(7)
+    m = Mamba(32, layer_idx=0, bimamba_type="none").eval()
+    x = torch.randn(2, 70, 32)
+    with torch.no_grad():
+        full = m(x)
+        params = SimpleNamespace(key_value_memory_dict={}, seqlen_offset=0)
+        outs = [m(x[:, :65], inference_params=params)]
+        conv_state, ssm_state = params.key_value_memory_dict[0]
+        assert conv_state.shape == (2, 64, 4) and ssm_state.shape == (2, 64, 16)
+        for t in range(65, 70):
+            params.seqlen_offset = t
+            outs.append(m(x[:, t:t + 1], inference_params=params))
+        got = torch.cat(outs, dim=1)
+    assert rel_err(got.numpy(), full.numpy()) < 1e-4
+    c2, s2 = m.allocate_inference_cache(3, 128)
+    assert c2.shape == (3, 64, 4) and s2.shape == (3, 64, 16) and float(c2.abs().sum()) == 0
+    with pytest.raises(NotImplementedError):
+        Mamba(32, layer_idx=0, bimamba_type="v1")(x, inference_params=params)
