@@ -144,7 +144,9 @@ AUM_DEV void scanh_bwd_dir_state(float Araw, int n, const vf2 (&Bn)[4], vf Bn8, 
         DA8 = vfma(splat(Araw), h8, DA8);
         dB8 = vfma(g8, dlu8, dB8);
         dC8 = vfma(dy8, x8, dC8);
-        if (want_dA) dAv = vsel(lane_id() == n, splat(wave_sum(vfma(dl8, h8, lo2(dAl) + hi2(dAl)))), dAv);
+        // dA[e][n] = sum over the row: reduced inside each 16-lane row now (lane 16q + n keeps row q's share), the four
+        // shares are added once per row after the state loop (sum_rows4) -- no v_readlane chain per state
+        if (want_dA) dAv = vsel((lane_id() & 15) == n, row_sum16(vfma(dl8, h8, lo2(dAl) + hi2(dAl))), dAv);
     }
 }
 
@@ -295,8 +297,8 @@ AUM_DEV void scanh_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_per
             if (active && want_dA) {
                 const vm mn = lane < N;
                 const vi ln = vmin_i(lane, N - 1);
-                gstore(ws + L.pA + ((int64_t)b * p.dim + e) * N, ln, dAv0, mn);
-                if (BI) gstore(ws + L.pAb + ((int64_t)b * p.dim + e) * N, ln, dAv1, mn);
+                gstore(ws + L.pA + ((int64_t)b * p.dim + e) * N, ln, sum_rows4(dAv0), mn);
+                if (BI) gstore(ws + L.pAb + ((int64_t)b * p.dim + e) * N, ln, sum_rows4(dAv1), mn);
             }
             if (active && !(p.flags & AUM_DBG_SKIP_EPILOGUE)) {
                 const float Dn = p.D ? ndir * p.D[e] : 0.f;

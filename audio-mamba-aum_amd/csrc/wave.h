@@ -197,6 +197,12 @@ template <int CTRL> AUM_DEV vf dpp_mov(vf x, vf old) {
 template <int N> AUM_DEV vf dpp_row_shr(vf x, vf old) { return dpp_mov<0x110 + N>(x, old); }
 // lane i <- lane i+N of its row; lanes with (i%16)+N > 15 keep `old`
 template <int N> AUM_DEV vf dpp_row_shl(vf x, vf old) { return dpp_mov<0x100 + N>(x, old); }
+// lane i <- lane (i + N) mod 16 of its own 16-lane row (rotate right by N: every lane has a source)
+template <int N> AUM_DEV vf dpp_row_ror(vf x) { return dpp_mov<0x120 + N>(x, x); }
+// lane i <- lane src[i] (any lane): ds_bpermute_b32, one pass through the LDS crossbar, no LDS memory
+AUM_DEV vf lane_gather(vf x, vi src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, x)));
+}
 AUM_DEV vf dpp_wave_shr1(vf x, vf old) { return dpp_mov<0x138>(x, old); }  // lane i <- i-1, lane 0 keeps old
 AUM_DEV vf dpp_wave_shl1(vf x, vf old) { return dpp_mov<0x130>(x, old); }  // lane i <- i+1, lane 63 keeps old
 AUM_DEV float readlane(vf x, int lane) {
@@ -315,6 +321,8 @@ template <int N> inline vf dpp_row_shr(const vf& x, const vf& old) {
 template <int N> inline vf dpp_row_shl(const vf& x, const vf& old) {
     vf r; AUM_LANES r.v[l] = ((l & 15) + N <= 15) ? x.v[l + N] : old.v[l]; return r;
 }
+template <int N> inline vf dpp_row_ror(const vf& x) { vf r; AUM_LANES r.v[l] = x.v[(l & ~15) | ((l + N) & 15)]; return r; }
+inline vf lane_gather(const vf& x, const vi& src) { vf r; AUM_LANES r.v[l] = x.v[src.v[l] & (WAVE - 1)]; return r; }
 inline vf dpp_wave_shr1(const vf& x, const vf& old) { vf r; AUM_LANES r.v[l] = l >= 1 ? x.v[l - 1] : old.v[l]; return r; }
 inline vf dpp_wave_shl1(const vf& x, const vf& old) { vf r; AUM_LANES r.v[l] = l < WAVE - 1 ? x.v[l + 1] : old.v[l]; return r; }
 template <int N> inline vf dpp_row_shr(const vf& x, float old) { return dpp_row_shr<N>(x, splat(old)); }
@@ -343,6 +351,22 @@ AUM_DEV vf vsoftplus(vf x) {
     vf lg = vlog2(w) * LN2;
     vf r = vsel(d == 0.0f, e, lg * vdiv(e, vsel(d == 0.0f, splat(1.0f), d)));
     return vsel(x > 20.0f, x, r);
+}
+
+// Sum over each 16-lane row, result in every lane of the row: 4 DPP rotate-and-add steps.
+AUM_DEV vf row_sum16(vf x) {
+    x = x + dpp_row_ror<8>(x);
+    x = x + dpp_row_ror<4>(x);
+    x = x + dpp_row_ror<2>(x);
+    x = x + dpp_row_ror<1>(x);
+    return x;
+}
+// lane 16q + n holds the partial of 16-lane row q for item n (n = 0..15): sum the four q's, every lane gets its item's total
+AUM_DEV vf sum_rows4(vf x) {
+    const vi lane = lane_id();
+    x = x + lane_gather(x, (lane + 16) & (WAVE - 1));
+    x = x + lane_gather(x, (lane + 32) & (WAVE - 1));
+    return x;
 }
 
 // Sum over the 64 lanes, result wave-uniform.  4 DPP row steps + 3 cross-row v_readlane.
