@@ -206,9 +206,8 @@ AUM_DEV void scanh_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_per
                 scanh_row_read<T>(dp, p.len, dd, d8);
                 AUM_UNROLL
                 for (int i = 0; i < 4; ++i) {
-                    vf d0 = lo2(dd[i]) + bias, d1 = hi2(dd[i]) + bias;
-                    if (softplus) { d0 = vsoftplus(d0); d1 = vsoftplus(d1); }
-                    dl[i] = mk2(d0, d1);
+                    const vf2 dr = dd[i] + spl2(splat(bias));
+                    dl[i] = softplus ? vsoftplus2(dr) : dr;
                     dlu[i] = dl[i] * uu[i];
                     G[i] = spl2(splat(0.f));
                     DA[i] = spl2(splat(0.f));
@@ -227,18 +226,12 @@ AUM_DEV void scanh_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_per
                     vf z8, yp8, dz8;
                     scanh_row_read<T>(row_ptr<T>(p.z, (int64_t)b * p.z_bs + (int64_t)ec * p.z_ds), p.len, zz, z8);
                     scanh_row_read<T>(row_ptr<T>(p.out_pre, (int64_t)b * p.out_bs + (int64_t)ec * p.out_ds), p.len, yp, yp8);
+                    const vf2 one2 = spl2(splat(1.f));
                     AUM_UNROLL
                     for (int i = 0; i < 4; ++i) {
-                        vf r[2][2];
-                        AUM_UNROLL
-                        for (int h = 0; h < 2; ++h) {
-                            const vf zv = h ? hi2(zz[i]) : lo2(zz[i]), gv = h ? hi2(go[i]) : lo2(go[i]), yv = h ? hi2(yp[i]) : lo2(yp[i]);
-                            const vf sg = vsigmoid(zv);
-                            r[h][0] = gv * yv * sg * vfma(zv, splat(1.f) - sg, splat(1.f));
-                            r[h][1] = gv * zv * sg;
-                        }
-                        dzv[i] = mk2(r[0][0], r[1][0]);
-                        go[i] = mk2(r[0][1], r[1][1]);
+                        const vf2 sg = vsigmoid2(zz[i]);
+                        dzv[i] = go[i] * yp[i] * sg * vfma2(zz[i], one2 - sg, one2);
+                        go[i] = go[i] * zz[i] * sg;
                     }
                     const vf sg = vsigmoid(z8);
                     dz8 = go8 * yp8 * sg * vfma(z8, splat(1.f) - sg, splat(1.f));
@@ -312,8 +305,9 @@ AUM_DEV void scanh_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_per
                     duv[i] = vfma2(dl[i], G[i], dy[i] * spl2(splat(Dn)));
                     vf2 dd = vfma2(uu[i], G[i], DA[i]);
                     if (softplus) {
-                        const vf r0 = lo2(raw[i]) + bias, r1 = hi2(raw[i]) + bias;
-                        dd = mk2(vsel(r0 > 20.f, lo2(dd), lo2(dd) * vsigmoid(r0)), vsel(r1 > 20.f, hi2(dd), hi2(dd) * vsigmoid(r1)));
+                        const vf2 rw = raw[i] + spl2(splat(bias));
+                        const vf2 ds = dd * vsigmoid2(rw);
+                        dd = mk2(vsel(lo2(rw) > 20.f, lo2(dd), lo2(ds)), vsel(hi2(rw) > 20.f, hi2(dd), hi2(ds)));
                     }
                     ddv[i] = dd;
                     dDl = vfma2(dy[i], uu[i], dDl);

@@ -248,36 +248,32 @@ AUM_DEV void scanwg_load_rows(const void* u, int64_t u_bs, int64_t u_ds, const v
                               const float* delta_bias, bool softplus, int b, int e0, int dim, int base, int len,
                               const vi (&t)[K + TAIL], const vm (&valid)[K + TAIL], vf2 (&dl)[K + TAIL],
                               vf2 (&dlu)[K + TAIL], vf2& sumd) {
-    vf dls[SCAN_R][K + TAIL], dlus[SCAN_R][K + TAIL], sds[SCAN_R];
+    vf uus[SCAN_R][K + TAIL], dds[SCAN_R][K + TAIL];
+    float biases[SCAN_R];
+    bool rowoks[SCAN_R];
     AUM_UNROLL
     for (int r = 0; r < SCAN_R; ++r) {
         const int e = e0 + r;
-        const bool rowok = e < dim;
-        const int ec = rowok ? e : dim - 1;
+        rowoks[r] = e < dim;
+        const int ec = rowoks[r] ? e : dim - 1;
         const T* up = row_ptr<T>(u, (int64_t)b * u_bs + (int64_t)ec * u_ds);
         const T* dp = row_ptr<T>(delta, (int64_t)b * d_bs + (int64_t)ec * d_ds);
-        const float bias = delta_bias ? delta_bias[ec] : 0.f;
-        vf uu[K + TAIL], dd[K + TAIL];
-        scan_row_read<T, K, TAIL>(up, base, len, t, valid, uu);
-        scan_row_read<T, K, TAIL>(dp, base, len, t, valid, dd);
-        vf sd = splat(0.f);
-        AUM_UNROLL
-        for (int k = 0; k < K + TAIL; ++k) {
-            vf d = dd[k] + bias;
-            if (softplus) d = vsoftplus(d);
-            d = vsel(valid[k] && rowok, d, splat(0.f));
-            dls[r][k] = d;
-            dlus[r][k] = d * uu[k];
-            sd = sd + d;
-        }
-        sds[r] = sd;
+        biases[r] = delta_bias ? delta_bias[ec] : 0.f;
+        scan_row_read<T, K, TAIL>(up, base, len, t, valid, uus[r]);
+        scan_row_read<T, K, TAIL>(dp, base, len, t, valid, dds[r]);
     }
+    // the two rows are packed BEFORE the softplus so that its adds / multiplies / residual step run as v_pk_*
+    const vf2 bias2 = mk2(splat(biases[0]), splat(biases[1]));
+    sumd = spl2(splat(0.f));
     AUM_UNROLL
     for (int k = 0; k < K + TAIL; ++k) {
-        dl[k] = mk2(dls[0][k], dls[1][k]);
-        dlu[k] = mk2(dlus[0][k], dlus[1][k]);
+        vf2 d = mk2(dds[0][k], dds[1][k]) + bias2;
+        if (softplus) d = vsoftplus2(d);
+        d = mk2(vsel(valid[k] && rowoks[0], lo2(d), splat(0.f)), vsel(valid[k] && rowoks[1], hi2(d), splat(0.f)));
+        dl[k] = d;
+        dlu[k] = d * mk2(uus[0][k], uus[1][k]);
+        sumd = sumd + d;
     }
-    sumd = mk2(sds[0], sds[1]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -342,6 +342,14 @@ constexpr float LN2 = 0.6931471805599453f;
 AUM_DEV vf vexp(vf x) { return vexp2(x * LOG2E); }
 AUM_DEV vf vsigmoid(vf x) { return vrcp(splat(1.0f) + vexp2(x * (-LOG2E))); }
 
+// a / b from v_rcp_f32 plus one residual correction (4 instructions, <= 1 ulp here) instead of the ~11-instruction IEEE
+// expansion: the softplus below runs once per element in the prologue of every scan kernel
+AUM_DEV vf vdiv_nr(vf a, vf b) {
+    const vf r = vrcp(b);
+    const vf q = a * r;
+    return vfma(vfma(-q, b, a), r, q);
+}
+
 // torch softplus(beta=1, threshold=20) (SSI:106-107): x > 20 ? x : log1p(exp(x)), with an accurate
 // log1p for small exp(x) (log(1+e) * e / ((1+e) - 1), exact e when 1+e rounds to 1).
 AUM_DEV vf vsoftplus(vf x) {
@@ -349,8 +357,30 @@ AUM_DEV vf vsoftplus(vf x) {
     vf w = e + 1.0f;
     vf d = w - 1.0f;
     vf lg = vlog2(w) * LN2;
-    vf r = vsel(d == 0.0f, e, lg * vdiv(e, vsel(d == 0.0f, splat(1.0f), d)));
+    vf r = vsel(d == 0.0f, e, lg * vdiv_nr(e, vsel(d == 0.0f, splat(1.0f), d)));
     return vsel(x > 20.0f, x, r);
+}
+
+// Packed-pair forms of the two element-wise functions of the scan prologues/epilogues: the adds, multiplies and the
+// residual step run as v_pk_* on both halves, only v_exp_f32 / v_log_f32 / v_rcp_f32 and the selects stay per half.
+AUM_DEV vf2 vsigmoid2(vf2 x) {
+    const vf2 e = vexp2_2(x * spl2(splat(-LOG2E)));
+    const vf2 w = e + spl2(splat(1.0f));
+    return mk2(vrcp(lo2(w)), vrcp(hi2(w)));
+}
+AUM_DEV vf2 vsoftplus2(vf2 x) {
+    const vf2 one = spl2(splat(1.0f));
+    const vf2 e = vexp2_2(x * spl2(splat(LOG2E)));
+    const vf2 w = e + one;
+    const vf2 d = w - one;
+    const vf2 lg = mk2(vlog2(lo2(w)), vlog2(hi2(w))) * spl2(splat(LN2));
+    const vm z0 = lo2(d) == 0.0f, z1 = hi2(d) == 0.0f;
+    const vf2 ds = mk2(vsel(z0, splat(1.0f), lo2(d)), vsel(z1, splat(1.0f), hi2(d)));
+    const vf2 r = mk2(vrcp(lo2(ds)), vrcp(hi2(ds)));
+    const vf2 q = e * r;
+    const vf2 qq = vfma2(vfma2(spl2(splat(0.f)) - q, ds, e), r, q);
+    const vf2 v = lg * qq;
+    return mk2(vsel(lo2(x) > 20.0f, lo2(x), vsel(z0, lo2(e), lo2(v))), vsel(hi2(x) > 20.0f, hi2(x), vsel(z1, hi2(e), hi2(v))));
 }
 
 // Sum over each 16-lane row, result in every lane of the row: 4 DPP rotate-and-add steps.
