@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 def enable(local_rank=0, tuning=True):
     if os.environ.get("AUM_NO_TUNABLEOP") == "1":
         return None
-    src = os.path.join(_HERE, "tunableop_gfx950.csv")
+    src = os.environ.get("AUM_TUNABLEOP_CSV", os.path.join(_HERE, "tunableop_gfx950.csv"))
     d = os.path.join(tempfile.gettempdir(), f"aum_tunableop_{os.getuid()}_{os.getpid()}")
     os.makedirs(d, exist_ok=True)
     if os.path.exists(src):
