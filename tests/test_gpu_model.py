@@ -110,7 +110,8 @@ def test_base_block_full_size_gradient_consistency():
     assert abs(fd - an) <= 2e-2 * max(abs(an), 1e-3), (fd, an)
 
 
-def test_launcher_end_to_end_on_gpu(tmp_path):
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_launcher_end_to_end_on_gpu(tmp_path, precision):
     """aum.train on the real library: waveform workers -> GPU mel/SpecAug -> bf16 autocast model -> Adam -> validation."""
     import json
     import subprocess
@@ -125,7 +126,8 @@ def test_launcher_end_to_end_on_gpu(tmp_path):
     cmd = [sys.executable, "-m", "aum.train", "--model_type", "small", "--depth", "4", "--n_class", "6",
            "--label-csv", data + "/class_labels_indices.csv", "--data-train", data + "/train.json",
            "--data-val", data + "/val.json", "--audio_length", "256", "--num-workers", "2", "-b", "8", "--lr", "1e-3",
-           "--n-epochs", "2", "--freqm", "24", "--timem", "48", "--mixup", "0.5", "--exp-dir", exp]
+           "--n-epochs", "2", "--freqm", "24", "--timem", "48", "--mixup", "0.5", "--exp-dir", exp,
+           "--mixed_precision", precision]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     res = np.loadtxt(exp + "/result.csv", delimiter=",")
