@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from mamba_ssm.ops.selective_scan_interface import (bimamba_inner_fn, mamba_inner_fn, mamba_inner_fn_no_out_proj,
+from mamba_ssm.ops.selective_scan_interface import (InProjFn, bimamba_inner_fn, mamba_inner_fn, mamba_inner_fn_no_out_proj,
                                                     selective_scan_fn)
 from causal_conv1d import causal_conv1d_fn
 
@@ -92,7 +92,7 @@ class Mamba(nn.Module):
                 return out
         batch, seqlen, _ = hidden_states.shape
         # matmul + transpose in one GEMM: xz is (B, 2E, L) stored channel-major, like MS:185-189
-        xz = torch.matmul(self.in_proj.weight, hidden_states.reshape(batch * seqlen, -1).t())
+        xz = InProjFn.apply(self.in_proj.weight, hidden_states.reshape(batch * seqlen, -1))
         xz = xz.reshape(-1, batch, seqlen).permute(1, 0, 2)
         if self.in_proj.bias is not None:
             xz = xz + self.in_proj.bias.to(xz.dtype)[None, :, None]

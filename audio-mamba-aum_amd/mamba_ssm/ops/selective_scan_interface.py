@@ -119,6 +119,42 @@ def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
 # =================================================================================================
 # fused inner blocks  (SSI:155-633)
 # =================================================================================================
+def split_k_wgrad(a_mk, b_kn, splits):
+    """a_mk [M, K] @ b_kn [K, N] with a long K (= batch*len tokens) and a small [M, N] result: the weight-gradient GEMMs
+    of the in/out projections.  hipBLASLt's best single-GEMM solutions keep the matrix pipe 20-31 % busy on these shapes
+    (profiles/r01_mfma_busy.txt: 18-48 output tiles for 256 CUs); splitting K into `splits` batched GEMMs on strided
+    views (no copies) and summing the partial products in fp32 fills the chip.  AUM_WGRAD_SPLIT=0 restores the single GEMM."""
+    K = a_mk.shape[1]
+    if splits <= 1 or K % splits or K // splits < 1024 or os.environ.get("AUM_WGRAD_SPLIT", "1") == "0" or not a_mk.is_cuda:
+        return torch.matmul(a_mk, b_kn)
+    kc = K // splits
+    a3 = a_mk.unflatten(1, (splits, kc)).permute(1, 0, 2)          # [S, M, kc], strided view
+    b3 = b_kn.unflatten(0, (splits, kc))                            # [S, kc, N]
+    return torch.bmm(a3, b3).sum(0, dtype=torch.float32).to(a_mk.dtype)
+
+
+class InProjFn(torch.autograd.Function):
+    """xz2d [2E, B*L] = W [2E, D] @ hidden2d[B*L, D]^T (MS:185-189: matmul and BLH -> HBL transpose in one GEMM) with the
+    split-K weight gradient above; autocast casts both operands like F.linear would."""
+
+    @staticmethod
+    def forward(ctx, weight, hidden2d):
+        act = _autocast_dtype()
+        w = weight.to(act) if act is not None else weight
+        h = hidden2d.to(w.dtype)
+        ctx.save_for_backward(w, h)
+        ctx.wdtype, ctx.hdtype = weight.dtype, hidden2d.dtype
+        return torch.matmul(w, h.t())
+
+    @staticmethod
+    def backward(ctx, dxz2d):
+        w, h = ctx.saved_tensors
+        dxz2d = dxz2d.to(w.dtype)
+        dh = torch.matmul(dxz2d.t(), w) if ctx.needs_input_grad[1] else None
+        dw = split_k_wgrad(dxz2d, h, 4) if ctx.needs_input_grad[0] else None
+        return (None if dw is None else dw.to(ctx.wdtype)), (None if dh is None else dh.to(ctx.hdtype))
+
+
 def _dm2d(t):
     """(B, E, L) channel-major tensor -> its [E, B*L] 2-D view (no copy)."""
     Bsz, E, L = t.shape
@@ -211,7 +247,7 @@ def _inner_backward(ctx, dout):
     if ctx.has_out_proj:
         dout2 = dout.reshape(Bsz * L, -1).to(out_proj_weight.dtype)
         dout_z = torch.matmul(out_proj_weight.t(), dout2.t()).reshape(E, Bsz, L).permute(1, 0, 2)   # SSI:540
-        dout_proj_weight = torch.matmul(dout2.t(), _dm2d(out_z).t())                                 # SSI:563
+        dout_proj_weight = split_k_wgrad(dout2.t(), _dm2d(out_z).t(), 8)                             # SSI:563
         dout_proj_bias = dout2.sum(0) if not ctx.out_proj_bias_is_None else None
     else:
         dout_z = dout if dout.stride(-1) == 1 else dout.contiguous()

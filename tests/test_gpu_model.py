@@ -134,3 +134,31 @@ def test_launcher_end_to_end_on_gpu(tmp_path, precision):
     assert res.shape == (2, 8) and np.isfinite(res).all()
     assert res[1, 5] < res[0, 5], res[:, 5]                       # training loss goes down
     assert json.load(open(data + "/val.json"))["data"] and os.path.exists(exp + "/models/best_audio_model.pth")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_split_k_weight_gradients_match_single_gemm(dtype, monkeypatch):
+    """in/out projection weight gradients: batched split-K GEMMs + fp32 sum vs one GEMM (AUM_WGRAD_SPLIT=0)"""
+    from mamba_ssm.ops.selective_scan_interface import split_k_wgrad, InProjFn
+    torch.manual_seed(0)
+    BL, D, E2 = 16 * 513, 256, 1024
+    a = torch.randn(E2, BL, device=DEV).to(dtype)
+    h = torch.randn(BL, D, device=DEV).to(dtype)
+    ref = torch.matmul(a.double(), h.double())
+    for splits in (4, 8):
+        got = split_k_wgrad(a, h, splits)
+        assert got.dtype == dtype and rel_err(got.double().cpu().numpy(), ref.cpu().numpy()) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+    # strided (transposed) operands as in the out_proj call site
+    got = split_k_wgrad(h.t(), a.t(), 8)
+    assert rel_err(got.double().cpu().numpy(), ref.t().cpu().numpy()) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+    # autograd of InProjFn == autograd of the plain matmul
+    w = torch.randn(E2, D, device=DEV, dtype=dtype, requires_grad=True)
+    x = torch.randn(BL, D, device=DEV, dtype=dtype, requires_grad=True)
+    g = torch.randn(E2, BL, device=DEV, dtype=dtype)
+    InProjFn.apply(w, x).backward(g)
+    gw, gx = w.grad.clone(), x.grad.clone()
+    w.grad = x.grad = None
+    torch.matmul(w, x.t()).backward(g)
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel_err(gw.double().cpu().numpy(), w.grad.double().cpu().numpy()) < tol
+    assert rel_err(gx.double().cpu().numpy(), x.grad.double().cpu().numpy()) < tol
