@@ -123,7 +123,8 @@ def split_k_wgrad(a_mk, b_kn, splits):
     """a_mk [M, K] @ b_kn [K, N] with a long K (= batch*len tokens) and a small [M, N] result: the weight-gradient GEMMs
     of the in/out projections.  hipBLASLt's best single-GEMM solutions keep the matrix pipe 20-31 % busy on these shapes
     (profiles/r01_mfma_busy.txt: 18-48 output tiles for 256 CUs); splitting K into `splits` batched GEMMs on strided
-    views (no copies) and summing the partial products in fp32 fills the chip.  AUM_WGRAD_SPLIT=0 restores the single GEMM."""
+    views (no copies) and summing the partial products in fp32 fills the chip (sweep on one box, in/out splits: 4/8 85.0,
+    8/8 86.1, 16/8 85.5, 4/4 85.8, 4/16 85.4, 2/8 85.9 ms per step; single GEMMs 87.9).  AUM_WGRAD_SPLIT=0 restores the single GEMM."""
     K = a_mk.shape[1]
     if splits <= 1 or K % splits or K // splits < 1024 or os.environ.get("AUM_WGRAD_SPLIT", "1") == "0" or not a_mk.is_cuda:
         return torch.matmul(a_mk, b_kn)
