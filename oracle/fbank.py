@@ -10,6 +10,10 @@ PARITY UNPINNED: torchaudio 2.1.1 is a third-party dependency that is absent fro
 (25 ms frames, snip_edges, remove_dc_offset, preemphasis 0.97, round window to a power of two, power spectrum,
 low_freq 20 Hz, high_freq = Nyquist, triangular filters equally spaced on mel(f) = 1127 ln(1 + f/700) evaluated at the
 FFT bin centres 0..N/2-1 with the Nyquist bin weighted 0, log floor = float32 epsilon).
+
+Cross-check (tests/test_frontend.py::test_oracle_matches_transformers_kaldi_fbank): agrees to 6e-7 with the numpy Kaldi
+fbank of Hugging Face `transformers.audio_utils` (ASTFeatureExtractor's torchaudio-free path) -- an independent
+restatement, not the reference's torchaudio call, so the status above stands.
 """
 import numpy as np
 

@@ -55,3 +55,29 @@ def test_fbank_gpu():
     lib = aum_hip.get()
     _check(lib, "cuda", 160000, 1024, batch=4)   # the AudioSet clip: 998 frames padded to 1024
     _check(lib, "cuda", 16000 + 37, 120)
+
+
+def test_oracle_matches_transformers_kaldi_fbank():
+    """Independent cross-check of oracle/fbank.py: Hugging Face `transformers.audio_utils` carries a numpy implementation of
+    Kaldi's fbank (the fallback of ASTFeatureExtractor when torchaudio is missing, written to reproduce
+    torchaudio.compliance.kaldi.fbank with the arguments AST -- and the reference's dataloader -- use).  It is not the
+    reference's torchaudio call itself (absent here), so the oracle stays formally unpinned, but two independent
+    restatements of the published algorithm agree to float32 rounding."""
+    import warnings
+    au = pytest.importorskip("transformers.audio_utils")
+    rng = np.random.default_rng(3)
+    sr = 16000
+    t = np.arange(2 * sr) / sr
+    wave = 0.3 * np.sin(2 * np.pi * 523.0 * t) + 0.2 * np.sin(2 * np.pi * 3111.0 * t + 1.0) + 0.05 * rng.standard_normal(len(t))
+    wave = (wave - wave.mean()).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mel_filters = au.mel_filter_bank(num_frequency_bins=257, num_mel_filters=128, min_frequency=20, max_frequency=sr // 2,
+                                         sampling_rate=sr, norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+    window = au.window_function(400, "hann", periodic=False)
+    ref = au.spectrogram(wave, window, frame_length=400, hop_length=160, fft_length=512, power=2.0, center=False,
+                         preemphasis=0.97, mel_filters=mel_filters, log_mel="log", mel_floor=1.192092955078125e-07,
+                         remove_dc_offset=True).T
+    mine = OF.fbank(wave.astype(np.float64))
+    assert mine.shape == ref.shape == (198, 128)
+    assert np.abs(mine - ref).max() < 2e-5
