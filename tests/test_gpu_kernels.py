@@ -122,3 +122,27 @@ def test_proj_full_size(lib):
     """AuM-Base block: d_inner 1536, dt_rank 48, d_state 16, 64 clips x 513 tokens (513 token tiles, 11 token splits)"""
     KC.check_proj(lib, "cuda", ("base_full", 1536, 48, 16, 64, 513), torch.bfloat16)
     KC.check_proj(lib, "cuda", ("base_b3", 1536, 48, 16, 3, 513), torch.bfloat16)        # ntok = 1539: ragged everything
+
+
+def test_scan_backward_bitwise_repeatable(lib):
+    """no atomics anywhere in the scan path (partials + a fixed-order reduce): the same launch gives the same bits, and a
+    read-add-write race between waves of the 12/16-wave workgroups would show up here as a flipped bit sooner or later"""
+    torch.manual_seed(0)
+    Bsz, E, L, N = 4, 384, 513, 16
+    dt = torch.bfloat16
+    mk = lambda: torch.randn(E, Bsz, L, device="cuda").to(dt).permute(1, 0, 2)
+    u, z, dout = mk(), mk(), mk()
+    delta = (0.5 * torch.randn(E, Bsz, L, device="cuda")).to(dt).permute(1, 0, 2)
+    Bm, Cm = torch.randn(Bsz, 1, N, L, device="cuda").to(dt), torch.randn(Bsz, 1, N, L, device="cuda").to(dt)
+    A = -torch.arange(1, N + 1, device="cuda", dtype=torch.float32).repeat(E, 1)
+    D, bias = torch.ones(E, device="cuda"), torch.full((E,), -4.0, device="cuda")
+    for A_b in (A * 1.05, None):
+        _, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, lib=lib)
+        ref = None
+        for it in range(5):
+            g = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, A_b=A_b, lib=lib)
+            cur = {k: v.clone() for k, v in g.items() if v is not None}
+            if ref is None:
+                ref = cur
+            for k in ref:
+                assert torch.equal(ref[k], cur[k]), (it, k)
