@@ -15,19 +15,19 @@ from aum.model import build_aum  # noqa: E402
 from aum.frontend import FbankTables, wav2fbank  # noqa: E402
 
 
-def run(size, btype, train, batch=64, steps=6, warm=3):
+def run(size, btype, train, batch=64, steps=6, warm=3, frames=1024):
     dev = torch.device("cuda")
     torch.manual_seed(0)
-    model = build_aum(size, depth=24, num_classes=527, bimamba_type=btype).to(dev)
+    model = build_aum(size, depth=24, num_classes=527, bimamba_type=btype, spectrogram_size=(128, frames)).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
     tabs = FbankTables(dev)
-    wave = (torch.randn(batch, 160000, device=dev) * 0.1).clamp_(-1, 1)
+    wave = (torch.randn(batch, 400 + (frames - 1) * 160 if frames != 1024 else 160000, device=dev) * 0.1).clamp_(-1, 1)
     y = torch.zeros(batch, 527, device=dev)
     y[:, :2] = 1
     loss_fn = torch.nn.BCEWithLogitsLoss()
 
     def step():
-        x = wav2fbank(wave, tabs, target_length=1024)
+        x = wav2fbank(wave, tabs, target_length=frames)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             if train:
                 loss = loss_fn(model(x).float(), y)
@@ -48,7 +48,7 @@ def run(size, btype, train, batch=64, steps=6, warm=3):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     r = {"size": size, "block": {"v1": "Fo-Bi", "v2": "Bi-Bi", "none": "Fo-Fo"}[btype], "mode": "train" if train else "inference",
-         "batch": batch, "ms_per_step": round(dt * 1e3, 2), "clips_per_s": round(batch / dt, 1),
+         "frames": frames, "tokens": model.num_patches + 1, "batch": batch, "ms_per_step": round(dt * 1e3, 2), "clips_per_s": round(batch / dt, 1),
          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
     print(json.dumps(r), flush=True)
     del model, opt
@@ -59,6 +59,7 @@ def run(size, btype, train, batch=64, steps=6, warm=3):
 
 if __name__ == "__main__":
     out = [run("base", "v1", True), run("base", "v1", False), run("base", "v2", True), run("base", "none", True),
-           run("small", "v1", True), run("tiny", "v1", True), run("base", "v1", True, batch=256, steps=3, warm=2)]
+           run("small", "v1", True), run("tiny", "v1", True), run("base", "v1", True, batch=256, steps=3, warm=2),
+           run("base", "v1", True, batch=8, steps=4, warm=2, frames=8192)]      # long-form: L = 4097, chunked scans
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "variants_bench.json"), "w"), indent=1)
