@@ -197,9 +197,9 @@ def main():
         if os.path.exists(pmc):
             roof["traffic"] = json.load(open(pmc)).get(dom)     # HBM bytes per launch from FETCH_SIZE/WRITE_SIZE passes
         if dom.startswith("scan"):
-            roof["note"] = ("VALU-bound kernel (16 states x 2 directions x v_exp_f32 per element): SQ_ACTIVE_INST_VALU shows the "
-                            "vector ALU 72-97% busy (profiles/r01_pmc), so the HBM fraction is bounded near 0.1 by arithmetic; "
-                            "see DESIGN.md 4.1")
+            roof["note"] = ("VALU-bound kernel (16 states x 2 directions x v_exp_f32 per element, ~6100 vector instructions per "
+                            "513-step row): SQ_ACTIVE_INST_VALU shows the vector ALU 74% (backward) / 77% (forward) busy "
+                            "(profiles/r01_valu_busy.txt), so the HBM fraction is bounded near 0.1 by arithmetic; see DESIGN.md 4.1")
         out = {
             "metric": "clips/sec/node AuM-Base 128x1024 fwd+bwd", "value": round(clips / elapsed, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
