@@ -196,6 +196,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             roof["traffic"] = json.load(open(pmc)).get(dom)     # HBM bytes per launch from FETCH_SIZE/WRITE_SIZE passes
+        vb = os.path.join(ROOT, "profiles", "valu_busy.json")
+        if os.path.exists(vb) and dom in json.load(open(vb)):
+            roof["valu"] = json.load(open(vb))[dom]             # vector-ALU occupancy of the same kernel (SQ PMC pass)
         if dom.startswith("scan"):
             roof["note"] = ("VALU-bound kernel (16 states x 2 directions x v_exp_f32 per element, ~6100 vector instructions per "
                             "513-step row): SQ_ACTIVE_INST_VALU shows the vector ALU 74% (backward) / 77% (forward) busy "
