@@ -104,12 +104,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()       # identity on a full node; lets 2 ranks share one GPU in a dry run
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm (xGMI within the node)
+        backend = os.environ.get("AUM_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm (xGMI within the node); gloo = dry run
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     aum_hip.get()      # fail loudly now if the HIP extension is missing
 
     torch.manual_seed(3949 + rank)
@@ -120,7 +125,7 @@ def main():
                            fused=True)                                         # TT:32-34
     net = model
     if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True,
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], gradient_as_bucket_view=True,
                                                         bucket_cap_mb=64, broadcast_buffers=False)
     loss_fn = torch.nn.BCEWithLogitsLoss()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
