@@ -120,11 +120,13 @@ class Dist:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.cuda = torch.cuda.is_available()
-        self.device = torch.device("cuda", self.local_rank) if self.cuda else torch.device("cpu")
+        # device index modulo + AUM_DIST_BACKEND=gloo: dry run of the multi-rank path on a box with fewer GPUs than ranks
+        self.dev_index = self.local_rank % torch.cuda.device_count() if self.cuda else 0
+        self.device = torch.device("cuda", self.dev_index) if self.cuda else torch.device("cpu")
         if self.cuda:
             torch.cuda.set_device(self.device)
         if self.world > 1 and not dist.is_initialized():
-            dist.init_process_group("nccl" if self.cuda else "gloo")
+            dist.init_process_group(os.environ.get("AUM_DIST_BACKEND", "nccl" if self.cuda else "gloo"))
         self.main = self.rank == 0
 
     def print(self, *a):
@@ -278,7 +280,7 @@ def train(model, train_loader, val_loader, args, D):
         optimizer.load_state_dict(torch.load(args.optim_path, map_location="cpu"))
     net = model
     if D.world > 1:
-        net = nn.parallel.DistributedDataParallel(model, device_ids=[D.local_rank] if D.cuda else None,
+        net = nn.parallel.DistributedDataParallel(model, device_ids=[D.dev_index] if D.cuda else None,
                                                   gradient_as_bucket_view=True, static_graph=True, bucket_cap_mb=100)
     scaler = torch.amp.GradScaler("cuda", enabled=(args.mixed_precision == "fp16" and D.cuda))
     scheduler = torch.optim.lr_scheduler.MultiStepLR(
