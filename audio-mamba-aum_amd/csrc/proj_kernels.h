@@ -37,10 +37,13 @@ constexpr int PJ_WPITCH = 72;     // weight-slice row pitch in LDS (144 B: 16-by
 constexpr int PJ_FPITCH = 68;     // fp32 scratch row pitch (floats) of the data-gradient epilogue
 constexpr int PJ_WSTAGE = 16 * PJ_MAXRB * PJ_WPITCH;            // one weight-slice buffer (80 rows x 64 channels)
 constexpr int PJ_LDS_ELEMS = 2 * PJ_STAGE + 2 * PJ_WSTAGE + PJ_XROWS * PJ_PITCH;   // 53.5 KB per workgroup
-constexpr int PJW_KS = 32;      // tokens per MFMA step of the weight-gradient kernel
-constexpr int PJW_NW = 4;        // wavefronts per workgroup of the weight-gradient kernel (split over tokens)
-constexpr int PJW_EB = 4;        // 16-row channel blocks per workgroup
-constexpr int PJW_LDS_FLOATS = PJW_NW * PJW_EB * PJ_MAXRB * 4 * WAVE;
+constexpr int PJW_KS = 64;      // tokens per step of the weight-gradient kernel (two MFMA k-extents: full 128-byte lines per row)
+constexpr int PJW_NW = 4;        // wavefronts per workgroup of the weight-gradient kernel (each owns 64 channel rows)
+constexpr int PJW_EB = 2;        // 16-row channel blocks per wavefront
+constexpr int PJW_ROWS = PJW_NW * PJW_EB * 16;                 // 256 channel rows per workgroup
+constexpr int PJW_YPITCH = 72;                                 // y-slice row pitch in LDS (144 B: 16-byte aligned rows, conflict-free b128 reads)
+constexpr int PJW_YSTAGE = 16 * PJ_MAXRB * PJW_YPITCH;          // one y-slice buffer (80 rows x 64 tokens)
+constexpr int PJW_LDS_ELEMS = 2 * PJW_YSTAGE;                  // 23 KB per workgroup
 
 #ifndef AUM_EMU
 typedef short s8v __attribute__((ext_vector_type(8)));
@@ -360,7 +363,7 @@ AUM_DEV void pj_reduce_channels(const T* act, int64_t ntok, int dim, int tok0, c
             if (C2) pj_w_load<T, NCB>(wmat, dim, ((KS) + 2) * PJ_KS, ncols, w, wr[AUM_W(w)]);                      \
             pj_mma<T, NCB>(stage + cb_ * PJ_STAGE, wstage + cb_ * PJ_WSTAGE, w, acc[AUM_W(w)]);                    \
         }                                                                                                          \
-        AUM_WG_BARRIER();
+        AUM_WG_BARRIER_LDS();
     int ks = 0;
     for (; ks + 6 <= nks; ks += 2) {
         PJ_STEP(ks, sa, true, true, true)
@@ -570,95 +573,139 @@ template <class T, int NDB, int NRC> AUM_DEV void proj_bwd_data_wg(const AumProj
 }
 
 // ---- backward, weights: out[e][r] (or out[r][e]) = sum_t X[e][t] * Y[r][t], split over tokens ------------------------
-// One workgroup = 64 channel rows x one token range, its 4 wavefronts take quarters of the range and meet in LDS.
+// One workgroup = 256 channel rows (4 waves x 4 sixteen-row blocks) x one token range.  Per 32-token step the y slice
+// ([<= 80 rows][32 tokens], the operand every channel block needs) is loaded ONCE per workgroup into a double-buffered LDS
+// tile and read as fragments by all four waves (per-wave y fragments from L1/L2 were 126 MB of extra L2 traffic next to
+// the 100 MB x stream); the x fragments of a wave (its own rows, 8 consecutive tokens per lane) come straight from
+// global memory, two steps ahead in ping-pong register sets.  One barrier per step, one fp32 partial per workgroup.
+template <class T> AUM_DEV void pjw_y_load(const T* Y, int64_t ntok, int nr, int64_t t0, int64_t t_end, int w, frag8 (&yr)[3]) {
+    const vi lane = lane_id();
+    AUM_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        const int qbase = w * 64 + 256 * i;                     // lane-load q: row q>>3, tokens 8*(q&7)..+7 of the step
+        yr[i] = frag_zero();
+        if (qbase < 16 * PJ_MAXRB * 8) {
+            const vi q = lane + qbase;
+            const vi row = q >> 3;
+            const vi n = clamp_i(spl_i((int)(t_end - t0)) - (q & 7) * 8, 0, 8);
+            if (t0 + PJW_KS <= t_end) yr[i] = gload_frag_n(Y + t0, vmin_i(row, nr - 1) * (int)ntok + (q & 7) * 8, vsel_i(row < nr, spl_i(8), spl_i(0)));
+            else yr[i] = gload_frag_n(Y + t0, vmin_i(row, nr - 1) * (int)ntok + (q & 7) * 8, vsel_i(row < nr, n, spl_i(0)));
+        }
+    }
+}
+AUM_DEV void pjw_y_store(uint16_t* ybuf, int w, const frag8 (&yr)[3]) {
+    const vi lane = lane_id();
+    AUM_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        const int qbase = w * 64 + 256 * i;
+        if (qbase < 16 * PJ_MAXRB * 8) {
+            const vi q = lane + qbase;
+            lds16_write8_a(ybuf, (q >> 3) * PJW_YPITCH + (q & 7) * 8, yr[i]);
+        }
+    }
+}
+template <class T> AUM_DEV void pjw_x_load(const T* xb, int64_t ntok, int rows_left, int64_t t0, int64_t t_end, frag8 (&xa)[2 * PJW_EB]) {
+    const vi lane = lane_id();
+    const vi t16 = lane & 15, g = lane >> 4;
+    AUM_UNROLL
+    for (int eb = 0; eb < PJW_EB; ++eb) {
+        AUM_UNROLL
+        for (int c = 0; c < 2; ++c) {                       // the two 32-token k-extents of the step: together one 128-byte line per row
+            xa[2 * eb + c] = frag_zero();
+            if (eb * 16 < rows_left) {
+                const vi off = (eb * 16 + t16) * (int)ntok + g * 8 + 32 * c;
+                if (t0 + PJW_KS <= t_end) xa[2 * eb + c] = gload_frag(xb + t0, off);
+                else xa[2 * eb + c] = gload_frag_n(xb + t0, off, clamp_i(spl_i((int)(t_end - t0)) - g * 8 - 32 * c, 0, 8));
+            }
+        }
+    }
+}
 template <class T>
-AUM_DEV void proj_bwd_weight_wg(const AumProjWArgs& p, int chunk, int wg, float* lds) {
+AUM_DEV void proj_bwd_weight_wg(const AumProjWArgs& p, int chunk, int wg, uint16_t* lds) {
     const int64_t ntok = p.ntok;
-    const int nec = p.dim / (16 * PJW_EB);
+    const int nec = (p.dim + PJW_ROWS - 1) / PJW_ROWS;
     const int ec = wg % nec, split = wg / nec;
     const int nr = p.nrows, nrb = (nr + 15) / 16;
     const T* X = static_cast<const T*>(p.x);
     const T* Y = static_cast<const T*>(p.y);
+    const int64_t t_begin = (int64_t)split * chunk;
+    const int64_t t_end = t_begin + chunk < ntok ? t_begin + chunk : ntok;
+    const int nsteps = t_begin < t_end ? (int)((t_end - t_begin + PJW_KS - 1) / PJW_KS) : 0;
+    acc4 acc[AUM_PER_WAVE(PJW_NW)][PJW_EB][PJ_MAXRB];
+    frag8 xa[AUM_PER_WAVE(PJW_NW)][2 * PJW_EB], xb2[AUM_PER_WAVE(PJW_NW)][2 * PJW_EB];
+    frag8 yr[AUM_PER_WAVE(PJW_NW)][3];
     AUM_FOR_EACH_WAVE(w, PJW_NW) {
-        const vi lane = lane_id();
-        const vi t16 = lane & 15, g = lane >> 4;
-        const int64_t t_begin = (int64_t)(split * PJW_NW + w) * chunk;
-        const int64_t t_end = t_begin + chunk < ntok ? t_begin + chunk : ntok;
-        acc4 acc[PJW_EB][PJ_MAXRB];
+        const int row0 = ec * PJW_ROWS + w * 16 * PJW_EB;          // this wave's first channel
+        const T* xb = X + (int64_t)(row0 < p.dim ? row0 : 0) * ntok;
+        const int rows_left = p.dim - row0;
         AUM_UNROLL
         for (int eb = 0; eb < PJW_EB; ++eb)
             AUM_UNROLL
-            for (int rb = 0; rb < PJ_MAXRB; ++rb) acc[eb][rb] = acc_zero();
-        const T* xb = X + (int64_t)ec * 16 * PJW_EB * ntok;
-        frag8 a0[PJW_EB], b0[PJ_MAXRB], a1[PJW_EB], b1[PJ_MAXRB];
-        // a step whose 32 tokens all exist takes plain vector loads (rows of y clamped: accumulator columns >= nrows are
-        // never stored); only the last step of a range can be ragged and takes the masked loads
-#define PJW_LOAD(A, B, T0)                                                                                     \
-        {                                                                                                      \
-            const int64_t t_ = (T0);                                                                           \
-            if (t_ + PJW_KS <= t_end) {                                                                        \
-                AUM_UNROLL                                                                                     \
-                for (int eb = 0; eb < PJW_EB; ++eb) A[eb] = gload_frag(xb + t_, (eb * 16 + t16) * (int)ntok + g * 8); \
-                AUM_UNROLL                                                                                     \
-                for (int rb = 0; rb < PJ_MAXRB; ++rb)                                                          \
-                    B[rb] = rb < nrb ? gload_frag(Y + t_, vmin_i(rb * 16 + t16, nr - 1) * (int)ntok + g * 8) : frag_zero(); \
-            } else {                                                                                           \
-                const vi n_ = clamp_i(spl_i((int)(t_end - t_)) - g * 8, 0, 8);                                 \
-                AUM_UNROLL                                                                                     \
-                for (int eb = 0; eb < PJW_EB; ++eb) A[eb] = gload_frag_n(xb + t_, (eb * 16 + t16) * (int)ntok + g * 8, n_); \
-                AUM_UNROLL                                                                                     \
-                for (int rb = 0; rb < PJ_MAXRB; ++rb)                                                          \
-                    B[rb] = rb < nrb ? gload_frag_n(Y + t_, vmin_i(rb * 16 + t16, nr - 1) * (int)ntok + g * 8, n_) : frag_zero(); \
-            }                                                                                                  \
-        }
-#define PJW_MMA(A, B)                                                                                          \
-        AUM_UNROLL                                                                                             \
-        for (int rb = 0; rb < PJ_MAXRB; ++rb)                                                                  \
-            if (rb < nrb) {                                                                                    \
-                AUM_UNROLL                                                                                     \
-                for (int eb = 0; eb < PJW_EB; ++eb) acc[eb][rb] = mfma16(T{}, A[eb], B[rb], acc[eb][rb]);      \
-            }
-        if (t_begin < t_end) {
-            PJW_LOAD(a0, b0, t_begin)
-            for (int64_t t = t_begin; t < t_end; t += 2 * PJW_KS) {
-                if (t + PJW_KS < t_end) PJW_LOAD(a1, b1, t + PJW_KS)
-                PJW_MMA(a0, b0)
-                if (t + PJW_KS < t_end) {
-                    if (t + 2 * PJW_KS < t_end) PJW_LOAD(a0, b0, t + 2 * PJW_KS)
-                    PJW_MMA(a1, b1)
-                }
+            for (int rb = 0; rb < PJ_MAXRB; ++rb) acc[AUM_W(w)][eb][rb] = acc_zero();
+        if (nsteps > 0) {
+            pjw_y_load(Y, ntok, nr, t_begin, t_end, w, yr[AUM_W(w)]);
+            pjw_y_store(lds, w, yr[AUM_W(w)]);
+            pjw_x_load(xb, ntok, rows_left, t_begin, t_end, xa[AUM_W(w)]);
+            if (nsteps > 1) {
+                pjw_y_load(Y, ntok, nr, t_begin + PJW_KS, t_end, w, yr[AUM_W(w)]);
+                pjw_x_load(xb, ntok, rows_left, t_begin + PJW_KS, t_end, xb2[AUM_W(w)]);
             }
         }
-#undef PJW_LOAD
-#undef PJW_MMA
-        float* mine = lds + w * (PJW_EB * PJ_MAXRB * 4 * WAVE);
-        AUM_UNROLL
-        for (int eb = 0; eb < PJW_EB; ++eb)
-            AUM_UNROLL
-            for (int rb = 0; rb < PJ_MAXRB; ++rb)
-                AUM_UNROLL
-                for (int q = 0; q < 4; ++q) lds_write(mine, lane + ((eb * PJ_MAXRB + rb) * 4 + q) * WAVE, acc_get(acc[eb][rb], q));
     }
     AUM_WG_BARRIER();
+    // step KS: publish y(KS+1), fetch y(KS+2) and x(KS+2) (into the x set used at KS), multiply x(KS) with y(KS) from LDS
+#define PJW_STEP(KS, XCUR)                                                                                           \
+    AUM_FOR_EACH_WAVE(w, PJW_NW) {                                                                                   \
+        const vi lane = lane_id();                                                                                   \
+        const vi t16 = lane & 15, g = lane >> 4;                                                                     \
+        const int row0 = ec * PJW_ROWS + w * 16 * PJW_EB;                                                            \
+        const T* xb = X + (int64_t)(row0 < p.dim ? row0 : 0) * ntok;                                                 \
+        const int rows_left = p.dim - row0;                                                                          \
+        const uint16_t* ycur = lds + ((KS) & 1) * PJW_YSTAGE;                                                        \
+        if ((KS) + 1 < nsteps) pjw_y_store(lds + (((KS) + 1) & 1) * PJW_YSTAGE, w, yr[AUM_W(w)]);                    \
+        frag8 xc[2 * PJW_EB];                                                                                        \
+        AUM_UNROLL                                                                                                   \
+        for (int eb = 0; eb < 2 * PJW_EB; ++eb) xc[eb] = XCUR[AUM_W(w)][eb];                                         \
+        if ((KS) + 2 < nsteps) {                                                                                     \
+            pjw_y_load(Y, ntok, nr, t_begin + (int64_t)((KS) + 2) * PJW_KS, t_end, w, yr[AUM_W(w)]);                 \
+            pjw_x_load(xb, ntok, rows_left, t_begin + (int64_t)((KS) + 2) * PJW_KS, t_end, XCUR[AUM_W(w)]);          \
+        }                                                                                                            \
+        AUM_UNROLL                                                                                                   \
+        for (int rb = 0; rb < PJ_MAXRB; ++rb) {                                                                      \
+            if (rb < nrb) {                                                                                          \
+                const frag8 y0 = lds16_read8_a(ycur, (t16 + rb * 16) * PJW_YPITCH + g * 8);                          \
+                const frag8 y1 = lds16_read8_a(ycur, (t16 + rb * 16) * PJW_YPITCH + g * 8 + 32);                     \
+                AUM_UNROLL                                                                                           \
+                for (int eb = 0; eb < PJW_EB; ++eb) {                                                                \
+                    acc[AUM_W(w)][eb][rb] = mfma16(T{}, xc[2 * eb], y0, acc[AUM_W(w)][eb][rb]);                      \
+                    acc[AUM_W(w)][eb][rb] = mfma16(T{}, xc[2 * eb + 1], y1, acc[AUM_W(w)][eb][rb]);                  \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+    }                                                                                                                \
+    AUM_WG_BARRIER_LDS();
+    for (int ks = 0; ks < nsteps; ks += 2) {
+        PJW_STEP(ks, xa)
+        if (ks + 1 < nsteps) { PJW_STEP(ks + 1, xb2) }
+    }
+#undef PJW_STEP
     AUM_FOR_EACH_WAVE(w, PJW_NW) {
-        // wave w sums channel block eb = w over the 4 partial sets and writes this split's partial result
         const vi lane = lane_id();
         const vi t16 = lane & 15, g = lane >> 4;
         float* outp = p.out + (int64_t)split * p.dim * nr;
-        const int eb = w;
+        const int row0 = ec * PJW_ROWS + w * 16 * PJW_EB;
         AUM_UNROLL
-        for (int rb = 0; rb < PJ_MAXRB; ++rb) {
-            if (rb < nrb) {
-                const vi r = rb * 16 + t16;
-                AUM_UNROLL
-                for (int q = 0; q < 4; ++q) {
-                    vf s = splat(0.f);
+        for (int eb = 0; eb < PJW_EB; ++eb) {
+            AUM_UNROLL
+            for (int rb = 0; rb < PJ_MAXRB; ++rb) {
+                if (rb < nrb && row0 + eb * 16 < p.dim) {
+                    const vi r = t16 + rb * 16;
                     AUM_UNROLL
-                    for (int ww = 0; ww < PJW_NW; ++ww)
-                        s = s + lds_read(lds + ww * (PJW_EB * PJ_MAXRB * 4 * WAVE), lane + ((eb * PJ_MAXRB + rb) * 4 + q) * WAVE);
-                    const vi e = (ec * PJW_EB + eb) * 16 + g * 4 + q;     // D row = channel, D col = r
-                    const vi idx = p.transpose_out ? r * p.dim + e : e * nr + r;
-                    gstore(outp, vsel_i(r < nr, idx, spl_i(0)), s, r < nr);
+                    for (int q = 0; q < 4; ++q) {
+                        const vi e = g * 4 + (row0 + eb * 16 + q);        // D row = channel, D col = r
+                        const vi idx = p.transpose_out ? r * p.dim + e : e * nr + r;
+                        gstore(outp, vsel_i(r < nr, idx, spl_i(0)), acc_get(acc[AUM_W(w)][eb][rb], q), r < nr);
+                    }
                 }
             }
         }

@@ -81,6 +81,11 @@ AUM_DEV int wave_in_wg() { return __builtin_amdgcn_readfirstlane((int)(threadIdx
 // build runs the waves of a phase one after another, where it is a no-op: sequential execution is one legal schedule,
 // so arithmetic is checked there while race-freedom under concurrency is argued at the call site and checked on the GPU.
 #define AUM_WG_BARRIER_IN_PHASE() __syncthreads()
+// Workgroup barrier that only orders LDS traffic: wait for this wave's LDS operations, then s_barrier.  __syncthreads()
+// is a release/acquire fence pair around the barrier and therefore also drains vmcnt -- every global load a wave has
+// prefetched for a LATER step is waited for at each step's barrier, which serialises software-pipelined K loops on
+// memory latency.  Use only where the data exchanged between the waves lives in LDS.
+#define AUM_WG_BARRIER_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 // Per-wave state that must survive from one phase to the next (registers on the device): declare `T name[AUM_PER_WAVE(NW)]...`
 // and index it with AUM_W(w).  One slot on the device; the lane-array build keeps a slot per wave it steps through.
 #define AUM_PER_WAVE(NW) 1
@@ -310,6 +315,7 @@ inline void lds_atomic_add(float* lds, const vi& idx, const vf& v) { AUM_LANES l
 #define AUM_FOR_EACH_WAVE(w, NW) for (int w = 0; w < (NW); ++w)
 #define AUM_WG_BARRIER() do { } while (0)
 #define AUM_WG_BARRIER_IN_PHASE() do { } while (0)
+#define AUM_WG_BARRIER_LDS() do { } while (0)
 #define AUM_PER_WAVE(NW) (NW)
 #define AUM_W(w) (w)
 inline void wave_sync() {}
