@@ -209,16 +209,19 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
             Cm = Cm + C_proj_bias.to(Cm.dtype)
         Bm = Bm.reshape(Bsz, L, N).transpose(1, 2).contiguous()                              # SSI:479  (B, N, L)
         Cm = Cm.reshape(Bsz, L, N).transpose(1, 2).contiguous()
+    # the pre-gate sum is only needed by the backward: skipped (one 2-byte write per element and layer) when no input of
+    # this call requires a gradient, i.e. in inference
+    need_bwd = any(ctx.needs_input_grad)
     bidir_fused = A_b is not None and L <= aum_hip.get().max_single_pass_len
     if A_b is None or bidir_fused:
         out_z, out_pre, _ = aum_hip.scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, reverse,
-                                             A_b=A_b, want_out_pre=True, dmajor=True)        # SSI:499-507, one launch
+                                             A_b=A_b, want_out_pre=need_bwd, dmajor=True)        # SSI:499-507, one launch
         out_pre_b = None
     else:   # long rows: two reverse-flag launches, still no flip copies
         of, out_pre, _ = aum_hip.scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, False,
-                                          want_out_pre=True, dmajor=True)
+                                          want_out_pre=need_bwd, dmajor=True)
         ob, out_pre_b, _ = aum_hip.scan_fwd(conv_out, delta, A_b, Bm, Cm, D, z, delta_bias, delta_softplus, True,
-                                            want_out_pre=True, dmajor=True)
+                                            want_out_pre=need_bwd, dmajor=True)
         out_z = of + ob
     ctx.delta_softplus, ctx.reverse, ctx.bidir_fused = delta_softplus, reverse, bidir_fused
     ctx.has_out_proj = out_proj_weight is not None
