@@ -21,7 +21,9 @@ def enable(local_rank=0, tuning=True):
     d = os.path.join(tempfile.gettempdir(), f"aum_tunableop_{os.getuid()}_{os.getpid()}")
     os.makedirs(d, exist_ok=True)
     if os.path.exists(src):
-        shutil.copyfile(src, os.path.join(d, f"results{local_rank}.csv"))
+        # ordinal = local rank on a full node, 0 when the launcher masks each rank to one visible device
+        for ordinal in {0, local_rank}:
+            shutil.copyfile(src, os.path.join(d, f"results{ordinal}.csv"))
     os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
     os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1" if tuning else "0")
     os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(d, "results.csv"))
