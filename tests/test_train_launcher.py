@@ -226,3 +226,30 @@ def test_launcher_two_ranks_gloo(toy_dataset, tmp_path):
     assert np.loadtxt(exp + "/predictions/target.csv", delimiter=",").shape == (6, 4)    # 6 clips over 2 ranks, all kept
     sd = torch.load(exp + "/models/best_audio_model.pth")
     assert all(k.startswith("module.") for k in sd)                          # what the reference's DDP runs save
+
+
+def test_tunableop_solution_file_is_seeded_per_rank(monkeypatch, tmp_path):
+    """aum.tunable.enable: the recorded GEMM solutions are copied where TunableOp looks for them (file name + device
+    ordinal) for this rank's ordinal and for ordinal 0 (ranks masked to one visible device); env defaults are not
+    overridden when the user already set them; AUM_NO_TUNABLEOP=1 turns the whole thing off."""
+    from aum import tunable
+    for k in ("PYTORCH_TUNABLEOP_ENABLED", "PYTORCH_TUNABLEOP_TUNING", "PYTORCH_TUNABLEOP_FILENAME",
+              "PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS", "PYTORCH_TUNABLEOP_VERBOSE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    import tempfile
+    monkeypatch.setattr(tempfile, "tempdir", None)
+    monkeypatch.setenv("AUM_NO_TUNABLEOP", "1")
+    assert tunable.enable(3) is None and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ
+    monkeypatch.delenv("AUM_NO_TUNABLEOP")
+    monkeypatch.setenv("PYTORCH_TUNABLEOP_VERBOSE", "2")
+    d = tunable.enable(3)
+    src = open(os.path.join(os.path.dirname(tunable.__file__), "tunableop_gfx950.csv")).read()
+    assert "GemmTunableOp" in src and "GemmStridedBatchedTunableOp" in src
+    for ordinal in (0, 3):
+        assert open(os.path.join(d, f"results{ordinal}.csv")).read() == src
+    assert os.environ["PYTORCH_TUNABLEOP_FILENAME"] == os.path.join(d, "results.csv")
+    assert os.environ["PYTORCH_TUNABLEOP_ENABLED"] == "1" and os.environ["PYTORCH_TUNABLEOP_VERBOSE"] == "2"
+    for k in ("PYTORCH_TUNABLEOP_ENABLED", "PYTORCH_TUNABLEOP_TUNING", "PYTORCH_TUNABLEOP_FILENAME",
+              "PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS"):
+        os.environ.pop(k, None)                   # enable() wrote them with setdefault: do not leak into other tests
