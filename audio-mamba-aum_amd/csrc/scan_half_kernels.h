@@ -56,7 +56,9 @@ template <class T> AUM_DEV void scanh_row_write(T* rp, int len, const vf2 (&m)[4
 // x' = m_k * x + b_k over the lane's 9 slots (8 half-packed + tail) and the 64 lanes; zero state before the first step.
 // REV = false: steps in order 0..7, tail, lanes 0 -> 63.  REV = true: tail, 7..0, lanes 63 -> 0.
 // Outputs: x[i] = state AFTER slots (i, 4+i), x8 after the tail slot, x_in = state entering the lane.
-template <bool REV> AUM_DEV void scanh_affine(const vf2 (&m)[4], vf m8, const vf2 (&b)[4], vf b8, vf2 (&x)[4], vf& x8, vf& x_in) {
+// CARRY: `cin` is the (wave-uniform) state before the first step of the chunk, `cout` the state after its last one.
+template <bool REV, bool CARRY>
+AUM_DEV void scanh_affine_c(const vf2 (&m)[4], vf m8, const vf2 (&b)[4], vf b8, vf cin, vf2 (&x)[4], vf& x8, vf& x_in, vf& cout) {
     vf2 s = spl2(splat(0.f));
     vf2 Pp = m[0] * m[1];
     Pp = Pp * m[2];
@@ -75,8 +77,11 @@ template <bool REV> AUM_DEV void scanh_affine(const vf2 (&m)[4], vf m8, const vf
         S = vfma(Phi, b8, hi2(s));
         S = vfma(Plo, S, lo2(s));
     }
+    if (CARRY) S = vsel(lane_id() == (REV ? WAVE - 1 : 0), vfma(P, cin, S), S);
     wave_scan_affine<REV>(P, S);
-    x_in = REV ? dpp_wave_shl1(S, splat(0.f)) : dpp_wave_shr1(S, splat(0.f));
+    const vf fill = CARRY ? cin : splat(0.f);
+    x_in = REV ? dpp_wave_shl1(S, fill) : dpp_wave_shr1(S, fill);
+    if (CARRY) cout = splat(readlane(S, REV ? 0 : WAVE - 1));
     vf2 xx;
     if (!REV) {
         xx = mk2(x_in, vfma(Plo, x_in, lo2(s)));
@@ -92,12 +97,20 @@ template <bool REV> AUM_DEV void scanh_affine(const vf2 (&m)[4], vf m8, const vf
     }
     if (!REV) x8 = vfma(m8, hi2(x[3]), b8);
 }
+template <bool REV> AUM_DEV void scanh_affine(const vf2 (&m)[4], vf m8, const vf2 (&b)[4], vf b8, vf2 (&x)[4], vf& x8, vf& x_in) {
+    vf unused;
+    scanh_affine_c<REV, false>(m, m8, b, b8, splat(0.f), x, x8, x_in, unused);
+}
 
 // one (state n, direction) of one row: forward states, adjoint, and the five accumulations
-template <bool REV>
-AUM_DEV void scanh_bwd_dir_state(float Araw, int n, const vf2 (&Bn)[4], vf Bn8, const vf2 (&Cn)[4], vf Cn8, const vf2 (&dl)[4], vf dl8,
-                                 const vf2 (&dlu)[4], vf dlu8, const vf2 (&dy)[4], vf dy8, vf2 (&G)[4], vf& G8, vf2 (&DA)[4], vf& DA8,
-                                 vf2 (&dBacc)[4], vf& dB8, vf2 (&dCacc)[4], vf& dC8, vf& dAv, bool want_dA) {
+// CARRY (chunked rows): xcin = state entering the chunk in scan order, gcin = adjoint entering it in adjoint order, a_edge =
+// multiplier of the step that follows the chunk in time (forward direction only; the reverse direction's carry already
+// holds it), gcout = adjoint leaving the chunk.
+template <bool REV, bool CARRY>
+AUM_DEV void scanh_bwd_dir_state_c(float Araw, int n, const vf2 (&Bn)[4], vf Bn8, const vf2 (&Cn)[4], vf Cn8, const vf2 (&dl)[4], vf dl8,
+                                   const vf2 (&dlu)[4], vf dlu8, const vf2 (&dy)[4], vf dy8, vf2 (&G)[4], vf& G8, vf2 (&DA)[4], vf& DA8,
+                                   vf2 (&dBacc)[4], vf& dB8, vf2 (&dCacc)[4], vf& dC8, vf& dAv, bool want_dA, vf xcin, vf gcin,
+                                   vf a_edge, vf& gcout) {
     const float An = Araw * LOG2E;
     vf2 a[4], bb[4], x[4], cc[4], m[4], g[4];
     AUM_UNROLL
@@ -107,21 +120,22 @@ AUM_DEV void scanh_bwd_dir_state(float Araw, int n, const vf2 (&Bn)[4], vf Bn8, 
         cc[i] = dy[i] * Cn[i];
     }
     const vf a8 = vexp2(dl8 * An), bb8 = dlu8 * Bn8, cc8 = dy8 * Cn8;
-    vf x8, xin, g8, gin;
-    scanh_affine<REV>(a, a8, bb, bb8, x, x8, xin);
+    vf x8, xin, g8, gin, xcout;
+    scanh_affine_c<REV, CARRY>(a, a8, bb, bb8, xcin, x, x8, xin, xcout);
+    (void)xcout;
     // adjoint g_k = dy_k C_k + a_succ(k) * g_succ(k), scanned against the recurrence; the multiplier of a slot is the `a` of its
     // scan successor (the neighbour lane's first slot at the lane edge; 1 past the end of the row)
     vf m8;
     if (!REV) {
         m[0] = a[1]; m[1] = a[2]; m[2] = a[3];
         m[3] = mk2(hi2(a[0]), a8);
-        m8 = dpp_wave_shl1(lo2(a[0]), splat(1.f));
+        m8 = dpp_wave_shl1(lo2(a[0]), CARRY ? a_edge : splat(1.f));
     } else {
         m[0] = mk2(dpp_wave_shr1(a8, splat(1.f)), lo2(a[3]));
         m[1] = a[0]; m[2] = a[1]; m[3] = a[2];
         m8 = hi2(a[3]);
     }
-    scanh_affine<!REV>(m, m8, cc, cc8, g, g8, gin);
+    scanh_affine_c<!REV, CARRY>(m, m8, cc, cc8, gcin, g, g8, gin, gcout);
     (void)gin;
     vf2 dAl = spl2(splat(0.f));
     const vf2 Ar = spl2(splat(Araw));
@@ -148,6 +162,15 @@ AUM_DEV void scanh_bwd_dir_state(float Araw, int n, const vf2 (&Bn)[4], vf Bn8, 
         // shares are added once per row after the state loop (sum_rows4) -- no v_readlane chain per state
         if (want_dA) dAv = vsel((lane_id() & 15) == n, row_sum16(vfma(dl8, h8, lo2(dAl) + hi2(dAl))), dAv);
     }
+}
+
+template <bool REV>
+AUM_DEV void scanh_bwd_dir_state(float Araw, int n, const vf2 (&Bn)[4], vf Bn8, const vf2 (&Cn)[4], vf Cn8, const vf2 (&dl)[4], vf dl8,
+                                 const vf2 (&dlu)[4], vf dlu8, const vf2 (&dy)[4], vf dy8, vf2 (&G)[4], vf& G8, vf2 (&DA)[4], vf& DA8,
+                                 vf2 (&dBacc)[4], vf& dB8, vf2 (&dCacc)[4], vf& dC8, vf& dAv, bool want_dA) {
+    vf unused;
+    scanh_bwd_dir_state_c<REV, false>(Araw, n, Bn, Bn8, Cn, Cn8, dl, dl8, dlu, dlu8, dy, dy8, G, G8, DA, DA8, dBacc, dB8, dCacc, dC8, dAv,
+                                      want_dA, splat(0.f), splat(0.f), splat(1.f), unused);
 }
 
 template <class T, int TAIL, int MODE>
@@ -334,6 +357,313 @@ AUM_DEV void scanh_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_per
     AUM_FOR_EACH_WAVE(w, SCANH_NW) {
         scanwg_store_tile<8, TAIL, SCANH_NW>(dBt, ws + L.pB + ((int64_t)g_idx * p.batch + b) * N * p.len, N, 0, p.len, w);
         scanwg_store_tile<8, TAIL, SCANH_NW>(dCt, ws + L.pC + ((int64_t)g_idx * p.batch + b) * N * p.len, N, 0, p.len, w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chunked rows (long-form clips: 512*m patches + the cls token, L = 1025, 2049, 4097, ...), ONE direction per launch.
+// Same one-row lane layout, 512 main steps per chunk; the single tail step belongs to the last chunk (an identity slot in
+// the others).  Opposite carries make direction fusion impossible here: the states enter a chunk from the scan side, the
+// adjoint from the other side, so the host issues one launch per direction (as it does for the row-pair kernels).
+//   pre-pass   chunks in scan order: lane totals only -> state entering every chunk (workspace `xck`, carry in LDS)
+//   main pass  chunks in adjoint order: states + adjoint with carries, per-chunk du / ddelta / dz, dB/dC tile per chunk
+// dA / dD / ddelta_bias partials of a row accumulate in their workspace slot across chunks (same wave every time).
+// 128 VGPRs -> 16 waves, 64 rows per workgroup, rotation offset 1 with a barrier after every state step.
+// ------------------------------------------------------------------------------------------------
+constexpr int SCANH_CH_NW = 16, SCANH_CH_ROWS = 64;
+template <int TAIL> constexpr int scanh_chunked_lds_floats() { return 4 * ScanGeo<8, TAIL>::TILE + 2 * SCANH_CH_ROWS * SCANWG_MAX_N; }
+// rows per workgroup (a multiple of the 16 waves, at most SCANH_CH_ROWS): long-form batches are small, so the grid is sized
+// to the 256 CUs -- B = 8, E = 1536: 64 rows would leave a quarter of the chip idle (192 workgroups), 48 rows give 256
+AUM_HOSTDEV int scanh_chunked_rows(int batch, int dim) {
+    int best = SCANH_CH_ROWS;
+    long best_cost = -1;
+    for (int rows = SCANH_CH_ROWS; rows >= SCANH_CH_NW; rows -= SCANH_CH_NW) {
+        const long grid = (long)batch * ((dim + rows - 1) / rows);
+        const long cost = ((grid + 255) / 256) * rows;          // rounds over the chip x rows a wave walks per round
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = rows; }
+    }
+    return best;
+}
+AUM_HOSTDEV bool scanh_chunked_selected(int len, int dstate, int mode, uint32_t flags) {
+    return mode != 2 && !(flags & AUM_SCAN_ROWPAIR) && len >= 1024 && (len & 511) <= 1 && dstate <= SCANWG_MAX_N;
+}
+
+template <class T> AUM_DEV void scanh_chunk_read(const T* rp, bool has_tail, vf2 (&m)[4], vf& tl) {
+    const vi lane = lane_id();
+    vf v[8];
+    gload8(rp, lane * 8, lane >= 0, v);
+    AUM_UNROLL
+    for (int i = 0; i < 4; ++i) m[i] = mk2(v[i], v[4 + i]);
+    tl = splat(0.f);
+    if (has_tail) tl = vsel(lane == WAVE - 1, gload_u(rp, spl_i(512)), splat(0.f));
+}
+template <class T> AUM_DEV void scanh_chunk_write(T* rp, bool has_tail, const vf2 (&m)[4], vf tl) {
+    const vi lane = lane_id();
+    vf v[8];
+    AUM_UNROLL
+    for (int i = 0; i < 4; ++i) { v[i] = lo2(m[i]); v[4 + i] = hi2(m[i]); }
+    gstore8(rp, lane * 8, v, lane >= 0);
+    if (has_tail) gstore(rp, spl_i(512), tl, lane == WAVE - 1);
+}
+
+// delta = softplus(delta + bias), delta * u of one chunk of one row (tail slot: identity unless the chunk owns the tail)
+template <class T>
+AUM_DEV void scanh_chunk_delta(const T* up, const T* dp, float bias, bool softplus, bool has_tail, vf2 (&dl)[4], vf& dl8, vf2 (&dlu)[4],
+                               vf& dlu8) {
+    vf2 uu[4], dd[4];
+    vf u8, d8;
+    scanh_chunk_read<T>(up, has_tail, uu, u8);
+    scanh_chunk_read<T>(dp, has_tail, dd, d8);
+    AUM_UNROLL
+    for (int i = 0; i < 4; ++i) {
+        const vf2 dr = dd[i] + spl2(splat(bias));
+        dl[i] = softplus ? vsoftplus2(dr) : dr;
+        dlu[i] = dl[i] * uu[i];
+    }
+    vf d = d8 + bias;
+    if (softplus) d = vsoftplus(d);
+    const vm tail_lane = (lane_id() == WAVE - 1) && (spl_i(has_tail ? 1 : 0) > 0);
+    dl8 = vsel(tail_lane, d, splat(0.f));
+    dlu8 = dl8 * u8;
+}
+
+template <class T, int TAIL, int MODE>
+AUM_DEV void scanh_bwd_chunked(const AumScanBwdArgs& p, int wg, float* lds, int rows_per_wg) {
+    using GE = ScanGeo<8, TAIL>;
+    static_assert(MODE == 0 || MODE == 1, "one direction per launch");
+    constexpr bool REV0 = MODE == 1;
+    constexpr int NW = SCANH_CH_NW;
+    constexpr int CS = 512;                                            // main steps per chunk
+    const int N = p.dstate;
+    float* Bt = lds;
+    float* Ct = lds + GE::TILE;
+    float* dBt = lds + 2 * GE::TILE;
+    float* dCt = lds + 3 * GE::TILE;
+    float* xcarry = lds + 4 * GE::TILE;                                // [rows][16]   pre-pass
+    float* gcarry = xcarry + SCANH_CH_ROWS * SCANWG_MAX_N;             // [rows][16]   main pass
+    const int nchunks = p.len / CS;
+    const ScanWgWs L = scanwg_ws_layout(p.batch, p.dim, p.len, N, rows_per_wg, nchunks, false);
+    float* ws = (float*)p.workspace;
+    const int b = wg / L.gpb, g_idx = wg % L.gpb;
+    const int eb = g_idx * rows_per_wg;
+    const bool softplus = (p.flags & AUM_SCAN_SOFTPLUS) != 0;
+    const T* Bsrc = row_ptr<T>(p.B, (int64_t)b * p.B_bs);
+    const T* Csrc = row_ptr<T>(p.C, (int64_t)b * p.C_bs);
+    const int64_t xck_row_stride = (int64_t)nchunks * N;
+    float* xck = ws + L.xck + (int64_t)wg * rows_per_wg * xck_row_stride;
+    const int niter = (rows_per_wg + NW - 1) / NW;
+
+    AUM_FOR_EACH_WAVE(w, NW) {
+        for (int i0 = w * WAVE; i0 < 2 * SCANH_CH_ROWS * SCANWG_MAX_N; i0 += NW * WAVE) lds_write(xcarry, lane_id() + i0, splat(0.f));
+    }
+    AUM_WG_BARRIER();
+    // ---- pre-pass: state entering every chunk, chunks in scan order ----
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int c = REV0 ? nchunks - 1 - ci : ci;
+        const int base = c * CS;
+        const bool has_tail = TAIL > 0 && c == nchunks - 1;
+        const int len_eff = has_tail ? p.len : base + CS;
+        AUM_FOR_EACH_WAVE(w, NW) { scanwg_load_tile<T, 8, TAIL, NW>(Bsrc, p.B_ns, N, base, len_eff, Bt, w); }
+        AUM_WG_BARRIER();
+        AUM_FOR_EACH_WAVE(w, NW) {
+            const vi lane = lane_id();
+            for (int it = 0; it < niter; ++it) {
+                const int rloc = w + it * NW;
+                const int e = eb + rloc;
+                if (rloc >= rows_per_wg || e >= p.dim) continue;
+                const float bias = p.delta_bias ? p.delta_bias[e] : 0.f;
+                vf2 dl[4], dlu[4];
+                vf dl8, dlu8;
+                scanh_chunk_delta<T>(row_ptr<T>(p.u, (int64_t)b * p.u_bs + (int64_t)e * p.u_ds) + base,
+                                     row_ptr<T>(p.delta, (int64_t)b * p.delta_bs + (int64_t)e * p.delta_ds) + base, bias, softplus, has_tail,
+                                     dl, dl8, dlu, dlu8);
+                for (int n = 0; n < N; ++n) {
+                    const float An = p.A[(int64_t)e * N + n] * LOG2E;
+                    vf2 a[4], bb[4], x[4];
+                    AUM_UNROLL
+                    for (int i = 0; i < 4; ++i) {
+                        a[i] = vexp2_2(dl[i] * spl2(splat(An)));
+                        bb[i] = dlu[i] * mk2(lds_read(Bt, lane * GE::LK + i + n * GE::SP), lds_read(Bt, lane * GE::LK + 4 + i + n * GE::SP));
+                    }
+                    const vf a8 = vexp2(dl8 * An), bb8 = dlu8 * lds_read(Bt, spl_i(WAVE * GE::LK + n * GE::SP));
+                    const vf cin = lds_read(xcarry, spl_i(rloc * SCANWG_MAX_N + n));
+                    gstore_coherent(xck + rloc * xck_row_stride + (int64_t)c * N + n, spl_i(0), cin, lane == 0);
+                    vf x8, xin, cout;
+                    scanh_affine_c<REV0, true>(a, a8, bb, bb8, cin, x, x8, xin, cout);    // only the chunk total is used
+                    lds_write(xcarry, spl_i(rloc * SCANWG_MAX_N + n), cout);
+                }
+            }
+        }
+        AUM_WG_BARRIER();
+    }
+    // ---- main pass: chunks in adjoint order ----
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int c = REV0 ? ci : nchunks - 1 - ci;
+        const int base = c * CS;
+        const bool has_tail = TAIL > 0 && c == nchunks - 1;
+        const int len_eff = has_tail ? p.len : base + CS;
+        const bool first_visit = ci == 0;
+        AUM_FOR_EACH_WAVE(w, NW) {
+            scanwg_load_tile<T, 8, TAIL, NW>(Bsrc, p.B_ns, N, base, len_eff, Bt, w);
+            scanwg_load_tile<T, 8, TAIL, NW>(Csrc, p.C_ns, N, base, len_eff, Ct, w);
+            for (int i0 = w * WAVE; i0 < GE::TILE; i0 += NW * WAVE) {
+                const vi idx = lane_id() + i0;
+                lds_write_m(dBt, idx, splat(0.f), idx < GE::TILE);
+                lds_write_m(dCt, idx, splat(0.f), idx < GE::TILE);
+            }
+        }
+        AUM_WG_BARRIER();
+        AUM_FOR_EACH_WAVE(w, NW) {
+            const vi lane = lane_id();
+            const vm tail_lane = (lane == WAVE - 1) && (spl_i(has_tail ? 1 : 0) > 0);
+            vi pos[4], pos4[4];
+            AUM_UNROLL
+            for (int i = 0; i < 4; ++i) { pos[i] = lane * GE::LK + i; pos4[i] = lane * GE::LK + 4 + i; }
+            const vi pos8 = spl_i(WAVE * GE::LK);
+            for (int it = 0; it < niter; ++it) {
+                const int rloc = w + it * NW;
+                const int e = eb + rloc;
+                const bool active = rloc < rows_per_wg && e < p.dim;   // wave-uniform; inactive waves still take every barrier below
+                const int ec = active ? e : p.dim - 1;
+                const int rl = active ? rloc : 0;
+                const float bias = p.delta_bias ? p.delta_bias[ec] : 0.f;
+                const T* up = row_ptr<T>(p.u, (int64_t)b * p.u_bs + (int64_t)ec * p.u_ds) + base;
+                const T* dp = row_ptr<T>(p.delta, (int64_t)b * p.delta_bs + (int64_t)ec * p.delta_ds) + base;
+                vf2 dl[4], dlu[4], dy[4], G[4], DA[4];
+                vf dl8, dlu8, dy8, G8 = splat(0.f), DA8 = splat(0.f);
+                scanh_chunk_delta<T>(up, dp, bias, softplus, has_tail, dl, dl8, dlu, dlu8);
+                AUM_UNROLL
+                for (int i = 0; i < 4; ++i) { G[i] = spl2(splat(0.f)); DA[i] = spl2(splat(0.f)); }
+                {   // dout (and the gate): dy = dout * silu(z), dz = dout * out_pre * silu'(z)
+                    vf2 go[4];
+                    vf go8;
+                    scanh_chunk_read<T>(row_ptr<T>(p.dout, (int64_t)b * p.dout_bs + (int64_t)ec * p.dout_ds) + base, has_tail, go, go8);
+                    if (p.z) {
+                        vf2 zz[4], yp[4], dzv[4];
+                        vf z8, yp8, dz8;
+                        scanh_chunk_read<T>(row_ptr<T>(p.z, (int64_t)b * p.z_bs + (int64_t)ec * p.z_ds) + base, has_tail, zz, z8);
+                        scanh_chunk_read<T>(row_ptr<T>(p.out_pre, (int64_t)b * p.out_bs + (int64_t)ec * p.out_ds) + base, has_tail, yp, yp8);
+                        const vf2 one2 = spl2(splat(1.f));
+                        AUM_UNROLL
+                        for (int i = 0; i < 4; ++i) {
+                            const vf2 sg = vsigmoid2(zz[i]);
+                            dzv[i] = go[i] * yp[i] * sg * vfma2(zz[i], one2 - sg, one2);
+                            go[i] = go[i] * zz[i] * sg;
+                        }
+                        const vf sg = vsigmoid(z8);
+                        dz8 = go8 * yp8 * sg * vfma(z8, splat(1.f) - sg, splat(1.f));
+                        go8 = go8 * z8 * sg;
+                        if (active)
+                            scanh_chunk_write<T>(row_ptr_w<T>(p.dz, (int64_t)b * p.dz_bs + (int64_t)ec * p.dz_ds) + base, has_tail, dzv, dz8);
+                    }
+                    AUM_UNROLL
+                    for (int i = 0; i < 4; ++i) dy[i] = go[i];
+                    dy8 = vsel(tail_lane, go8, splat(0.f));
+                }
+                // forward direction: the adjoint enters from the chunk that follows in time and is multiplied by that chunk's
+                // first step, a = exp(delta_next * A_n); nothing follows the last chunk (multiplier 1, carry 0)
+                vf dnf = splat(0.f);
+                if (!REV0 && base + CS + (has_tail ? 1 : 0) < p.len) {
+                    dnf = gload_u(dp, spl_i(CS)) + bias;
+                    if (softplus) dnf = vsoftplus(dnf);
+                }
+                vf dAv0 = splat(0.f);
+                const bool want_dA = !(p.flags & AUM_DBG_SKIP_PARTIALS);
+                for (int j = 0; j < SCANWG_MAX_N; ++j) {
+                    const int n = (j + w) & (SCANWG_MAX_N - 1);
+                    if (active && n < N) {
+                        vf2 Bn[4], Cn[4], dBacc[4], dCacc[4];
+                        vf dB8 = splat(0.f), dC8 = splat(0.f);
+                        AUM_UNROLL
+                        for (int i = 0; i < 4; ++i) {
+                            Bn[i] = mk2(lds_read(Bt, pos[i] + n * GE::SP), lds_read(Bt, pos4[i] + n * GE::SP));
+                            Cn[i] = mk2(lds_read(Ct, pos[i] + n * GE::SP), lds_read(Ct, pos4[i] + n * GE::SP));
+                            dBacc[i] = spl2(splat(0.f));
+                            dCacc[i] = spl2(splat(0.f));
+                        }
+                        const vf Bn8 = lds_read(Bt, pos8 + n * GE::SP), Cn8 = lds_read(Ct, pos8 + n * GE::SP);
+                        const float Araw = p.A[(int64_t)ec * N + n];
+                        const vf xcin = gload_coherent(xck + rl * xck_row_stride + (int64_t)c * N + n, spl_i(0), lane >= 0);
+                        const vf gcin = lds_read(gcarry, spl_i(rl * SCANWG_MAX_N + n));
+                        const vf a_edge = vexp2(dnf * (Araw * LOG2E));
+                        vf gcout;
+                        scanh_bwd_dir_state_c<REV0, true>(Araw, n, Bn, Bn8, Cn, Cn8, dl, dl8, dlu, dlu8, dy, dy8, G, G8, DA, DA8, dBacc, dB8,
+                                                          dCacc, dC8, dAv0, want_dA, xcin, gcin, a_edge, gcout);
+                        lds_write(gcarry, spl_i(rl * SCANWG_MAX_N + n), gcout);
+                        AUM_UNROLL
+                        for (int i = 0; i < 4; ++i) {
+                            const vi a0 = pos[i] + n * GE::SP, a1 = pos4[i] + n * GE::SP;
+                            lds_write(dBt, a0, lds_read(dBt, a0) + lo2(dBacc[i]));
+                            lds_write(dBt, a1, lds_read(dBt, a1) + hi2(dBacc[i]));
+                            lds_write(dCt, a0, lds_read(dCt, a0) + lo2(dCacc[i]));
+                            lds_write(dCt, a1, lds_read(dCt, a1) + hi2(dCacc[i]));
+                        }
+                        if (TAIL > 0) {
+                            const vi a8 = pos8 + n * GE::SP;          // shared slot: owned by the last lane
+                            lds_write_m(dBt, a8, lds_read(dBt, a8) + dB8, lane == WAVE - 1);
+                            lds_write_m(dCt, a8, lds_read(dCt, a8) + dC8, lane == WAVE - 1);
+                        }
+                    }
+                    AUM_WG_BARRIER_IN_PHASE();
+                }
+                if (active && want_dA) {
+                    const vm mn = lane < N;
+                    const vi ln = vmin_i(lane, N - 1);
+                    float* sA = ws + L.pA + ((int64_t)b * p.dim + e) * N;
+                    vf v0 = sum_rows4(dAv0);
+                    if (!first_visit) v0 = v0 + gload_coherent(sA, ln, mn);
+                    gstore_coherent(sA, ln, v0, mn);
+                }
+                if (active) {
+                    const float Dn = p.D ? p.D[e] : 0.f;
+                    vf2 uu[4], raw[4], duv[4], ddv[4];
+                    vf u8, raw8 = splat(0.f);
+                    scanh_chunk_read<T>(up, has_tail, uu, u8);
+                    if (softplus) scanh_chunk_read<T>(dp, has_tail, raw, raw8);
+                    vf2 dDl = spl2(splat(0.f)), dbl = spl2(splat(0.f));
+                    AUM_UNROLL
+                    for (int i = 0; i < 4; ++i) {
+                        duv[i] = vfma2(dl[i], G[i], dy[i] * spl2(splat(Dn)));
+                        vf2 dd = vfma2(uu[i], G[i], DA[i]);
+                        if (softplus) {
+                            const vf2 rw = raw[i] + spl2(splat(bias));
+                            const vf2 ds = dd * vsigmoid2(rw);
+                            dd = mk2(vsel(lo2(rw) > 20.f, lo2(dd), lo2(ds)), vsel(hi2(rw) > 20.f, hi2(dd), hi2(ds)));
+                        }
+                        ddv[i] = dd;
+                        dDl = vfma2(dy[i], uu[i], dDl);
+                        dbl = dbl + dd;
+                    }
+                    vf du8 = vfma(dl8, G8, dy8 * Dn);
+                    vf dd8 = vfma(u8, G8, DA8);
+                    if (softplus) {
+                        const vf r8 = raw8 + bias;
+                        dd8 = vsel(r8 > 20.f, dd8, dd8 * vsigmoid(r8));
+                    }
+                    dd8 = vsel(tail_lane, dd8, splat(0.f));
+                    du8 = vsel(tail_lane, du8, splat(0.f));
+                    scanh_chunk_write<T>(row_ptr_w<T>(p.du, (int64_t)b * p.du_bs + (int64_t)e * p.du_ds) + base, has_tail, duv, du8);
+                    scanh_chunk_write<T>(row_ptr_w<T>(p.ddelta, (int64_t)b * p.ddelta_bs + (int64_t)e * p.ddelta_ds) + base, has_tail, ddv, dd8);
+                    float sD = wave_sum(vfma(dy8, u8, lo2(dDl) + hi2(dDl)));
+                    float sb = wave_sum(lo2(dbl) + hi2(dbl) + dd8);
+                    float* slotD = ws + L.pD + (int64_t)b * p.dim + e;
+                    float* slotb = ws + L.pbias + (int64_t)b * p.dim + e;
+                    if (!first_visit) {
+                        sD += readlane(gload_coherent(slotD, spl_i(0), lane >= 0), 0);
+                        sb += readlane(gload_coherent(slotb, spl_i(0), lane >= 0), 0);
+                    }
+                    gstore_coherent(slotD, spl_i(0), splat(sD), lane == 0);
+                    gstore_coherent(slotb, spl_i(0), splat(sb), lane == 0);
+                }
+            }
+        }
+        AUM_WG_BARRIER();
+        // flush this chunk's dB/dC tile: one partial per workgroup, every (g,b,n,t) written exactly once
+        AUM_FOR_EACH_WAVE(w, NW) {
+            scanwg_store_tile<8, TAIL, NW>(dBt, ws + L.pB + ((int64_t)g_idx * p.batch + b) * N * p.len, N, base, len_eff, w, p.len);
+            scanwg_store_tile<8, TAIL, NW>(dCt, ws + L.pC + ((int64_t)g_idx * p.batch + b) * N * p.len, N, base, len_eff, w, p.len);
+        }
+        AUM_WG_BARRIER();
     }
 }
 

@@ -30,7 +30,8 @@ constexpr int SCANWG_MAX_ROWS = 64;   // rows per workgroup (8 waves x 4 pairs x
 constexpr int SCANWG_MAX_K = 9;       // <= 577 steps per chunk keeps the backward's 4 fp32 tiles inside 160 KB of LDS
 // debug-only ablation bits (upper half of `flags`; set through AUM_ABLATE in the Python binding, never by the product)
 constexpr uint32_t AUM_DBG_SKIP_STATES = 1u << 16, AUM_DBG_SKIP_LDS_ATOMICS = 1u << 17, AUM_DBG_SKIP_PARTIALS = 1u << 18,
-                   AUM_DBG_SKIP_EPILOGUE = 1u << 19, AUM_DBG_NO_STEP_BARRIER = 1u << 20;
+                   AUM_DBG_SKIP_EPILOGUE = 1u << 19, AUM_DBG_NO_STEP_BARRIER = 1u << 20,
+                   AUM_DBG_CHUNKED_MAX_ROWS = 1u << 21;   // tests: 64-row workgroups in the chunked one-row backward whatever the grid
 
 template <int K, int TAIL> struct ScanGeo {
     static constexpr int KT = K + TAIL;                    // slots per lane
@@ -136,10 +137,13 @@ AUM_DEV void scanwg_load_tile(const T* src, int64_t n_stride, int N, int base, i
 }
 
 // Write one [N][S] fp32 LDS tile to a dense (N, len) fp32 global partial (t >= len skipped); vectorised like the load.
+// `pitch` (default: len) is the row pitch of dst when `len` is only the validity bound (chunked rows whose tail column
+// belongs to the last chunk).
 template <int K, int TAIL, int NW = SCANWG_NW>
-AUM_DEV void scanwg_store_tile(const float* tile, float* dst, int N, int base, int len, int w) {
+AUM_DEV void scanwg_store_tile(const float* tile, float* dst, int N, int base, int len, int w, int pitch = -1) {
     using G = ScanGeo<K, TAIL>;
     const vi lane = lane_id();
+    if (pitch < 0) pitch = len;
     if constexpr (K == 8) {
         if (base + WAVE * K <= len) {
             for (int i0 = w * WAVE; i0 < N * WAVE; i0 += NW * WAVE) {
@@ -150,14 +154,14 @@ AUM_DEV void scanwg_store_tile(const float* tile, float* dst, int N, int base, i
                 vf v[8];
                 AUM_UNROLL
                 for (int k = 0; k < 8; ++k) v[k] = lds_read(tile, n * G::SP + j * G::LK + k);
-                gstore8(dst, n * len + j * 8 + base, v, in);
+                gstore8(dst, n * pitch + j * 8 + base, v, in);
             }
             if (TAIL > 0) {
                 const vi n = vmin_i(lane / (TAIL > 0 ? TAIL : 1), N - 1);
                 const vi jt = lane - (lane / (TAIL > 0 ? TAIL : 1)) * (TAIL > 0 ? TAIL : 1);
                 const vi t = jt + (base + WAVE * K);
                 const vm in = (lane < N * TAIL) && (spl_i(w) == 0) && (t < len);
-                gstore(dst, n * len + t, lds_read(tile, n * G::SP + WAVE * G::LK + jt), in);
+                gstore(dst, n * pitch + t, lds_read(tile, n * G::SP + WAVE * G::LK + jt), in);
             }
             return;
         }
@@ -168,7 +172,7 @@ AUM_DEV void scanwg_store_tile(const float* tile, float* dst, int N, int base, i
         const vi tt = vmin_i(idx - (idx / G::S) * G::S, G::S - 1);
         const vi tg = tt + base;
         const vm m = (idx < N * G::S) && (tg < len);
-        gstore(dst, n * len + tg, lds_read(tile, n * G::SP + scan_tile_pos<K, TAIL>(tt)), m);
+        gstore(dst, n * pitch + tg, lds_read(tile, n * G::SP + scan_tile_pos<K, TAIL>(tt)), m);
     }
 }
 

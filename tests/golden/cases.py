@@ -27,6 +27,15 @@ SCAN_WIDE_CASES = [
     ("l513_d70_n8_noz", 1, 70, 513, 8, False, True, False, True),
 ]
 
+# long rows of 512*m (+1) steps: the backward is the chunked one-row kernel (one launch per direction, carries between the
+# 512-step chunks, the tail step owned by the last chunk); live oracle only.  Two row groups with idle waves / fewer states /
+# no gate, no D, no bias, no softplus / three chunks
+SCAN_LONG_CASES = [
+    ("l1024_d70_n8", 1, 70, 1024, 8, True, True, True, True),
+    ("l1025_d5_plain", 2, 5, 1025, 16, False, False, False, False),
+    ("l1537_d3", 1, 3, 1537, 16, True, True, True, True),
+]
+
 # (name, batch, dim, len, width, has_bias)
 CONV_CASES = [
     ("l1", 2, 8, 1, 4, True),

@@ -46,6 +46,26 @@ def test_scan_one_row_backward_vs_row_pair(emu, case, mode):
     KC.check_scan(emu, "cpu", case, torch.bfloat16, reverse=(mode == "rev"), bidir=(mode == "bidir"))
 
 
+@pytest.mark.parametrize("case", cases.SCAN_LONG_CASES + [c for c in cases.SCAN_CASES if c[0] == "l2049"], ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev"])
+def test_scan_chunked_one_row_backward(emu, case, mode):
+    """L = 512 m (+1) >= 1024: the backward is scanh_bwd_chunked (pre-pass for the chunk-entry states, adjoint carried from
+    chunk to chunk); it and the row-pair kernel it replaces (AUM_SCAN_ROWPAIR) must both match the oracle"""
+    for rowpair in (False, True):
+        KC.check_scan(emu, "cpu", case, torch.float32, reverse=(mode == "rev"), rowpair=rowpair)
+    KC.check_scan(emu, "cpu", case, torch.bfloat16, reverse=(mode == "rev"))
+    KC.check_scan(emu, "cpu", case, torch.float32, reverse=(mode == "rev"), strided=True)
+
+
+def test_scan_chunked_one_row_backward_row_groupings(emu, monkeypatch):
+    """the chunked kernel sizes its workgroups (16..64 rows) to the grid; small test shapes always get 16 rows, so the
+    64-row grouping (four rows per wave, a ragged second group) is forced through the debug bit"""
+    case = [c for c in cases.SCAN_LONG_CASES if c[0] == "l1024_d70_n8"][0]
+    monkeypatch.setenv("AUM_ABLATE", str(1 << 5))
+    for reverse in (False, True):
+        KC.check_scan(emu, "cpu", case, torch.float32, reverse=reverse)
+
+
 @pytest.mark.parametrize("mode", ["fwd", "bidir"])
 def test_scan_bf16_and_strided(emu, mode):
     case = [c for c in cases.SCAN_CASES if c[0] == "l65"][0]

@@ -49,6 +49,40 @@ def test_scan_one_row_backward_vs_row_pair(lib, case, mode, dtype):
         KC.check_scan(lib, "cuda", case, dtype, reverse=(mode == "rev"), bidir=(mode == "bidir"), rowpair=rowpair)
 
 
+@pytest.mark.parametrize("case", cases.SCAN_LONG_CASES + [c for c in cases.SCAN_CASES if c[0] == "l2049"], ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_chunked_one_row_backward(lib, case, mode, dtype):
+    for rowpair in (False, True):
+        KC.check_scan(lib, "cuda", case, dtype, reverse=(mode == "rev"), rowpair=rowpair)
+    KC.check_scan(lib, "cuda", case, dtype, reverse=(mode == "rev"), strided=True)
+
+
+def test_scan_long_form_full_size(lib):
+    """long-form shape (BASELINE config 5: B=2 of the 8, E=1536, L=4097, N=16, bf16, d-major rows): the chunked one-row
+    backward against the row-pair kernels on the same inputs, and bitwise repeatable from launch to launch"""
+    torch.manual_seed(0)
+    Bsz, E, L, N = 2, 1536, 4097, 16
+    dt = torch.bfloat16
+    mk = lambda: torch.randn(E, Bsz, L, device="cuda").to(dt).permute(1, 0, 2)
+    u, z, dout = mk(), mk(), mk()
+    delta = (0.5 * torch.randn(E, Bsz, L, device="cuda")).to(dt).permute(1, 0, 2)
+    Bm, Cm = torch.randn(Bsz, 1, N, L, device="cuda").to(dt), torch.randn(Bsz, 1, N, L, device="cuda").to(dt)
+    A = -torch.arange(1, N + 1, device="cuda", dtype=torch.float32).repeat(E, 1) * (1 + 0.1 * torch.rand(E, N, device="cuda"))
+    D, bias = torch.ones(E, device="cuda"), torch.full((E,), -4.0, device="cuda") + torch.rand(E, device="cuda")
+    for reverse in (False, True):
+        _, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, reverse, want_out_pre=True, lib=lib)
+        g = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, reverse, lib=lib)
+        g2 = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, reverse, lib=lib)
+        gp = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, reverse, rowpair=True, lib=lib)
+        for k, v in g.items():
+            if v is None:
+                continue
+            assert torch.equal(v, g2[k]), (reverse, k)
+            a, b = v.float(), gp[k].float()
+            assert (a - b).abs().max() <= 2e-2 * b.abs().max() + 1e-6, (reverse, k, float((a - b).abs().max()), float(b.abs().max()))
+
+
 def test_scan_strided_layout(lib):
     c = [x for x in cases.SCAN_CASES if x[0] == "l65"][0]
     KC.check_scan(lib, "cuda", c, torch.float32, bidir=True, strided=True)

@@ -67,14 +67,22 @@ def main():
         rec("torch_copy_1GiB", timeit(lambda: dst.copy_(src)), 2 * src.numel())
         del src, dst
     bc = 2 * Bsz * N * L * s
+    fused = L <= aum_hip.get().max_single_pass_len      # longer rows: chunked kernels, one launch per direction
     if want("scan_fwd"):
         rec("scan_fwd_uni", timeit(lambda: aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True)), 4 * T * s + bc)
+    if want("scan_fwd") and not fused:
+        rec("scan_fwd_uni_train", timeit(lambda: aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, want_out_pre=True)), 5 * T * s + bc)
+        rec("scan_fwd_rev_train", timeit(lambda: aum_hip.scan_fwd(u, delta, A_b, Bm, Cm, D, z, bias, True, True, want_out_pre=True)), 5 * T * s + bc)
+    if want("scan_fwd") and fused:
         rec("scan_fwd_bidir", timeit(lambda: aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b)), 4 * T * s + bc)
         rec("scan_fwd_bidir_train", timeit(lambda: aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True)), 5 * T * s + bc)
     if want("scan_bwd"):
-        _, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True)
+        _, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b if fused else None, want_out_pre=True)
         bw_bytes = 8 * T * s + bc + 2 * Bsz * N * L * 4
         rec("scan_bwd_uni", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True), iters=10), bw_bytes)
+    if want("scan_bwd") and not fused:
+        rec("scan_bwd_rev", timeit(lambda: aum_hip.scan_bwd(u, delta, A_b, Bm, Cm, D, z, bias, dout, pre, True, True), iters=10), bw_bytes)
+    if want("scan_bwd") and fused:
         rec("scan_bwd_bidir", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, A_b=A_b), iters=10), bw_bytes)
     if want("conv"):
         w = torch.randn(E, 4, device=dev)

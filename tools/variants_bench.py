@@ -58,8 +58,13 @@ def run(size, btype, train, batch=64, steps=6, warm=3, frames=1024):
 
 
 if __name__ == "__main__":
-    out = [run("base", "v1", True), run("base", "v1", False), run("base", "v2", True), run("base", "none", True),
-           run("small", "v1", True), run("tiny", "v1", True), run("base", "v1", True, batch=256, steps=3, warm=2),
-           run("base", "v1", True, batch=8, steps=4, warm=2, frames=8192)]      # long-form: L = 4097, chunked scans
+    # `--only long` runs just the long-form configuration (BASELINE config 5: B = 8, 128 x 8192 frames, L = 4097)
+    long_form = lambda: run("base", "v1", True, batch=8, steps=4, warm=2, frames=8192)
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "long":
+        out, name = [long_form()], "variants_bench_long.json"
+    else:
+        out = [run("base", "v1", True), run("base", "v1", False), run("base", "v2", True), run("base", "none", True),
+               run("small", "v1", True), run("tiny", "v1", True), run("base", "v1", True, batch=256, steps=3, warm=2), long_form()]
+        name = "variants_bench.json"
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "variants_bench.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", name), "w"), indent=1)
