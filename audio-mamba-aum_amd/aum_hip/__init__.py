@@ -207,7 +207,7 @@ def _alloc(batch, dim, length, dtype, device, dmajor):
 
 
 def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, reverse=False, A_b=None,
-             want_out_pre=False, want_last_state=False, dmajor=False, generic=False, lib=None):
+             want_out_pre=False, want_last_state=False, dmajor=False, generic=False, rowpair=False, lib=None):
     """selective_scan_cuda.fwd.  Returns (out, out_pre|None, last_state|None).  A_b != None: fused bidirectional."""
     lib = lib or get()
     B, C = _bc3(B), _bc3(C)
@@ -237,6 +237,7 @@ def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     a.out_bs, a.out_ds = out.stride(0), out.stride(1)
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
     a.flags = ((SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0) | (SCAN_GENERIC if generic else 0)
+               | (8 if rowpair or os.environ.get('AUM_SCAN_ROWPAIR') == '1' else 0)
                | (int(os.environ.get('AUM_ABLATE', '0')) << 16))   # AUM_ABLATE: kernel-ablation bits for tools/kbench.py only
     _launch(lib.c.aum_selective_scan_fwd, a, u, lib, "scan_fwd_bidir" if A_b is not None else "scan_fwd",
             (batch, dim, length, dstate, u.element_size(), want_out_pre))

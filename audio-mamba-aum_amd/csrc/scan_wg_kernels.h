@@ -41,7 +41,11 @@ template <int K, int TAIL> struct ScanGeo {
     static constexpr int TILE = SCANWG_MAX_N * SP;
 };
 // geometries with a tail slot are single-chunk only: no carry area, which keeps <8,1> at two workgroups per CU
-template <int K, int TAIL> constexpr int scanwg_fwd_lds_floats() { return 2 * ScanGeo<K, TAIL>::TILE + (TAIL ? 0 : 2 * SCANWG_MAX_ROWS * SCANWG_MAX_N); }
+// CT ("chunked tail"): rows of 64K*m + 1 steps walked in 64K-step chunks, the tail slot owned by the last chunk; one direction
+// per launch, so one carry area
+template <int K, int TAIL, bool CT = false> constexpr int scanwg_fwd_lds_floats() {
+    return 2 * ScanGeo<K, TAIL>::TILE + (CT ? SCANWG_MAX_ROWS * SCANWG_MAX_N : TAIL ? 0 : 2 * SCANWG_MAX_ROWS * SCANWG_MAX_N);
+}
 template <int K, int TAIL> constexpr int scanwg_bwd_lds_floats() { return 4 * ScanGeo<K, TAIL>::TILE + 3 * SCANWG_MAX_ROWS * SCANWG_MAX_N; }
 
 // Workspace layout of the backward (floats), shared by host dispatch, kernel and the reduce kernel.
@@ -402,6 +406,103 @@ AUM_DEV void scanwg_fwd(const AumScanFwdArgs& p, int wg, float* lds, int rows_pe
                             for (int k = 0; k < KT; ++k) o[k] = o[k] * (zz[k] * vsigmoid(zz[k]));
                         }
                         scan_row_write<T, K, TAIL>(row_ptr_w<T>(p.out, ooff), base, p.len, t, valid, o);
+                    }
+                }
+            }
+        }
+        AUM_WG_BARRIER();
+    }
+}
+
+// scanwg_fwd for rows of 64K*m + 1 steps walked in 64K-step chunks (CT, "chunked tail"): the tail slot is owned by the last
+// chunk and hidden from the others through `len_eff`.  Kept as a separate function so that the single-chunk kernels above
+// compile exactly as before.
+template <class T, int K, int TAIL, int MODE, bool CT = true>
+AUM_DEV void scanwg_fwd_ct(const AumScanFwdArgs& p, int wg, float* lds, int rows_per_wg) {
+    using G = ScanGeo<K, TAIL>;
+    constexpr bool BI = MODE == 2;
+    constexpr int KT = G::KT;
+    const int N = p.dstate;
+    float* Bt = lds;
+    float* Ct = lds + G::TILE;
+    float* carry = lds + 2 * G::TILE;     // [2][SCANWG_MAX_ROWS][SCANWG_MAX_N]
+    const int gpb = (p.dim + rows_per_wg - 1) / rows_per_wg;
+    const int b = wg / gpb;
+    const int eb = (wg % gpb) * rows_per_wg;
+    static_assert(!CT || (TAIL == 1 && MODE != 2), "chunked-tail rows: tail geometry, one direction");
+    constexpr int CSTEP = CT ? WAVE * K : G::S;                       // time steps between chunk starts
+    const int nchunks = CT ? p.len / CSTEP : (p.len + G::S - 1) / G::S;
+    const bool multi = nchunks > 1;
+    const bool softplus = (p.flags & AUM_SCAN_SOFTPLUS) != 0;
+    const T* Bsrc = row_ptr<T>(p.B, (int64_t)b * p.B_bs);
+    const T* Csrc = row_ptr<T>(p.C, (int64_t)b * p.C_bs);
+
+    if (multi) {
+        AUM_FOR_EACH_WAVE(w, SCANWG_NW) {
+            for (int i0 = w * WAVE; i0 < (CT ? 1 : 2) * SCANWG_MAX_ROWS * SCANWG_MAX_N; i0 += SCANWG_NW * WAVE)
+                lds_write(carry, lane_id() + i0, splat(0.f));
+        }
+        AUM_WG_BARRIER();
+    }
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int c = (MODE == 1) ? nchunks - 1 - ci : ci;
+        const int base = c * CSTEP;
+        const int len_eff = (CT && c != nchunks - 1) ? base + CSTEP : p.len;      // hides the tail slot from all but the last chunk
+        AUM_FOR_EACH_WAVE(w, SCANWG_NW) {
+            scanwg_load_tile<T, K, TAIL>(Bsrc, p.B_ns, N, base, len_eff, Bt, w);
+            scanwg_load_tile<T, K, TAIL>(Csrc, p.C_ns, N, base, len_eff, Ct, w);
+        }
+        AUM_WG_BARRIER();
+        AUM_FOR_EACH_WAVE(w, SCANWG_NW) {
+            for (int pair = w; 2 * pair < rows_per_wg; pair += SCANWG_NW) {
+                const int rloc = 2 * pair;
+                const int e0 = eb + rloc;
+                if (e0 >= p.dim) break;
+                vi t[KT], pos[KT];
+                vm valid[KT];
+                scan_slots<K, TAIL>(base, len_eff, t, valid, pos);
+                vf2 dl[KT], dlu[KT], y[KT], sumd;
+                scanwg_load_rows<T, K, TAIL>(p.u, p.u_bs, p.u_ds, p.delta, p.delta_bs, p.delta_ds, p.delta_bias, softplus, b,
+                                             e0, p.dim, base, len_eff, t, valid, dl, dlu, sumd);
+                AUM_UNROLL
+                for (int k = 0; k < KT; ++k) y[k] = spl2(splat(0.f));
+                const bool wl = (ci == nchunks - 1) && p.last_state != nullptr;
+                if (!(p.flags & AUM_DBG_SKIP_STATES)) {
+                    if (MODE == 0 || BI)
+                        scanwg_fwd_dir<T, K, TAIL, false>(p, b, e0, rloc, p.A, Bt, Ct, pos, dl, dlu, sumd, carry, multi,
+                                                          wl && !BI, y);
+                    if (MODE == 1)
+                        scanwg_fwd_dir<T, K, TAIL, true>(p, b, e0, rloc, p.A, Bt, Ct, pos, dl, dlu, sumd, carry, multi, wl, y);
+                    if (BI)
+                        scanwg_fwd_dir<T, K, TAIL, true>(p, b, e0, rloc, p.A_b, Bt, Ct, pos, dl, dlu, sumd,
+                                                         carry + SCANWG_MAX_ROWS * SCANWG_MAX_N, multi, false, y);
+                }
+                AUM_UNROLL
+                for (int r = 0; r < SCAN_R; ++r) {
+                    const int e = e0 + r;
+                    if (e < p.dim) {
+                        const float Dn = p.D ? (BI ? 2.f : 1.f) * p.D[e] : 0.f;
+                        const int64_t ooff = (int64_t)b * p.out_bs + (int64_t)e * p.out_ds;
+                        vf o[KT];
+                        if (p.D) {
+                            vf uu[KT];
+                            scan_row_read<T, K, TAIL>(row_ptr<T>(p.u, (int64_t)b * p.u_bs + (int64_t)e * p.u_ds), base, len_eff, t,
+                                                      valid, uu);
+                            AUM_UNROLL
+                            for (int k = 0; k < KT; ++k) o[k] = vfma(uu[k], splat(Dn), r == 0 ? lo2(y[k]) : hi2(y[k]));
+                        } else {
+                            AUM_UNROLL
+                            for (int k = 0; k < KT; ++k) o[k] = r == 0 ? lo2(y[k]) : hi2(y[k]);
+                        }
+                        if (p.out_pre) scan_row_write<T, K, TAIL>(row_ptr_w<T>(p.out_pre, ooff), base, len_eff, t, valid, o);
+                        if (p.z) {
+                            vf zz[KT];
+                            scan_row_read<T, K, TAIL>(row_ptr<T>(p.z, (int64_t)b * p.z_bs + (int64_t)e * p.z_ds), base, len_eff, t,
+                                                      valid, zz);
+                            AUM_UNROLL
+                            for (int k = 0; k < KT; ++k) o[k] = o[k] * (zz[k] * vsigmoid(zz[k]));
+                        }
+                        scan_row_write<T, K, TAIL>(row_ptr_w<T>(p.out, ooff), base, len_eff, t, valid, o);
                     }
                 }
             }

@@ -46,7 +46,8 @@ enum {
 #define AUM_SCAN_REVERSE 2u  /* run the recurrence from t=len-1 down to 0 (replaces the .flip([-1]) copies of   */
                              /* selective_scan_interface.py:503-507,547-561 and mamba_simple.py:229-246)        */
 #define AUM_SCAN_GENERIC 4u  /* force the generic single-wave kernels (any dstate <= 256); default: 8-wave workgroup */
-#define AUM_SCAN_ROWPAIR 8u  /* debug / A-B: keep the row-pair backward where the one-row kernel (512 + tail rows) would run */
+#define AUM_SCAN_ROWPAIR 8u  /* debug / A-B: keep the general row-pair kernels where a specialised one would run (one-row backward for
+                                 512 + tail rows, chunked kernels for rows of 512*m + 1 steps, forward and backward) */
                              /* kernels when dstate <= 16                                                        */
 #define AUM_CONV_SILU 1u
 #define AUM_CONV_REVERSE 2u  /* anti-causal: y[l] = act(b + sum_w W[w] x[l+(W-1)-w])                            */

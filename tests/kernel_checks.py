@@ -42,7 +42,7 @@ def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, 
     Bm, Cm = act(d["B"]).unsqueeze(1), act(d["C"]).unsqueeze(1)
     A, D, bias = T(d["A"], dev), T(d["D"], dev), T(d["delta_bias"], dev)
     out, out_pre, last = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, softplus, reverse, T(A_b, dev),
-                                          want_out_pre=True, want_last_state=not bidir, generic=generic, lib=lib)
+                                          want_out_pre=True, want_last_state=not bidir, generic=generic, rowpair=rowpair, lib=lib)
     ref = O.scan_fwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], softplus,
                      reverse, "f64")
     ref_out, ref_pre = ref["out"], ref["y_pre"]
