@@ -66,6 +66,8 @@ INNER_CASES = [
     ("none_d16_l65", "none", 2, 16, 65),
     ("v2_d16_l65", "v2", 2, 16, 65),
     ("v2_d64_l130", "v2", 1, 64, 130),
+    # long-form row (512*2 + cls): the host composes one launch per direction, kernels = the 512-step chunked ones
+    ("v1_d16_l1025", "v1", 1, 16, 1025),
 ]
 
 
