@@ -32,7 +32,7 @@ class ScanFwdArgs(C.Structure):
                                     "last_state", "workspace")]
                 + [(n, _i64) for n in ("workspace_bytes", "u_bs", "u_ds", "delta_bs", "delta_ds", "z_bs", "z_ds", "B_bs",
                                        "B_ns", "C_bs", "C_ns", "out_bs", "out_ds")]
-                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32)])
+                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32), ("x_ck", _vp)])
 
 
 class ScanBwdArgs(C.Structure):
@@ -41,7 +41,7 @@ class ScanBwdArgs(C.Structure):
                 + [(n, _i64) for n in ("workspace_bytes", "u_bs", "u_ds", "delta_bs", "delta_ds", "z_bs", "z_ds", "B_bs",
                                        "B_ns", "C_bs", "C_ns", "dout_bs", "dout_ds", "out_bs", "out_ds", "du_bs", "du_ds",
                                        "ddelta_bs", "ddelta_ds", "dz_bs", "dz_ds", "dB_bs", "dB_ns", "dC_bs", "dC_ns")]
-                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32)])
+                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32), ("x_ck", _vp)])
 
 
 class ConvArgs(C.Structure):
@@ -79,7 +79,7 @@ class ProjWArgs(C.Structure):
 
 
 EXPORTS = ["aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
-           "aum_selective_scan_workspace_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
+           "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy"]
 
 
@@ -106,7 +106,9 @@ class Lib:
         self.c.aum_proj_bwd_weight_splits.argtypes = [_i32, _i64]
         self.c.aum_selftest_wave_scan.argtypes = [_vp, _vp, C.c_int, _vp]
         self.c.aum_hbm_copy.argtypes = [_vp, _vp, _i64, _vp]
-        assert self.c.aum_abi_version() == 1
+        self.c.aum_selective_scan_ckpt_bytes.restype = _i64
+        self.c.aum_selective_scan_ckpt_bytes.argtypes = [_i32] * 4
+        assert self.c.aum_abi_version() == 2
         self.max_single_pass_len = int(self.c.aum_scan_max_single_pass_len())
 
     def stream(self, t):
@@ -206,9 +208,23 @@ def _alloc(batch, dim, length, dtype, device, dmajor):
     return torch.empty((batch, dim, length), dtype=dtype, device=device)
 
 
+def scan_ckpt(u, dstate, lib=None):
+    """An empty `x` checkpoint tensor (batch, dim, len/512, dstate) fp32 for rows the chunked kernels take (long-form clips,
+    L = 512 m + 1), else None.  Pass it as x_ck to scan_fwd (filled) and then to scan_bwd of the same direction (which then
+    skips its pre-pass); not with generic=/rowpair=."""
+    lib = lib or get()
+    batch, dim, length = u.shape
+    if os.environ.get('AUM_SCAN_ROWPAIR') == '1' or os.environ.get('AUM_SCAN_NO_CKPT') == '1':
+        return None
+    if lib.c.aum_selective_scan_ckpt_bytes(batch, dim, length, dstate) <= 0:
+        return None
+    return torch.empty((batch, dim, length // 512, dstate), dtype=torch.float32, device=u.device)
+
+
 def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, reverse=False, A_b=None,
-             want_out_pre=False, want_last_state=False, dmajor=False, generic=False, rowpair=False, lib=None):
-    """selective_scan_cuda.fwd.  Returns (out, out_pre|None, last_state|None).  A_b != None: fused bidirectional."""
+             want_out_pre=False, want_last_state=False, dmajor=False, generic=False, rowpair=False, x_ck=None, lib=None):
+    """selective_scan_cuda.fwd.  Returns (out, out_pre|None, last_state|None).  A_b != None: fused bidirectional.
+    x_ck: a scan_ckpt() tensor to fill."""
     lib = lib or get()
     B, C = _bc3(B), _bc3(C)
     for n, t in (("u", u), ("delta", delta), ("z", z), ("B", B), ("C", C)):
@@ -228,6 +244,10 @@ def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     a.u, a.delta, a.z, a.B, a.C = _ptr(u), _ptr(delta), _ptr(z), _ptr(B), _ptr(C)
     a.A, a.A_b, a.D, a.delta_bias = _ptr(A), _ptr(A_b), _ptr(D), _ptr(delta_bias)
     a.out, a.out_pre, a.last_state = _ptr(out), _ptr(out_pre), _ptr(last)
+    if x_ck is not None:
+        assert x_ck.dtype == torch.float32 and x_ck.is_contiguous() and x_ck.shape == (batch, dim, length // 512, dstate)
+        lib.check_tensor(x_ck)
+        a.x_ck = _ptr(x_ck)
     a.u_bs, a.u_ds = u.stride(0), u.stride(1)
     a.delta_bs, a.delta_ds = delta.stride(0), delta.stride(1)
     if z is not None:
@@ -249,7 +269,7 @@ def C_byref(s):
 
 
 def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=False, reverse=False, A_b=None,
-             dz_out=None, dmajor=False, generic=False, rowpair=False, lib=None):
+             dz_out=None, dmajor=False, generic=False, rowpair=False, x_ck=None, lib=None):
     """selective_scan_cuda.bwd.  Returns dict(du, ddelta, dA, dA_b, dB, dC, dD, dz, ddelta_bias); dB/dC fp32
     (batch, dstate, len).  dz_out: optional preallocated (possibly strided) tensor written in place (SSI:537-545)."""
     lib = lib or get()
@@ -287,6 +307,9 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=
     a.du, a.ddelta, a.dz = _ptr(du), _ptr(ddelta), _ptr(dz)
     a.dA, a.dA_b, a.dB, a.dC, a.dD, a.ddelta_bias = map(_ptr, (dA, dA_b, dB, dC, dD, dbias))
     a.workspace, a.workspace_bytes = _ptr(ws), ws_bytes
+    if x_ck is not None:
+        assert x_ck.dtype == torch.float32 and x_ck.is_contiguous() and x_ck.shape == (batch, dim, length // 512, dstate)
+        a.x_ck = _ptr(x_ck)
     a.u_bs, a.u_ds = u.stride(0), u.stride(1)
     a.delta_bs, a.delta_ds = delta.stride(0), delta.stride(1)
     if z is not None:

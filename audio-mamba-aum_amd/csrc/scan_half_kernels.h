@@ -365,7 +365,8 @@ AUM_DEV void scanh_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_per
 // Same one-row lane layout, 512 main steps per chunk; the single tail step belongs to the last chunk (an identity slot in
 // the others).  Opposite carries make direction fusion impossible here: the states enter a chunk from the scan side, the
 // adjoint from the other side, so the host issues one launch per direction (as it does for the row-pair kernels).
-//   pre-pass   chunks in scan order: lane totals only -> state entering every chunk (workspace `xck`, carry in LDS)
+//   pre-pass   chunks in scan order: lane totals only -> state entering every chunk (workspace `xck`, carry in LDS);
+//              skipped when the caller hands in the forward's checkpoint (`x_ck`, written by scanwg_fwd_ct)
 //   main pass  chunks in adjoint order: states + adjoint with carries, per-chunk du / ddelta / dz, dB/dC tile per chunk
 // dA / dD / ddelta_bias partials of a row accumulate in their workspace slot across chunks (same wave every time).
 // 128 VGPRs -> 16 waves, 64 rows per workgroup, rotation offset 1 with a barrier after every state step.
@@ -457,8 +458,9 @@ AUM_DEV void scanh_bwd_chunked(const AumScanBwdArgs& p, int wg, float* lds, int 
         for (int i0 = w * WAVE; i0 < 2 * SCANH_CH_ROWS * SCANWG_MAX_N; i0 += NW * WAVE) lds_write(xcarry, lane_id() + i0, splat(0.f));
     }
     AUM_WG_BARRIER();
-    // ---- pre-pass: state entering every chunk, chunks in scan order ----
-    for (int ci = 0; ci < nchunks; ++ci) {
+    // ---- pre-pass: state entering every chunk, chunks in scan order (skipped when the forward's checkpoint is handed in) ----
+    const float* ckpt = (TAIL > 0) ? p.x_ck : nullptr;
+    for (int ci = 0; ci < (ckpt ? 0 : nchunks); ++ci) {
         const int c = REV0 ? nchunks - 1 - ci : ci;
         const int base = c * CS;
         const bool has_tail = TAIL > 0 && c == nchunks - 1;
@@ -583,7 +585,8 @@ AUM_DEV void scanh_bwd_chunked(const AumScanBwdArgs& p, int wg, float* lds, int 
                         }
                         const vf Bn8 = lds_read(Bt, pos8 + n * GE::SP), Cn8 = lds_read(Ct, pos8 + n * GE::SP);
                         const float Araw = p.A[(int64_t)ec * N + n];
-                        const vf xcin = gload_coherent(xck + rl * xck_row_stride + (int64_t)c * N + n, spl_i(0), lane >= 0);
+                        const vf xcin = ckpt ? gload_coherent(ckpt + (((int64_t)b * p.dim + ec) * nchunks + c) * N + n, spl_i(0), lane >= 0)
+                                             : gload_coherent(xck + rl * xck_row_stride + (int64_t)c * N + n, spl_i(0), lane >= 0);
                         const vf gcin = lds_read(gcarry, spl_i(rl * SCANWG_MAX_N + n));
                         const vf a_edge = vexp2(dnf * (Araw * LOG2E));
                         vf gcout;

@@ -466,6 +466,15 @@ AUM_DEV void scanwg_fwd_ct(const AumScanFwdArgs& p, int wg, float* lds, int rows
                                              e0, p.dim, base, len_eff, t, valid, dl, dlu, sumd);
                 AUM_UNROLL
                 for (int k = 0; k < KT; ++k) y[k] = spl2(splat(0.f));
+                if (CT && p.x_ck) {      // checkpoint: the state entering this chunk, lanes 0..N-1 <- states of the pair's two rows
+                    const vi ln = lane_id() & (SCANWG_MAX_N - 1);
+                    const vm mn = (lane_id() < SCANWG_MAX_N) && (ln < N);
+                    AUM_UNROLL
+                    for (int r = 0; r < SCAN_R; ++r)
+                        if (e0 + r < p.dim)
+                            gstore(p.x_ck + (((int64_t)b * p.dim + e0 + r) * nchunks + c) * N, vmin_i(ln, N - 1),
+                                   lds_read(carry, ln + (rloc + r) * SCANWG_MAX_N), mn);
+                }
                 const bool wl = (ci == nchunks - 1) && p.last_state != nullptr;
                 if (!(p.flags & AUM_DBG_SKIP_STATES)) {
                     if (MODE == 0 || BI)

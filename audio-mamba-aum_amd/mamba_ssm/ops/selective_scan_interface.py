@@ -214,21 +214,24 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     need_bwd = any(ctx.needs_input_grad)
     bidir_fused = A_b is not None and L <= aum_hip.get().max_single_pass_len
     if A_b is None or bidir_fused:
+        ck_f = aum_hip.scan_ckpt(conv_out, A.shape[1]) if need_bwd and A_b is None else None    # long one-direction rows only
         out_z, out_pre, _ = aum_hip.scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, reverse,
-                                             A_b=A_b, want_out_pre=need_bwd, dmajor=True)        # SSI:499-507, one launch
-        out_pre_b = None
-    else:   # long rows: two reverse-flag launches, still no flip copies
+                                             A_b=A_b, want_out_pre=need_bwd, dmajor=True, x_ck=ck_f)   # SSI:499-507, one launch
+        out_pre_b = ck_b = None
+    else:   # long rows: two reverse-flag launches, still no flip copies; the chunked kernels checkpoint the chunk-entry states
+        ck_f = aum_hip.scan_ckpt(conv_out, A.shape[1]) if need_bwd else None
+        ck_b = aum_hip.scan_ckpt(conv_out, A.shape[1]) if need_bwd else None
         of, out_pre, _ = aum_hip.scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, False,
-                                          want_out_pre=need_bwd, dmajor=True)
+                                          want_out_pre=need_bwd, dmajor=True, x_ck=ck_f)
         ob, out_pre_b, _ = aum_hip.scan_fwd(conv_out, delta, A_b, Bm, Cm, D, z, delta_bias, delta_softplus, True,
-                                            want_out_pre=need_bwd, dmajor=True)
+                                            want_out_pre=need_bwd, dmajor=True, x_ck=ck_b)
         out_z = of + ob
     ctx.delta_softplus, ctx.reverse, ctx.bidir_fused = delta_softplus, reverse, bidir_fused
     ctx.has_out_proj = out_proj_weight is not None
     ctx.out_proj_bias_is_None = out_proj_bias is None
     ctx.B_proj_bias_is_None, ctx.C_proj_bias_is_None = B_proj_bias is None, C_proj_bias is None
     ctx.save_for_backward(xz, conv_w, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight,
-                          conv_out, delta, A, A_b, Bm, Cm, D, delta_bias, out_pre, out_pre_b, out_z)
+                          conv_out, delta, A, A_b, Bm, Cm, D, delta_bias, out_pre, out_pre_b, out_z, ck_f, ck_b)
     if out_proj_weight is None:
         return out_z                                                                          # SSI:224
     out = torch.matmul(_dm2d(out_z).t(), out_proj_weight.t())                                 # SSI:517
@@ -239,7 +242,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
 
 def _inner_backward(ctx, dout):
     (xz, conv_w, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, A_b, Bm,
-     Cm, D, delta_bias, out_pre, out_pre_b, out_z) = ctx.saved_tensors
+     Cm, D, delta_bias, out_pre, out_pre_b, out_z, ck_f, ck_b) = ctx.saved_tensors
     Bsz, two_e, L = xz.shape
     E = two_e // 2
     R = delta_proj_weight.shape[1]
@@ -259,12 +262,12 @@ def _inner_backward(ctx, dout):
     drop = os.environ.get("AUM_REF_DZ_DROP", "0") == "1" and A_b is not None
     if A_b is None or ctx.bidir_fused:
         g = aum_hip.scan_bwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_z, out_pre, ctx.delta_softplus,
-                             ctx.reverse, A_b=A_b, dz_out=dz, dmajor=True)                   # SSI:541-561, one launch
+                             ctx.reverse, A_b=A_b, dz_out=dz, dmajor=True, x_ck=ck_f)        # SSI:541-561, one launch
     else:
         g = aum_hip.scan_bwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_z, out_pre, ctx.delta_softplus, False,
-                             dz_out=dz, dmajor=True)
+                             dz_out=dz, dmajor=True, x_ck=ck_f)
         gb = aum_hip.scan_bwd(conv_out, delta, A_b, Bm, Cm, D, z, delta_bias, dout_z, out_pre_b, ctx.delta_softplus,
-                              True, dmajor=True)
+                              True, dmajor=True, x_ck=ck_b)
         for k in ("du", "ddelta", "dB", "dC", "dD", "ddelta_bias"):
             g[k] = g[k] + gb[k]
         if not drop:

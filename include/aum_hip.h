@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AUM_ABI_VERSION 1
+#define AUM_ABI_VERSION 2   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 
@@ -64,6 +64,10 @@ enum {
  * copies.  z == NULL: no gate.  out_pre (optional) receives the pre-gate value y + D*u summed over directions (what
  * the reference saves as `out` / `out_f`,`out_b` for the backward's dz).
  * workspace: unused by the forward (kept for ABI symmetry).
+ * x_ck (optional, output): the `x` checkpoint tensor of selective_scan_cuda.fwd in this library's chunking -- the state
+ * entering every 512-step chunk in scan order, (batch, dim, len/512, dstate) fp32.  Only rows the chunked kernels take
+ * (aum_selective_scan_ckpt_bytes(...) > 0, one direction, neither AUM_SCAN_GENERIC nor AUM_SCAN_ROWPAIR) have one;
+ * passing it for any other call is AUM_E_UNSUPPORTED.  Handed to the backward it replaces the backward's own pre-pass.
  */
 typedef struct AumScanFwdArgs {
     const void *u, *delta, *z, *B, *C;
@@ -81,6 +85,7 @@ typedef struct AumScanFwdArgs {
     int32_t batch, dim, len, dstate;
     int32_t dtype;
     uint32_t flags;
+    float *x_ck;                /* ABI 2 */
 } AumScanFwdArgs;
 
 /*
@@ -108,6 +113,7 @@ typedef struct AumScanBwdArgs {
     int32_t batch, dim, len, dstate;
     int32_t dtype;
     uint32_t flags;
+    const float *x_ck;          /* ABI 2: the forward's checkpoint of the same call shape and direction, or NULL */
 } AumScanBwdArgs;
 
 int aum_selective_scan_fwd(const AumScanFwdArgs* args, void* stream);
@@ -116,6 +122,8 @@ int aum_selective_scan_bwd(const AumScanBwdArgs* args, void* stream);
 int aum_scan_max_single_pass_len(void);
 int64_t aum_selective_scan_workspace_bytes(int32_t batch, int32_t dim, int32_t len, int32_t dstate, int32_t bidirectional,
                                            int32_t backward);
+/* bytes of the x_ck checkpoint for this shape (one direction), 0 when the shape has none */
+int64_t aum_selective_scan_ckpt_bytes(int32_t batch, int32_t dim, int32_t len, int32_t dstate);
 
 /*
  * Depthwise causal conv1d + bias + SiLU (causal_conv1d_cuda.causal_conv1d_fwd / _bwd).

@@ -55,6 +55,20 @@ def test_scan_chunked_one_row_backward(emu, case, mode):
         KC.check_scan(emu, "cpu", case, torch.float32, reverse=(mode == "rev"), rowpair=rowpair)
     KC.check_scan(emu, "cpu", case, torch.bfloat16, reverse=(mode == "rev"))
     KC.check_scan(emu, "cpu", case, torch.float32, reverse=(mode == "rev"), strided=True)
+    if case[3] % 512 == 1:      # rows with a checkpoint: the backward reads the forward's chunk-entry states instead of its pre-pass
+        KC.check_scan(emu, "cpu", case, torch.float32, reverse=(mode == "rev"), ckpt=True)
+        KC.check_scan(emu, "cpu", case, torch.bfloat16, reverse=(mode == "rev"), ckpt=True, strided=True)
+
+
+def test_scan_checkpoint_contract(emu):
+    """x_ck exists only for rows the chunked kernels take; handing one to any other call is refused, not ignored"""
+    u = torch.zeros(2, 4, 513)
+    assert aum_hip.scan_ckpt(u, 16, lib=emu) is None and aum_hip.scan_ckpt(torch.zeros(2, 4, 1024), 16, lib=emu) is None
+    ck = aum_hip.scan_ckpt(torch.zeros(1, 4, 2049), 16, lib=emu)
+    assert ck.shape == (1, 4, 4, 16) and emu.c.aum_selective_scan_ckpt_bytes(1, 4, 2049, 16) == ck.numel() * 4
+    case = [c for c in cases.SCAN_CASES if c[0] == "l2049"][0]
+    with pytest.raises(RuntimeError):
+        KC.check_scan(emu, "cpu", case, torch.float32, ckpt=True, rowpair=True)
 
 
 def test_scan_chunked_one_row_backward_row_groupings(emu, monkeypatch):

@@ -56,6 +56,8 @@ def test_scan_chunked_one_row_backward(lib, case, mode, dtype):
     for rowpair in (False, True):
         KC.check_scan(lib, "cuda", case, dtype, reverse=(mode == "rev"), rowpair=rowpair)
     KC.check_scan(lib, "cuda", case, dtype, reverse=(mode == "rev"), strided=True)
+    if case[3] % 512 == 1:
+        KC.check_scan(lib, "cuda", case, dtype, reverse=(mode == "rev"), ckpt=True)
 
 
 def test_scan_long_form_full_size(lib):
@@ -74,11 +76,16 @@ def test_scan_long_form_full_size(lib):
         _, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, reverse, want_out_pre=True, lib=lib)
         g = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, reverse, lib=lib)
         g2 = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, reverse, lib=lib)
+        ck = aum_hip.scan_ckpt(u, N, lib=lib)
+        aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, reverse, want_out_pre=True, x_ck=ck, lib=lib)
+        gc = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, reverse, x_ck=ck, lib=lib)
         gp = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, reverse, rowpair=True, lib=lib)
         for k, v in g.items():
             if v is None:
                 continue
             assert torch.equal(v, g2[k]), (reverse, k)
+            c = gc[k].float()      # the forward's checkpoint and the backward's pre-pass hold the same states up to rounding
+            assert (c - v.float()).abs().max() <= 5e-3 * v.float().abs().max() + 1e-6, ("checkpoint", reverse, k)
             a, b = v.float(), gp[k].float()
             assert (a - b).abs().max() <= 2e-2 * b.abs().max() + 1e-6, (reverse, k, float((a - b).abs().max()), float(b.abs().max()))
 
