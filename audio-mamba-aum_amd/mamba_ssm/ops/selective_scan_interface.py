@@ -46,10 +46,12 @@ class SelectiveScanFn(torch.autograd.Function):
         fix = lambda t: t if t is None or t.stride(-1) == 1 else t.contiguous()      # SSI:19-30
         u, delta, B, C, z = fix(u), fix(delta), fix(B), fix(C), fix(z)
         ctx.squeeze_B, ctx.squeeze_C = B.dim() == 3, C.dim() == 3
+        # long-form rows: the `x` checkpoint of SSI:37-45 (chunk-entry states), kept for the backward
+        x_ck = aum_hip.scan_ckpt(u, A.shape[1]) if any(ctx.needs_input_grad) else None
         out, out_pre, last = aum_hip.scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, reverse,
-                                              want_out_pre=z is not None, want_last_state=return_last_state)
+                                              want_out_pre=z is not None, want_last_state=return_last_state, x_ck=x_ck)
         ctx.delta_softplus, ctx.reverse, ctx.has_z = delta_softplus, reverse, z is not None
-        ctx.save_for_backward(u, delta, A, B, C, D, z, delta_bias, out_pre)
+        ctx.save_for_backward(u, delta, A, B, C, D, z, delta_bias, out_pre, x_ck)
         if return_last_state:
             ctx.mark_non_differentiable(last)       # SSI:79-82: no gradient through last_state
             return out, last
@@ -57,11 +59,11 @@ class SelectiveScanFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, *args):
-        u, delta, A, B, C, D, z, delta_bias, out_pre = ctx.saved_tensors
+        u, delta, A, B, C, D, z, delta_bias, out_pre, x_ck = ctx.saved_tensors
         if dout.stride(-1) != 1:
             dout = dout.contiguous()
         g = aum_hip.scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout.to(u.dtype), out_pre, ctx.delta_softplus,
-                             ctx.reverse)
+                             ctx.reverse, x_ck=x_ck)
         dB = g["dB"].to(B.dtype)
         dC = g["dC"].to(C.dtype)
         if not ctx.squeeze_B:
