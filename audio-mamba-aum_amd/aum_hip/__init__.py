@@ -211,7 +211,7 @@ def _alloc(batch, dim, length, dtype, device, dmajor):
 def scan_ckpt(u, dstate, lib=None):
     """An empty `x` checkpoint tensor (batch, dim, len/512, dstate) fp32 for rows the chunked kernels take (long-form clips,
     L = 512 m + 1), else None.  Pass it as x_ck to scan_fwd (filled) and then to scan_bwd of the same direction (which then
-    skips its pre-pass); not with generic=/rowpair=."""
+    skips its pre-pass); not with generic=/rowpair=.  AUM_SCAN_NO_CKPT=1 (A/B runs) or AUM_SCAN_ROWPAIR=1: no checkpoint."""
     lib = lib or get()
     batch, dim, length = u.shape
     if os.environ.get('AUM_SCAN_ROWPAIR') == '1' or os.environ.get('AUM_SCAN_NO_CKPT') == '1':
