@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libaum_hip.so")
 
 AUM_F32, AUM_BF16, AUM_F16 = 0, 1, 2
-SCAN_SOFTPLUS, SCAN_REVERSE, SCAN_GENERIC = 1, 2, 4
+SCAN_SOFTPLUS, SCAN_REVERSE, SCAN_GENERIC, SCAN_ROWPAIR, SCAN_ACCUMULATE = 1, 2, 4, 8, 16
 CONV_SILU, CONV_REVERSE = 1, 2
 _DT = {torch.float32: AUM_F32, torch.bfloat16: AUM_BF16, torch.float16: AUM_F16}
 _ERR = {-1: "AUM_E_NULL", -2: "AUM_E_SHAPE", -3: "AUM_E_DTYPE", -4: "AUM_E_UNSUPPORTED", -5: "AUM_E_WORKSPACE",
@@ -221,10 +221,22 @@ def scan_ckpt(u, dstate, lib=None):
     return torch.empty((batch, dim, length // 512, dstate), dtype=torch.float32, device=u.device)
 
 
+def scan_accumulates(u, dstate, lib=None):
+    """True when a second-direction call on this shape can add to the first one's tensors (accumulate_into=): the rows the
+    chunked kernels take, i.e. exactly when scan_ckpt() gives a checkpoint."""
+    lib = lib or get()
+    batch, dim, length = u.shape
+    if os.environ.get('AUM_SCAN_ROWPAIR') == '1' or os.environ.get('AUM_SCAN_NO_ACCUMULATE') == '1':
+        return False
+    return lib.c.aum_selective_scan_ckpt_bytes(batch, dim, length, dstate) > 0
+
+
 def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, reverse=False, A_b=None,
-             want_out_pre=False, want_last_state=False, dmajor=False, generic=False, rowpair=False, x_ck=None, lib=None):
+             want_out_pre=False, want_last_state=False, dmajor=False, generic=False, rowpair=False, x_ck=None,
+             accumulate_into=None, lib=None):
     """selective_scan_cuda.fwd.  Returns (out, out_pre|None, last_state|None).  A_b != None: fused bidirectional.
-    x_ck: a scan_ckpt() tensor to fill."""
+    x_ck: a scan_ckpt() tensor to fill.  accumulate_into: the `out` of the other direction's call (long rows only, see
+    scan_accumulates): this call adds to it and returns it."""
     lib = lib or get()
     B, C = _bc3(B), _bc3(C)
     for n, t in (("u", u), ("delta", delta), ("z", z), ("B", B), ("C", C)):
@@ -237,7 +249,8 @@ def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     if A.shape != (dim, dstate) or B.shape != (batch, dstate, length) or C.shape != B.shape:
         raise RuntimeError("shape mismatch in selective scan arguments")
     A, A_b, D, delta_bias = _f32c(A), _f32c(A_b), _f32c(D), _f32c(delta_bias)
-    out = _alloc(batch, dim, length, u.dtype, u.device, dmajor)
+    out = accumulate_into if accumulate_into is not None else _alloc(batch, dim, length, u.dtype, u.device, dmajor)
+    assert out.shape == u.shape and out.dtype == u.dtype and out.stride(2) == 1
     out_pre = _alloc(batch, dim, length, u.dtype, u.device, dmajor) if want_out_pre else None
     last = torch.empty((batch, dim, dstate), dtype=torch.float32, device=u.device) if want_last_state else None
     a = ScanFwdArgs()
@@ -257,7 +270,8 @@ def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     a.out_bs, a.out_ds = out.stride(0), out.stride(1)
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
     a.flags = ((SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0) | (SCAN_GENERIC if generic else 0)
-               | (8 if rowpair or os.environ.get('AUM_SCAN_ROWPAIR') == '1' else 0)
+               | (SCAN_ROWPAIR if rowpair or os.environ.get('AUM_SCAN_ROWPAIR') == '1' else 0)
+               | (SCAN_ACCUMULATE if accumulate_into is not None else 0)
                | (int(os.environ.get('AUM_ABLATE', '0')) << 16))   # AUM_ABLATE: kernel-ablation bits for tools/kbench.py only
     _launch(lib.c.aum_selective_scan_fwd, a, u, lib, "scan_fwd_bidir" if A_b is not None else "scan_fwd",
             (batch, dim, length, dstate, u.element_size(), want_out_pre))
@@ -269,9 +283,11 @@ def C_byref(s):
 
 
 def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=False, reverse=False, A_b=None,
-             dz_out=None, dmajor=False, generic=False, rowpair=False, x_ck=None, lib=None):
+             dz_out=None, dmajor=False, generic=False, rowpair=False, x_ck=None, accumulate_into=None, lib=None):
     """selective_scan_cuda.bwd.  Returns dict(du, ddelta, dA, dA_b, dB, dC, dD, dz, ddelta_bias); dB/dC fp32
-    (batch, dstate, len).  dz_out: optional preallocated (possibly strided) tensor written in place (SSI:537-545)."""
+    (batch, dstate, len).  dz_out: optional preallocated (possibly strided) tensor written in place (SSI:537-545).
+    accumulate_into: the dict the other direction's call returned (long rows only, see scan_accumulates): this call adds its
+    du, ddelta, dz, dB, dC, dD, ddelta_bias to those tensors and returns them, with its own dA."""
     lib = lib or get()
     B, C = _bc3(B), _bc3(C)
     for n, t in (("u", u), ("delta", delta), ("z", z), ("B", B), ("C", C), ("dout", dout), ("out_pre", out_pre)):
@@ -281,24 +297,29 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=
     dstate = A.shape[1]
     dev = u.device
     A, A_b, D, delta_bias = _f32c(A), _f32c(A_b), _f32c(D), _f32c(delta_bias)
-    du = _alloc(batch, dim, length, u.dtype, dev, dmajor)
-    ddelta = _alloc(batch, dim, length, u.dtype, dev, dmajor)
+    acc = accumulate_into
+    du = acc["du"] if acc else _alloc(batch, dim, length, u.dtype, dev, dmajor)
+    ddelta = acc["ddelta"] if acc else _alloc(batch, dim, length, u.dtype, dev, dmajor)
     dz = None
     if z is not None:
-        dz = dz_out if dz_out is not None else _alloc(batch, dim, length, u.dtype, dev, dmajor)
+        dz = acc["dz"] if acc else dz_out if dz_out is not None else _alloc(batch, dim, length, u.dtype, dev, dmajor)
         _unit(dz, "dz")
     f32 = dict(dtype=torch.float32, device=dev)
     # one zero-fill for all accumulate-into outputs (dA, dA_b, dD, ddelta_bias, dB, dC) instead of six
     nA, nBC = dim * dstate, batch * dstate * length
-    sizes = [nA, nA if A_b is not None else 0, dim if D is not None else 0, dim if delta_bias is not None else 0, nBC, nBC]
+    sizes = [nA, nA if A_b is not None else 0, dim if D is not None and not acc else 0,
+             dim if delta_bias is not None and not acc else 0, 0 if acc else nBC, 0 if acc else nBC]
     zbuf = torch.zeros((sum(sizes),), **f32)
     parts = torch.split(zbuf, sizes)
     dA = parts[0].view(dim, dstate)
     dA_b = parts[1].view(dim, dstate) if A_b is not None else None
     dD = parts[2] if D is not None else None
     dbias = parts[3] if delta_bias is not None else None
-    dB = parts[4].view(batch, dstate, length)
-    dC = parts[5].view(batch, dstate, length)
+    dB = parts[4].view(batch, dstate, length) if not acc else None
+    dC = parts[5].view(batch, dstate, length) if not acc else None
+    if acc:      # the reduce stage of the call adds its partial sums to what is there
+        assert A_b is None
+        dB, dC, dD, dbias = acc["dB"], acc["dC"], acc["dD"], acc["ddelta_bias"]
     ws_bytes = int(lib.c.aum_selective_scan_workspace_bytes(batch, dim, length, dstate, int(A_b is not None), 1))
     ws = torch.empty((max(ws_bytes, 4) // 4,), **f32) if ws_bytes else None
     a = ScanBwdArgs()
@@ -323,7 +344,8 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=
     a.dB_bs, a.dB_ns, a.dC_bs, a.dC_ns = dB.stride(0), dB.stride(1), dC.stride(0), dC.stride(1)
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
     a.flags = ((SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0) | (SCAN_GENERIC if generic else 0)
-               | (8 if rowpair or os.environ.get('AUM_SCAN_ROWPAIR') == '1' else 0)
+               | (SCAN_ROWPAIR if rowpair or os.environ.get('AUM_SCAN_ROWPAIR') == '1' else 0)
+               | (SCAN_ACCUMULATE if acc else 0)
                | (int(os.environ.get('AUM_ABLATE', '0')) << 16))   # AUM_ABLATE: kernel-ablation bits for tools/kbench.py only
     _launch(lib.c.aum_selective_scan_bwd, a, u, lib, "scan_bwd_bidir" if A_b is not None else "scan_bwd",
             (batch, dim, length, dstate, u.element_size(), True))

@@ -448,6 +448,7 @@ AUM_DEV void scanh_bwd_chunked(const AumScanBwdArgs& p, int wg, float* lds, int 
     const int b = wg / L.gpb, g_idx = wg % L.gpb;
     const int eb = g_idx * rows_per_wg;
     const bool softplus = (p.flags & AUM_SCAN_SOFTPLUS) != 0;
+    const bool accumulate = (p.flags & AUM_SCAN_ACCUMULATE) != 0;
     const T* Bsrc = row_ptr<T>(p.B, (int64_t)b * p.B_bs);
     const T* Csrc = row_ptr<T>(p.C, (int64_t)b * p.C_bs);
     const int64_t xck_row_stride = (int64_t)nchunks * N;
@@ -555,8 +556,18 @@ AUM_DEV void scanh_bwd_chunked(const AumScanBwdArgs& p, int wg, float* lds, int 
                         const vf sg = vsigmoid(z8);
                         dz8 = go8 * yp8 * sg * vfma(z8, splat(1.f) - sg, splat(1.f));
                         go8 = go8 * z8 * sg;
-                        if (active)
-                            scanh_chunk_write<T>(row_ptr_w<T>(p.dz, (int64_t)b * p.dz_bs + (int64_t)ec * p.dz_ds) + base, has_tail, dzv, dz8);
+                        if (active) {
+                            T* dzp = row_ptr_w<T>(p.dz, (int64_t)b * p.dz_bs + (int64_t)ec * p.dz_ds) + base;
+                            if (accumulate) {
+                                vf2 pv[4];
+                                vf pv8;
+                                scanh_chunk_read<T>(dzp, has_tail, pv, pv8);
+                                AUM_UNROLL
+                                for (int i = 0; i < 4; ++i) dzv[i] = dzv[i] + pv[i];
+                                dz8 = dz8 + pv8;
+                            }
+                            scanh_chunk_write<T>(dzp, has_tail, dzv, dz8);
+                        }
                     }
                     AUM_UNROLL
                     for (int i = 0; i < 4; ++i) dy[i] = go[i];
@@ -645,8 +656,23 @@ AUM_DEV void scanh_bwd_chunked(const AumScanBwdArgs& p, int wg, float* lds, int 
                     }
                     dd8 = vsel(tail_lane, dd8, splat(0.f));
                     du8 = vsel(tail_lane, du8, splat(0.f));
-                    scanh_chunk_write<T>(row_ptr_w<T>(p.du, (int64_t)b * p.du_bs + (int64_t)e * p.du_ds) + base, has_tail, duv, du8);
-                    scanh_chunk_write<T>(row_ptr_w<T>(p.ddelta, (int64_t)b * p.ddelta_bs + (int64_t)e * p.ddelta_ds) + base, has_tail, ddv, dd8);
+                    T* dup = row_ptr_w<T>(p.du, (int64_t)b * p.du_bs + (int64_t)e * p.du_ds) + base;
+                    T* ddp = row_ptr_w<T>(p.ddelta, (int64_t)b * p.ddelta_bs + (int64_t)e * p.ddelta_ds) + base;
+                    vf du8s = du8, dd8s = dd8;      // stored values; dd8 itself still feeds the ddelta_bias partial below
+                    if (accumulate) {       // second direction: lands on the first one's gradients
+                        vf2 pv[4];
+                        vf pv8;
+                        scanh_chunk_read<T>(dup, has_tail, pv, pv8);
+                        AUM_UNROLL
+                        for (int i = 0; i < 4; ++i) duv[i] = duv[i] + pv[i];
+                        du8s = du8s + pv8;
+                        scanh_chunk_read<T>(ddp, has_tail, pv, pv8);
+                        AUM_UNROLL
+                        for (int i = 0; i < 4; ++i) ddv[i] = ddv[i] + pv[i];
+                        dd8s = dd8s + pv8;
+                    }
+                    scanh_chunk_write<T>(dup, has_tail, duv, du8s);
+                    scanh_chunk_write<T>(ddp, has_tail, ddv, dd8s);
                     float sD = wave_sum(vfma(dy8, u8, lo2(dDl) + hi2(dDl)));
                     float sb = wave_sum(lo2(dbl) + hi2(dbl) + dd8);
                     float* slotD = ws + L.pD + (int64_t)b * p.dim + e;

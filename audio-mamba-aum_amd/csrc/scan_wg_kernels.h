@@ -511,6 +511,12 @@ AUM_DEV void scanwg_fwd_ct(const AumScanFwdArgs& p, int wg, float* lds, int rows
                             AUM_UNROLL
                             for (int k = 0; k < KT; ++k) o[k] = o[k] * (zz[k] * vsigmoid(zz[k]));
                         }
+                        if (p.flags & AUM_SCAN_ACCUMULATE) {     // second direction: lands on the first one's output
+                            vf prev[KT];
+                            scan_row_read<T, K, TAIL>(row_ptr<T>(p.out, ooff), base, len_eff, t, valid, prev);
+                            AUM_UNROLL
+                            for (int k = 0; k < KT; ++k) o[k] = o[k] + prev[k];
+                        }
                         scan_row_write<T, K, TAIL>(row_ptr_w<T>(p.out, ooff), base, len_eff, t, valid, o);
                     }
                 }

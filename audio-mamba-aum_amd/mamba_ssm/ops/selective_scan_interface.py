@@ -225,9 +225,10 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
         ck_b = aum_hip.scan_ckpt(conv_out, A.shape[1]) if need_bwd else None
         of, out_pre, _ = aum_hip.scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, False,
                                           want_out_pre=need_bwd, dmajor=True, x_ck=ck_f)
+        acc = aum_hip.scan_accumulates(conv_out, A.shape[1])      # the reverse launch adds to the forward launch's output
         ob, out_pre_b, _ = aum_hip.scan_fwd(conv_out, delta, A_b, Bm, Cm, D, z, delta_bias, delta_softplus, True,
-                                            want_out_pre=need_bwd, dmajor=True, x_ck=ck_b)
-        out_z = of + ob
+                                            want_out_pre=need_bwd, dmajor=True, x_ck=ck_b, accumulate_into=of if acc else None)
+        out_z = ob if acc else of + ob
     ctx.delta_softplus, ctx.reverse, ctx.bidir_fused = delta_softplus, reverse, bidir_fused
     ctx.has_out_proj = out_proj_weight is not None
     ctx.out_proj_bias_is_None = out_proj_bias is None
@@ -268,12 +269,14 @@ def _inner_backward(ctx, dout):
     else:
         g = aum_hip.scan_bwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_z, out_pre, ctx.delta_softplus, False,
                              dz_out=dz, dmajor=True, x_ck=ck_f)
+        acc = not drop and aum_hip.scan_accumulates(conv_out, A.shape[1])   # SSI:554-559 inside the reverse launch
         gb = aum_hip.scan_bwd(conv_out, delta, A_b, Bm, Cm, D, z, delta_bias, dout_z, out_pre_b, ctx.delta_softplus,
-                              True, dmajor=True, x_ck=ck_b)
-        for k in ("du", "ddelta", "dB", "dC", "dD", "ddelta_bias"):
-            g[k] = g[k] + gb[k]
-        if not drop:
-            dz.add_(gb["dz"])
+                              True, dmajor=True, x_ck=ck_b, accumulate_into=g if acc else None)
+        if not acc:
+            for k in ("du", "ddelta", "dB", "dC", "dD", "ddelta_bias"):
+                g[k] = g[k] + gb[k]
+            if not drop:
+                dz.add_(gb["dz"])
         g["dA_b"] = gb["dA"]
     if drop and ctx.bidir_fused:
         # reproduce SSI:560/599 for A/B runs against a CUDA run of the reference: keep only the forward term

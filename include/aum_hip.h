@@ -49,6 +49,9 @@ enum {
 #define AUM_SCAN_ROWPAIR 8u  /* debug / A-B: keep the general row-pair kernels where a specialised one would run (one-row backward for
                                  512 + tail rows, chunked kernels for rows of 512*m + 1 steps, forward and backward) */
                              /* kernels when dstate <= 16                                                        */
+#define AUM_SCAN_ACCUMULATE 16u /* long rows (the chunked kernels; anything else: AUM_E_UNSUPPORTED): add to out (forward) / du, ddelta, dz
+                                  (backward) instead of overwriting them -- the second direction of a bidirectional layer lands on
+                                  the first one's tensors, replacing the element-wise sums of selective_scan_interface.py:507,554-559 */
 #define AUM_CONV_SILU 1u
 #define AUM_CONV_REVERSE 2u  /* anti-causal: y[l] = act(b + sum_w W[w] x[l+(W-1)-w])                            */
 #define AUM_CONV_GENERIC 4u  /* force the any-width kernel (default: the vectorised width-4 kernel when width == 4)  */

@@ -173,3 +173,40 @@ def check_proj(lib, dev, case, dtype=torch.bfloat16):
     for k, e in errs.items():
         assert e < (1e-4 if k.startswith("dw") else tol), (name, k, e, errs)
     return errs
+
+
+def check_scan_accumulate(lib, dev, case, dtype=torch.float32, tol=None):
+    """long rows: a reverse-time call with accumulate_into= lands on the forward-time call's out / du / ddelta / dz / dB / dC /
+    dD / ddelta_bias; the result must be the oracle's sum of the two directions (SSI:507, 554-559)"""
+    name, batch, dim, length, dstate, has_z, has_D, has_bias, softplus = case
+    d = cases.scan_inputs(*case)
+    tol = tol or (TOL_F32 if dtype == torch.float32 else TOL_BF16)
+    act = lambda a: T(a, dev, dtype)
+    q = {k: rq(d[k], dtype) for k in ("u", "delta", "z", "B", "C", "dout")}
+    A_b = (d["A"] * np.exp(np.random.default_rng(7).normal(0, 0.1, d["A"].shape))).astype(np.float32)
+    u, delta, z = act(d["u"]), act(d["delta"]), act(d["z"])
+    Bm, Cm = act(d["B"]).unsqueeze(1), act(d["C"]).unsqueeze(1)
+    A, Ab, D, bias = T(d["A"], dev), T(A_b, dev), T(d["D"], dev), T(d["delta_bias"], dev)
+    assert aum_hip.scan_accumulates(u, dstate, lib=lib)
+    of, pre_f, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, softplus, False, want_out_pre=True, lib=lib)
+    out, pre_b, _ = aum_hip.scan_fwd(u, delta, Ab, Bm, Cm, D, z, bias, softplus, True, want_out_pre=True, accumulate_into=of, lib=lib)
+    assert out is of
+    rf = O.scan_fwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], softplus, False, "f64")
+    rb = O.scan_fwd(q["u"], q["delta"], A_b, q["B"], q["C"], d["D"], q["z"], d["delta_bias"], softplus, True, "f64")
+    errs = {"out": rel_err(N(out), rf["out"] + rb["out"]), "out_pre_b": rel_err(N(pre_b), rb["y_pre"])}
+    dout = act(d["dout"])
+    g = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre_f if has_z else None, softplus, False, lib=lib)
+    g2 = aum_hip.scan_bwd(u, delta, Ab, Bm, Cm, D, z, bias, dout, pre_b if has_z else None, softplus, True, accumulate_into=g, lib=lib)
+    gf = O.scan_bwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus, False, "f64")
+    gb = O.scan_bwd(q["u"], q["delta"], A_b, q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus, True, "f64")
+    for k in ("du", "ddelta", "dB", "dC", "dD", "dz", "ddelta_bias"):
+        if gf.get(k) is None:
+            continue
+        assert g2[k] is g[k], k
+        errs[k] = rel_err(N(g2[k]), gf[k] + gb[k])
+    errs["dA"] = rel_err(N(g["dA"]), gf["dA"])
+    errs["dA_b"] = rel_err(N(g2["dA"]), gb["dA"])
+    bad = {k: v for k, v in errs.items() if not v < tol}
+    assert not bad, (name, str(dtype), bad)
+    return errs
+

@@ -61,6 +61,26 @@ def test_scan_chunked_one_row_backward(emu, case, mode):
         KC.check_scan(emu, "cpu", case, torch.bfloat16, reverse=(mode == "rev"), ckpt=True, strided=True)
 
 
+@pytest.mark.parametrize("case", [c for c in cases.SCAN_LONG_CASES if c[3] % 512 == 1] + [c for c in cases.SCAN_CASES if c[0] == "l2049"],
+                         ids=lambda c: c[0])
+def test_scan_second_direction_accumulates(emu, case):
+    KC.check_scan_accumulate(emu, "cpu", case, torch.float32)
+    KC.check_scan_accumulate(emu, "cpu", case, torch.bfloat16)
+
+
+def test_scan_accumulate_contract(emu):
+    """AUM_SCAN_ACCUMULATE is refused (not ignored) where the chunked kernels do not run"""
+    case = [c for c in cases.SCAN_CASES if c[0] == "l65"][0]
+    d = cases.scan_inputs(*case)
+    t = lambda a: torch.tensor(a)
+    u, delta, z = t(d["u"]), t(d["delta"]), t(d["z"])
+    Bm, Cm = t(d["B"]).unsqueeze(1), t(d["C"]).unsqueeze(1)
+    assert not aum_hip.scan_accumulates(u, 16, lib=emu)
+    of, _, _ = aum_hip.scan_fwd(u, delta, t(d["A"]), Bm, Cm, t(d["D"]), z, t(d["delta_bias"]), True, lib=emu)
+    with pytest.raises(RuntimeError):
+        aum_hip.scan_fwd(u, delta, t(d["A"]), Bm, Cm, t(d["D"]), z, t(d["delta_bias"]), True, True, accumulate_into=of, lib=emu)
+
+
 def test_scan_checkpoint_contract(emu):
     """x_ck exists only for rows the chunked kernels take; handing one to any other call is refused, not ignored"""
     u = torch.zeros(2, 4, 513)

@@ -60,6 +60,13 @@ def test_scan_chunked_one_row_backward(lib, case, mode, dtype):
         KC.check_scan(lib, "cuda", case, dtype, reverse=(mode == "rev"), ckpt=True)
 
 
+@pytest.mark.parametrize("case", [c for c in cases.SCAN_LONG_CASES if c[3] % 512 == 1] + [c for c in cases.SCAN_CASES if c[0] == "l2049"],
+                         ids=lambda c: c[0])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_second_direction_accumulates(lib, case, dtype):
+    KC.check_scan_accumulate(lib, "cuda", case, dtype)
+
+
 def test_scan_long_form_full_size(lib):
     """long-form shape (BASELINE config 5: B=2 of the 8, E=1536, L=4097, N=16, bf16, d-major rows): the chunked one-row
     backward against the row-pair kernels on the same inputs, and bitwise repeatable from launch to launch"""
