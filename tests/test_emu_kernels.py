@@ -150,7 +150,6 @@ def test_proj(emu, case):
 
 
 def test_proj_limits(emu):
-    import numpy as np
     x = torch.zeros(64, 8, dtype=torch.float32)
     assert not aum_hip.proj_supported(64, 48, 16, 8, torch.float32)
     assert not aum_hip.proj_supported(96, 48, 16, 8, torch.bfloat16)

@@ -45,7 +45,6 @@ def test_audio_mamba_vs_reference_model(case):
 
 @pytest.mark.parametrize("case", cases.INNER_CASES, ids=lambda c: c[0])
 def test_inner_fns_vs_reference(case):
-    import test_host_package as H
     g = load_golden("inner")
     name = case[0]
     import mamba_ssm.ops.selective_scan_interface as ssi

@@ -220,7 +220,6 @@ def test_mfma_projection_path_matches_library_gemm_path(btype, monkeypatch):
     module with that path switched off takes torch.matmul + explicit B/C transposes.  Outputs and every gradient
     must agree to bf16 rounding -- this pins the layout plumbing (strided B/C into the scan, dB/dC back)."""
     from mamba_ssm.modules.mamba_simple import Mamba
-    import mamba_ssm.ops.selective_scan_interface as SSI
     torch.manual_seed(5)
     m = Mamba(64, bimamba_type=btype).to(torch.bfloat16)          # d_inner 128, dt_rank 4, R + 2N = 36
     x = torch.randn(3, 37, 64).to(torch.bfloat16)

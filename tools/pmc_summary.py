@@ -4,7 +4,6 @@ launch of the hand-written kernels.  Units KiB; FETCH_SIZE is doubled for wide c
 MI355X_MICROARCH.md prescribes (calibrated on this box with a 1 GiB float4 copy: FETCH_SIZE reads 0.50 GiB)."""
 import csv
 import json
-import re
 import sys
 from collections import defaultdict
 
