@@ -25,6 +25,16 @@ namespace aum {
 // the one-direction kernels fit 128 VGPRs -> 16 waves 0.97 ms vs 12 waves 1.05 ms vs 8 waves 1.18 ms.
 AUM_HOSTDEV constexpr int scanh_nw(int mode) { return mode == 2 ? 12 : 16; }
 AUM_HOSTDEV constexpr int scanh_rows(int mode) { return mode == 2 ? 96 : 64; }      // a multiple of the wave count
+// Opt-in tile layout (-DAUM_SCANH_PAIRED=1, off until measured on the GPU): a lane's steps i and 4+i adjacent in the LDS tiles, so
+// the B/C reads and the dB/dC read-add-write move whole vf2 values (ds_read2_b32 / v_pk_add_f32 / ds_write2_b32) and the 12
+// v_mov_b32 per state that re-pair the default layout's (i, i+1) reads disappear ("next (0)").
+#ifndef AUM_SCANH_PAIRED
+#define AUM_SCANH_PAIRED 0
+#endif
+constexpr bool SCANH_PAIRED = AUM_SCANH_PAIRED != 0;
+// tile words of a lane's packed slot i: .x = step i, .y = step 4+i
+AUM_HOSTDEV constexpr int scanh_slot_lo(int i) { return SCANH_PAIRED ? 2 * i : i; }
+AUM_HOSTDEV constexpr int scanh_slot_hi(int i) { return SCANH_PAIRED ? 2 * i + 1 : 4 + i; }
 // state rotation of the dB/dC tile updates (see scanwg_bwd): 8 waves would use offsets 2 apart and a barrier every second
 // step; denser wave counts use adjacent offsets and a barrier after every step, which keeps the plain read-add-write race-free
 template <int TAIL> constexpr int scanh_bwd_lds_floats() { return 4 * ScanGeo<8, TAIL>::TILE; }
@@ -195,8 +205,8 @@ AUM_DEV void scanh_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_per
     const T* Csrc = row_ptr<T>(p.C, (int64_t)b * p.C_bs);
 
     AUM_FOR_EACH_WAVE(w, SCANH_NW) {
-        scanwg_load_tile<T, 8, TAIL, SCANH_NW>(Bsrc, p.B_ns, N, 0, p.len, Bt, w);
-        scanwg_load_tile<T, 8, TAIL, SCANH_NW>(Csrc, p.C_ns, N, 0, p.len, Ct, w);
+        scanwg_load_tile<T, 8, TAIL, SCANH_NW, SCANH_PAIRED>(Bsrc, p.B_ns, N, 0, p.len, Bt, w);
+        scanwg_load_tile<T, 8, TAIL, SCANH_NW, SCANH_PAIRED>(Csrc, p.C_ns, N, 0, p.len, Ct, w);
         for (int i0 = w * WAVE; i0 < GE::TILE; i0 += SCANH_NW * WAVE) {
             const vi idx = lane_id() + i0;
             lds_write_m(dBt, idx, splat(0.f), idx < GE::TILE);
@@ -209,7 +219,7 @@ AUM_DEV void scanh_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_per
         const vm tail_lane = (lane == WAVE - 1) && (spl_i(p.len) > 512);
         vi pos[4], pos4[4];
         AUM_UNROLL
-        for (int i = 0; i < 4; ++i) { pos[i] = lane * GE::LK + i; pos4[i] = lane * GE::LK + 4 + i; }
+        for (int i = 0; i < 4; ++i) { pos[i] = lane * GE::LK + scanh_slot_lo(i); pos4[i] = lane * GE::LK + scanh_slot_hi(i); }
         const vi pos8 = spl_i(WAVE * GE::LK);
         const int niter = (rows_per_wg + SCANH_NW - 1) / SCANH_NW;
         for (int it = 0; it < niter; ++it) {
@@ -296,10 +306,19 @@ AUM_DEV void scanh_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_per
                         AUM_UNROLL
                         for (int i = 0; i < 4; ++i) {
                             const vi a0 = pos[i] + n * GE::SP, a1 = pos4[i] + n * GE::SP;
-                            lds_write(dBt, a0, lds_read(dBt, a0) + lo2(dBacc[i]));
-                            lds_write(dBt, a1, lds_read(dBt, a1) + hi2(dBacc[i]));
-                            lds_write(dCt, a0, lds_read(dCt, a0) + lo2(dCacc[i]));
-                            lds_write(dCt, a1, lds_read(dCt, a1) + hi2(dCacc[i]));
+                            if constexpr (SCANH_PAIRED) {      // adjacent words: one packed add per pair
+                                const vf2 tb = mk2(lds_read(dBt, a0), lds_read(dBt, a1)) + dBacc[i];
+                                const vf2 tc = mk2(lds_read(dCt, a0), lds_read(dCt, a1)) + dCacc[i];
+                                lds_write(dBt, a0, lo2(tb));
+                                lds_write(dBt, a1, hi2(tb));
+                                lds_write(dCt, a0, lo2(tc));
+                                lds_write(dCt, a1, hi2(tc));
+                            } else {
+                                lds_write(dBt, a0, lds_read(dBt, a0) + lo2(dBacc[i]));
+                                lds_write(dBt, a1, lds_read(dBt, a1) + hi2(dBacc[i]));
+                                lds_write(dCt, a0, lds_read(dCt, a0) + lo2(dCacc[i]));
+                                lds_write(dCt, a1, lds_read(dCt, a1) + hi2(dCacc[i]));
+                            }
                         }
                         if (TAIL > 0) {
                             const vi a8 = pos8 + n * GE::SP;          // shared slot: owned by the last lane
@@ -355,8 +374,8 @@ AUM_DEV void scanh_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_per
     }
     AUM_WG_BARRIER();
     AUM_FOR_EACH_WAVE(w, SCANH_NW) {
-        scanwg_store_tile<8, TAIL, SCANH_NW>(dBt, ws + L.pB + ((int64_t)g_idx * p.batch + b) * N * p.len, N, 0, p.len, w);
-        scanwg_store_tile<8, TAIL, SCANH_NW>(dCt, ws + L.pC + ((int64_t)g_idx * p.batch + b) * N * p.len, N, 0, p.len, w);
+        scanwg_store_tile<8, TAIL, SCANH_NW, SCANH_PAIRED>(dBt, ws + L.pB + ((int64_t)g_idx * p.batch + b) * N * p.len, N, 0, p.len, w);
+        scanwg_store_tile<8, TAIL, SCANH_NW, SCANH_PAIRED>(dCt, ws + L.pC + ((int64_t)g_idx * p.batch + b) * N * p.len, N, 0, p.len, w);
     }
 }
 
@@ -466,7 +485,7 @@ AUM_DEV void scanh_bwd_chunked(const AumScanBwdArgs& p, int wg, float* lds, int 
         const int base = c * CS;
         const bool has_tail = TAIL > 0 && c == nchunks - 1;
         const int len_eff = has_tail ? p.len : base + CS;
-        AUM_FOR_EACH_WAVE(w, NW) { scanwg_load_tile<T, 8, TAIL, NW>(Bsrc, p.B_ns, N, base, len_eff, Bt, w); }
+        AUM_FOR_EACH_WAVE(w, NW) { scanwg_load_tile<T, 8, TAIL, NW, SCANH_PAIRED>(Bsrc, p.B_ns, N, base, len_eff, Bt, w); }
         AUM_WG_BARRIER();
         AUM_FOR_EACH_WAVE(w, NW) {
             const vi lane = lane_id();
@@ -486,7 +505,7 @@ AUM_DEV void scanh_bwd_chunked(const AumScanBwdArgs& p, int wg, float* lds, int 
                     AUM_UNROLL
                     for (int i = 0; i < 4; ++i) {
                         a[i] = vexp2_2(dl[i] * spl2(splat(An)));
-                        bb[i] = dlu[i] * mk2(lds_read(Bt, lane * GE::LK + i + n * GE::SP), lds_read(Bt, lane * GE::LK + 4 + i + n * GE::SP));
+                        bb[i] = dlu[i] * mk2(lds_read(Bt, lane * GE::LK + scanh_slot_lo(i) + n * GE::SP), lds_read(Bt, lane * GE::LK + scanh_slot_hi(i) + n * GE::SP));
                     }
                     const vf a8 = vexp2(dl8 * An), bb8 = dlu8 * lds_read(Bt, spl_i(WAVE * GE::LK + n * GE::SP));
                     const vf cin = lds_read(xcarry, spl_i(rloc * SCANWG_MAX_N + n));
@@ -507,8 +526,8 @@ AUM_DEV void scanh_bwd_chunked(const AumScanBwdArgs& p, int wg, float* lds, int 
         const int len_eff = has_tail ? p.len : base + CS;
         const bool first_visit = ci == 0;
         AUM_FOR_EACH_WAVE(w, NW) {
-            scanwg_load_tile<T, 8, TAIL, NW>(Bsrc, p.B_ns, N, base, len_eff, Bt, w);
-            scanwg_load_tile<T, 8, TAIL, NW>(Csrc, p.C_ns, N, base, len_eff, Ct, w);
+            scanwg_load_tile<T, 8, TAIL, NW, SCANH_PAIRED>(Bsrc, p.B_ns, N, base, len_eff, Bt, w);
+            scanwg_load_tile<T, 8, TAIL, NW, SCANH_PAIRED>(Csrc, p.C_ns, N, base, len_eff, Ct, w);
             for (int i0 = w * WAVE; i0 < GE::TILE; i0 += NW * WAVE) {
                 const vi idx = lane_id() + i0;
                 lds_write_m(dBt, idx, splat(0.f), idx < GE::TILE);
@@ -521,7 +540,7 @@ AUM_DEV void scanh_bwd_chunked(const AumScanBwdArgs& p, int wg, float* lds, int 
             const vm tail_lane = (lane == WAVE - 1) && (spl_i(has_tail ? 1 : 0) > 0);
             vi pos[4], pos4[4];
             AUM_UNROLL
-            for (int i = 0; i < 4; ++i) { pos[i] = lane * GE::LK + i; pos4[i] = lane * GE::LK + 4 + i; }
+            for (int i = 0; i < 4; ++i) { pos[i] = lane * GE::LK + scanh_slot_lo(i); pos4[i] = lane * GE::LK + scanh_slot_hi(i); }
             const vi pos8 = spl_i(WAVE * GE::LK);
             for (int it = 0; it < niter; ++it) {
                 const int rloc = w + it * NW;
@@ -607,10 +626,19 @@ AUM_DEV void scanh_bwd_chunked(const AumScanBwdArgs& p, int wg, float* lds, int 
                         AUM_UNROLL
                         for (int i = 0; i < 4; ++i) {
                             const vi a0 = pos[i] + n * GE::SP, a1 = pos4[i] + n * GE::SP;
-                            lds_write(dBt, a0, lds_read(dBt, a0) + lo2(dBacc[i]));
-                            lds_write(dBt, a1, lds_read(dBt, a1) + hi2(dBacc[i]));
-                            lds_write(dCt, a0, lds_read(dCt, a0) + lo2(dCacc[i]));
-                            lds_write(dCt, a1, lds_read(dCt, a1) + hi2(dCacc[i]));
+                            if constexpr (SCANH_PAIRED) {      // adjacent words: one packed add per pair
+                                const vf2 tb = mk2(lds_read(dBt, a0), lds_read(dBt, a1)) + dBacc[i];
+                                const vf2 tc = mk2(lds_read(dCt, a0), lds_read(dCt, a1)) + dCacc[i];
+                                lds_write(dBt, a0, lo2(tb));
+                                lds_write(dBt, a1, hi2(tb));
+                                lds_write(dCt, a0, lo2(tc));
+                                lds_write(dCt, a1, hi2(tc));
+                            } else {
+                                lds_write(dBt, a0, lds_read(dBt, a0) + lo2(dBacc[i]));
+                                lds_write(dBt, a1, lds_read(dBt, a1) + hi2(dBacc[i]));
+                                lds_write(dCt, a0, lds_read(dCt, a0) + lo2(dCacc[i]));
+                                lds_write(dCt, a1, lds_read(dCt, a1) + hi2(dCacc[i]));
+                            }
                         }
                         if (TAIL > 0) {
                             const vi a8 = pos8 + n * GE::SP;          // shared slot: owned by the last lane
@@ -689,8 +717,8 @@ AUM_DEV void scanh_bwd_chunked(const AumScanBwdArgs& p, int wg, float* lds, int 
         AUM_WG_BARRIER();
         // flush this chunk's dB/dC tile: one partial per workgroup, every (g,b,n,t) written exactly once
         AUM_FOR_EACH_WAVE(w, NW) {
-            scanwg_store_tile<8, TAIL, NW>(dBt, ws + L.pB + ((int64_t)g_idx * p.batch + b) * N * p.len, N, base, len_eff, w, p.len);
-            scanwg_store_tile<8, TAIL, NW>(dCt, ws + L.pC + ((int64_t)g_idx * p.batch + b) * N * p.len, N, base, len_eff, w, p.len);
+            scanwg_store_tile<8, TAIL, NW, SCANH_PAIRED>(dBt, ws + L.pB + ((int64_t)g_idx * p.batch + b) * N * p.len, N, base, len_eff, w, p.len);
+            scanwg_store_tile<8, TAIL, NW, SCANH_PAIRED>(dCt, ws + L.pC + ((int64_t)g_idx * p.batch + b) * N * p.len, N, base, len_eff, w, p.len);
         }
         AUM_WG_BARRIER();
     }

@@ -99,10 +99,14 @@ template <int K, int TAIL> AUM_DEV vi scan_tile_pos(vi tt) {
     return vsel_i(tt < WAVE * K, main_pos, tt + (WAVE * G::LK - WAVE * K));
 }
 
+// Word of main step k (0..7) inside a lane's 8-step group of a tile row.  PAIRED (the half-packed one-row kernels, opt-in):
+// steps i and 4+i sit next to each other, so the two halves of a vf2 are one ds_read2_b32 / ds_write2_b32 of adjacent words.
+template <bool PAIRED> AUM_DEV constexpr int scan_tile_slot(int k) { return PAIRED ? ((k & 3) * 2 + (k >> 2)) : k; }
+
 // Cooperative load of one [N][S] tile of B (or C) into LDS as fp32; t outside [0,len) -> 0.
 // K == 8 with the main part inside the row: 16-byte loads of 8 consecutive steps (= one lane's main slots), so a tile is
 // 2 load instructions per thread instead of 36 dependent 2-byte gathers; otherwise element-wise.
-template <class T, int K, int TAIL, int NW = SCANWG_NW>
+template <class T, int K, int TAIL, int NW = SCANWG_NW, bool PAIRED = false>
 AUM_DEV void scanwg_load_tile(const T* src, int64_t n_stride, int N, int base, int len, float* tile, int w) {
     using G = ScanGeo<K, TAIL>;
     const vi lane = lane_id();
@@ -116,7 +120,7 @@ AUM_DEV void scanwg_load_tile(const T* src, int64_t n_stride, int N, int base, i
                 vf v[8];
                 gload8(src, n * (int)n_stride + j * 8 + base, in, v);
                 AUM_UNROLL
-                for (int k = 0; k < 8; ++k) lds_write_m(tile, n * G::SP + j * G::LK + k, v[k], in);
+                for (int k = 0; k < 8; ++k) lds_write_m(tile, n * G::SP + j * G::LK + scan_tile_slot<PAIRED>(k), v[k], in);
             }
             if (TAIL > 0) {       // tail columns: N x TAIL scalars
                 const vi n = vmin_i(lane / (TAIL > 0 ? TAIL : 1), N - 1);
@@ -129,7 +133,8 @@ AUM_DEV void scanwg_load_tile(const T* src, int64_t n_stride, int N, int base, i
             return;
         }
     }
-    for (int i0 = w * WAVE; i0 < N * G::S; i0 += NW * WAVE) {
+    static_assert(!PAIRED || K == 8, "paired tiles: K == 8 only");
+    for (int i0 = w * WAVE; i0 < N * G::S; i0 += NW * WAVE) {     // (PAIRED callers never get here: their rows hold >= 512 steps)
         const vi idx = lane + i0;
         const vm in = idx < N * G::S;
         const vi n = vmin_i(idx / G::S, N - 1);
@@ -143,7 +148,7 @@ AUM_DEV void scanwg_load_tile(const T* src, int64_t n_stride, int N, int base, i
 // Write one [N][S] fp32 LDS tile to a dense (N, len) fp32 global partial (t >= len skipped); vectorised like the load.
 // `pitch` (default: len) is the row pitch of dst when `len` is only the validity bound (chunked rows whose tail column
 // belongs to the last chunk).
-template <int K, int TAIL, int NW = SCANWG_NW>
+template <int K, int TAIL, int NW = SCANWG_NW, bool PAIRED = false>
 AUM_DEV void scanwg_store_tile(const float* tile, float* dst, int N, int base, int len, int w, int pitch = -1) {
     using G = ScanGeo<K, TAIL>;
     const vi lane = lane_id();
@@ -157,7 +162,7 @@ AUM_DEV void scanwg_store_tile(const float* tile, float* dst, int N, int base, i
                 const vi j = idx & (WAVE - 1);
                 vf v[8];
                 AUM_UNROLL
-                for (int k = 0; k < 8; ++k) v[k] = lds_read(tile, n * G::SP + j * G::LK + k);
+                for (int k = 0; k < 8; ++k) v[k] = lds_read(tile, n * G::SP + j * G::LK + scan_tile_slot<PAIRED>(k));
                 gstore8(dst, n * pitch + j * 8 + base, v, in);
             }
             if (TAIL > 0) {
