@@ -32,6 +32,12 @@ AUM_HOSTDEV constexpr int scanh_rows(int mode) { return mode == 2 ? 96 : 64; }  
 #define AUM_SCANH_PAIRED 0
 #endif
 constexpr bool SCANH_PAIRED = AUM_SCANH_PAIRED != 0;
+// Opt-in (-DAUM_SCANH_RMW_BATCH=1): the dB/dC tile update of the fused bidirectional kernel issues all 18 LDS reads, then adds,
+// then writes -- one LDS round trip in the latency chain between the arithmetic and the step barrier instead of several.
+#ifndef AUM_SCANH_RMW_BATCH
+#define AUM_SCANH_RMW_BATCH 0
+#endif
+constexpr bool SCANH_RMW_BATCH = AUM_SCANH_RMW_BATCH != 0;
 // tile words of a lane's packed slot i: .x = step i, .y = step 4+i
 AUM_HOSTDEV constexpr int scanh_slot_lo(int i) { return SCANH_PAIRED ? 2 * i : i; }
 AUM_HOSTDEV constexpr int scanh_slot_hi(int i) { return SCANH_PAIRED ? 2 * i + 1 : 4 + i; }
@@ -302,7 +308,41 @@ AUM_DEV void scanh_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_per
                             scanh_bwd_dir_state<true>(p.A_b[(int64_t)ec * N + n], n, Bn, Bn8, Cn, Cn8, dl, dl8, dlu, dlu8, dy, dy8, G,
                                                       G8, DA, DA8, dBacc, dB8, dCacc, dC8, dAv1, want_dA);
                     }
-                    if (!(p.flags & AUM_DBG_SKIP_LDS_ATOMICS)) {
+                    if (SCANH_RMW_BATCH && !(p.flags & AUM_DBG_SKIP_LDS_ATOMICS)) {
+                        vf rb[9], rc[9];
+                        AUM_UNROLL
+                        for (int i = 0; i < 4; ++i) {
+                            const vi a0 = pos[i] + n * GE::SP, a1 = pos4[i] + n * GE::SP;
+                            rb[i] = lds_read(dBt, a0);
+                            rb[4 + i] = lds_read(dBt, a1);
+                            rc[i] = lds_read(dCt, a0);
+                            rc[4 + i] = lds_read(dCt, a1);
+                        }
+                        rb[8] = lds_read(dBt, pos8 + n * GE::SP);
+                        rc[8] = lds_read(dCt, pos8 + n * GE::SP);
+                        AUM_SCHED_FENCE();
+                        AUM_UNROLL
+                        for (int i = 0; i < 4; ++i) {
+                            rb[i] = rb[i] + lo2(dBacc[i]);
+                            rb[4 + i] = rb[4 + i] + hi2(dBacc[i]);
+                            rc[i] = rc[i] + lo2(dCacc[i]);
+                            rc[4 + i] = rc[4 + i] + hi2(dCacc[i]);
+                        }
+                        AUM_SCHED_FENCE();
+                        AUM_UNROLL
+                        for (int i = 0; i < 4; ++i) {
+                            const vi a0 = pos[i] + n * GE::SP, a1 = pos4[i] + n * GE::SP;
+                            lds_write(dBt, a0, rb[i]);
+                            lds_write(dBt, a1, rb[4 + i]);
+                            lds_write(dCt, a0, rc[i]);
+                            lds_write(dCt, a1, rc[4 + i]);
+                        }
+                        if (TAIL > 0) {
+                            const vi a8 = pos8 + n * GE::SP;
+                            lds_write_m(dBt, a8, rb[8] + dB8, lane == WAVE - 1);
+                            lds_write_m(dCt, a8, rc[8] + dC8, lane == WAVE - 1);
+                        }
+                    } else if (!(p.flags & AUM_DBG_SKIP_LDS_ATOMICS)) {
                         AUM_UNROLL
                         for (int i = 0; i < 4; ++i) {
                             const vi a0 = pos[i] + n * GE::SP, a1 = pos4[i] + n * GE::SP;

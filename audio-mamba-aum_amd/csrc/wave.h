@@ -86,6 +86,8 @@ AUM_DEV int wave_in_wg() { return __builtin_amdgcn_readfirstlane((int)(threadIdx
 // prefetched for a LATER step is waited for at each step's barrier, which serialises software-pipelined K loops on
 // memory latency.  Use only where the data exchanged between the waves lives in LDS.
 #define AUM_WG_BARRIER_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+// compiler scheduling fence (no instruction): keeps what was issued before it ahead of what follows
+#define AUM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // Per-wave state that must survive from one phase to the next (registers on the device): declare `T name[AUM_PER_WAVE(NW)]...`
 // and index it with AUM_W(w).  One slot on the device; the lane-array build keeps a slot per wave it steps through.
 #define AUM_PER_WAVE(NW) 1
@@ -316,6 +318,7 @@ inline void lds_atomic_add(float* lds, const vi& idx, const vf& v) { AUM_LANES l
 #define AUM_WG_BARRIER() do { } while (0)
 #define AUM_WG_BARRIER_IN_PHASE() do { } while (0)
 #define AUM_WG_BARRIER_LDS() do { } while (0)
+#define AUM_SCHED_FENCE() do { } while (0)
 #define AUM_PER_WAVE(NW) (NW)
 #define AUM_W(w) (w)
 inline void wave_sync() {}
