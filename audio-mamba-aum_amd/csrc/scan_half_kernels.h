@@ -35,7 +35,7 @@ constexpr bool SCANH_PAIRED = AUM_SCANH_PAIRED != 0;
 // Opt-in (-DAUM_SCANH_RMW_BATCH=1): the dB/dC tile update of the fused bidirectional kernel issues all 18 LDS reads, then adds,
 // then writes -- one LDS round trip in the latency chain between the arithmetic and the step barrier instead of several.
 #ifndef AUM_SCANH_RMW_BATCH
-#define AUM_SCANH_RMW_BATCH 0
+#define AUM_SCANH_RMW_BATCH 1
 #endif
 constexpr bool SCANH_RMW_BATCH = AUM_SCANH_RMW_BATCH != 0;
 // tile words of a lane's packed slot i: .x = step i, .y = step 4+i
