@@ -25,6 +25,29 @@ _ERR = {-1: "AUM_E_NULL", -2: "AUM_E_SHAPE", -3: "AUM_E_DTYPE", -4: "AUM_E_UNSUP
         -6: "AUM_E_LAUNCH"}
 
 _i64, _i32, _u32, _vp, _fp = C.c_int64, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p
+ABI_VERSION = 3
+
+
+class _Debug:
+    """Kernel-selection switches for A/B runs and ablations (tools/kbench.py, tests).  They are attributes set by the tool that
+    wants them; the environment is consulted ONCE, at import, and only when AUM_DEBUG=1 -- a stray variable in a training
+    environment cannot change which kernel runs."""
+
+    def __init__(self):
+        self.ablate = 0            # AUM_DBG_* bits (upper half of the kernel `flags`)
+        self.rowpair = False       # general row-pair kernels instead of the specialised ones
+        self.no_ckpt = False       # long rows: no chunk-entry checkpoint
+        self.no_accumulate = False  # long rows: second direction does not accumulate into the first one's tensors
+        self.no_lane_ckpt = False  # L = 513 rows: scan_lane_ckpt() hands out no checkpoint
+        if os.environ.get("AUM_DEBUG") == "1":
+            self.ablate = int(os.environ.get("AUM_ABLATE", "0"))
+            self.rowpair = os.environ.get("AUM_SCAN_ROWPAIR") == "1"
+            self.no_ckpt = os.environ.get("AUM_SCAN_NO_CKPT") == "1"
+            self.no_accumulate = os.environ.get("AUM_SCAN_NO_ACCUMULATE") == "1"
+            self.no_lane_ckpt = os.environ.get("AUM_SCAN_NO_LANE_CKPT") == "1"
+
+
+debug = _Debug()
 
 
 class ScanFwdArgs(C.Structure):
@@ -32,7 +55,7 @@ class ScanFwdArgs(C.Structure):
                                     "last_state", "workspace")]
                 + [(n, _i64) for n in ("workspace_bytes", "u_bs", "u_ds", "delta_bs", "delta_ds", "z_bs", "z_ds", "B_bs",
                                        "B_ns", "C_bs", "C_ns", "out_bs", "out_ds")]
-                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32), ("x_ck", _vp)])
+                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32), ("x_ck", _vp), ("x_lane", _vp)])
 
 
 class ScanBwdArgs(C.Structure):
@@ -41,7 +64,7 @@ class ScanBwdArgs(C.Structure):
                 + [(n, _i64) for n in ("workspace_bytes", "u_bs", "u_ds", "delta_bs", "delta_ds", "z_bs", "z_ds", "B_bs",
                                        "B_ns", "C_bs", "C_ns", "dout_bs", "dout_ds", "out_bs", "out_ds", "du_bs", "du_ds",
                                        "ddelta_bs", "ddelta_ds", "dz_bs", "dz_ds", "dB_bs", "dB_ns", "dC_bs", "dC_ns")]
-                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32), ("x_ck", _vp)])
+                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32), ("x_ck", _vp), ("x_lane", _vp)])
 
 
 class ConvArgs(C.Structure):
@@ -79,7 +102,7 @@ class ProjWArgs(C.Structure):
 
 
 EXPORTS = ["aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
-           "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
+           "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy"]
 
 
@@ -108,7 +131,11 @@ class Lib:
         self.c.aum_hbm_copy.argtypes = [_vp, _vp, _i64, _vp]
         self.c.aum_selective_scan_ckpt_bytes.restype = _i64
         self.c.aum_selective_scan_ckpt_bytes.argtypes = [_i32] * 4
-        assert self.c.aum_abi_version() == 2
+        self.c.aum_selective_scan_lane_ckpt_bytes.restype = _i64
+        self.c.aum_selective_scan_lane_ckpt_bytes.argtypes = [_i32] * 5
+        if self.c.aum_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{path}: ABI version {self.c.aum_abi_version()}, this binding speaks {ABI_VERSION} -- rebuild the library "
+                               "(python audio-mamba-aum_amd/csrc/build.py)")
         self.max_single_pass_len = int(self.c.aum_scan_max_single_pass_len())
 
     def stream(self, t):
@@ -133,7 +160,10 @@ def get():
     """The product library (libaum_hip.so).  Raises ImportError if it has not been built."""
     global _product
     if _product is None:
-        _product = Lib(_SO, host=False)
+        so = _SO
+        if os.environ.get("AUM_DEBUG") == "1" and os.environ.get("AUM_HIP_LIB"):     # A/B builds (tools/ only)
+            so = os.environ["AUM_HIP_LIB"]
+        _product = Lib(so, host=False)
     return _product
 
 
@@ -211,14 +241,26 @@ def _alloc(batch, dim, length, dtype, device, dmajor):
 def scan_ckpt(u, dstate, lib=None):
     """An empty `x` checkpoint tensor (batch, dim, len/512, dstate) fp32 for rows the chunked kernels take (long-form clips,
     L = 512 m + 1), else None.  Pass it as x_ck to scan_fwd (filled) and then to scan_bwd of the same direction (which then
-    skips its pre-pass); not with generic=/rowpair=.  AUM_SCAN_NO_CKPT=1 (A/B runs) or AUM_SCAN_ROWPAIR=1: no checkpoint."""
+    skips its pre-pass); not with generic=/rowpair=.  debug.no_ckpt (A/B runs) or debug.rowpair: no checkpoint."""
     lib = lib or get()
     batch, dim, length = u.shape
-    if os.environ.get('AUM_SCAN_ROWPAIR') == '1' or os.environ.get('AUM_SCAN_NO_CKPT') == '1':
+    if debug.rowpair or debug.no_ckpt:
         return None
     if lib.c.aum_selective_scan_ckpt_bytes(batch, dim, length, dstate) <= 0:
         return None
     return torch.empty((batch, dim, length // 512, dstate), dtype=torch.float32, device=u.device)
+
+
+def scan_lane_ckpt(u, dstate, bidir, lib=None):
+    """An empty lane-entry checkpoint (batch, dim, directions, dstate, 64) fp32 for rows the L = 513 row kernels take, else None.
+    Pass it as x_lane to scan_fwd (filled) and to scan_bwd of the same call, which then skips recomputing the forward scan."""
+    lib = lib or get()
+    batch, dim, length = u.shape
+    if debug.rowpair or debug.no_lane_ckpt:
+        return None
+    if lib.c.aum_selective_scan_lane_ckpt_bytes(batch, dim, length, dstate, int(bool(bidir))) <= 0:
+        return None
+    return torch.empty((batch, dim, 2 if bidir else 1, dstate, 64), dtype=torch.float32, device=u.device)
 
 
 def scan_accumulates(u, dstate, lib=None):
@@ -226,14 +268,14 @@ def scan_accumulates(u, dstate, lib=None):
     chunked kernels take, i.e. exactly when scan_ckpt() gives a checkpoint."""
     lib = lib or get()
     batch, dim, length = u.shape
-    if os.environ.get('AUM_SCAN_ROWPAIR') == '1' or os.environ.get('AUM_SCAN_NO_ACCUMULATE') == '1':
+    if debug.rowpair or debug.no_accumulate:
         return False
     return lib.c.aum_selective_scan_ckpt_bytes(batch, dim, length, dstate) > 0
 
 
 def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, reverse=False, A_b=None,
              want_out_pre=False, want_last_state=False, dmajor=False, generic=False, rowpair=False, x_ck=None,
-             accumulate_into=None, lib=None):
+             accumulate_into=None, x_lane=None, lib=None):
     """selective_scan_cuda.fwd.  Returns (out, out_pre|None, last_state|None).  A_b != None: fused bidirectional.
     x_ck: a scan_ckpt() tensor to fill.  accumulate_into: the `out` of the other direction's call (long rows only, see
     scan_accumulates): this call adds to it and returns it."""
@@ -261,6 +303,10 @@ def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
         assert x_ck.dtype == torch.float32 and x_ck.is_contiguous() and x_ck.shape == (batch, dim, length // 512, dstate)
         lib.check_tensor(x_ck)
         a.x_ck = _ptr(x_ck)
+    if x_lane is not None:
+        assert x_lane.dtype == torch.float32 and x_lane.is_contiguous() and x_lane.shape == (batch, dim, 2 if A_b is not None else 1, dstate, 64)
+        lib.check_tensor(x_lane)
+        a.x_lane = _ptr(x_lane)
     a.u_bs, a.u_ds = u.stride(0), u.stride(1)
     a.delta_bs, a.delta_ds = delta.stride(0), delta.stride(1)
     if z is not None:
@@ -270,9 +316,9 @@ def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     a.out_bs, a.out_ds = out.stride(0), out.stride(1)
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
     a.flags = ((SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0) | (SCAN_GENERIC if generic else 0)
-               | (SCAN_ROWPAIR if rowpair or os.environ.get('AUM_SCAN_ROWPAIR') == '1' else 0)
+               | (SCAN_ROWPAIR if rowpair or debug.rowpair else 0)
                | (SCAN_ACCUMULATE if accumulate_into is not None else 0)
-               | (int(os.environ.get('AUM_ABLATE', '0')) << 16))   # AUM_ABLATE: kernel-ablation bits for tools/kbench.py only
+               | (debug.ablate << 16))   # kernel-ablation bits, set by tools/kbench.py only
     _launch(lib.c.aum_selective_scan_fwd, a, u, lib, "scan_fwd_bidir" if A_b is not None else "scan_fwd",
             (batch, dim, length, dstate, u.element_size(), want_out_pre))
     return out, out_pre, last
@@ -283,7 +329,7 @@ def C_byref(s):
 
 
 def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=False, reverse=False, A_b=None,
-             dz_out=None, dmajor=False, generic=False, rowpair=False, x_ck=None, accumulate_into=None, lib=None):
+             dz_out=None, dmajor=False, generic=False, rowpair=False, x_ck=None, accumulate_into=None, x_lane=None, lib=None):
     """selective_scan_cuda.bwd.  Returns dict(du, ddelta, dA, dA_b, dB, dC, dD, dz, ddelta_bias); dB/dC fp32
     (batch, dstate, len).  dz_out: optional preallocated (possibly strided) tensor written in place (SSI:537-545).
     accumulate_into: the dict the other direction's call returned (long rows only, see scan_accumulates): this call adds its
@@ -331,6 +377,10 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=
     if x_ck is not None:
         assert x_ck.dtype == torch.float32 and x_ck.is_contiguous() and x_ck.shape == (batch, dim, length // 512, dstate)
         a.x_ck = _ptr(x_ck)
+    if x_lane is not None:
+        assert x_lane.dtype == torch.float32 and x_lane.is_contiguous() and x_lane.shape == (batch, dim, 2 if A_b is not None else 1, dstate, 64)
+        lib.check_tensor(x_lane)
+        a.x_lane = _ptr(x_lane)
     a.u_bs, a.u_ds = u.stride(0), u.stride(1)
     a.delta_bs, a.delta_ds = delta.stride(0), delta.stride(1)
     if z is not None:
@@ -344,9 +394,9 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=
     a.dB_bs, a.dB_ns, a.dC_bs, a.dC_ns = dB.stride(0), dB.stride(1), dC.stride(0), dC.stride(1)
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
     a.flags = ((SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0) | (SCAN_GENERIC if generic else 0)
-               | (SCAN_ROWPAIR if rowpair or os.environ.get('AUM_SCAN_ROWPAIR') == '1' else 0)
+               | (SCAN_ROWPAIR if rowpair or debug.rowpair else 0)
                | (SCAN_ACCUMULATE if acc else 0)
-               | (int(os.environ.get('AUM_ABLATE', '0')) << 16))   # AUM_ABLATE: kernel-ablation bits for tools/kbench.py only
+               | (debug.ablate << 16))   # kernel-ablation bits, set by tools/kbench.py only
     _launch(lib.c.aum_selective_scan_bwd, a, u, lib, "scan_bwd_bidir" if A_b is not None else "scan_bwd",
             (batch, dim, length, dstate, u.element_size(), True))
     return dict(du=du, ddelta=ddelta, dA=dA, dA_b=dA_b, dB=dB, dC=dC, dD=dD, dz=dz, ddelta_bias=dbias)

@@ -114,6 +114,7 @@ AUM_DEV vi vmax_i(vi a, int b) { return a > b ? a : b; }
 // v_pk_add_f32 do TWO fp32 per lane in the same 4 cycles -- the 157 TFLOP/s vector peak is a packed-math number.
 // The scan kernels therefore carry their two rows per wave as one vf2.
 typedef float vf2 __attribute__((ext_vector_type(2)));
+typedef vf2 vf2_raw;
 AUM_DEV vf2 mk2(vf a, vf b) { return vf2{a, b}; }
 AUM_DEV vf2 spl2(vf a) { return vf2{a, a}; }
 AUM_DEV vf lo2(vf2 v) { return v.x; }
@@ -122,10 +123,13 @@ AUM_DEV vf2 vfma2(vf2 a, vf2 b, vf2 c) { return __builtin_elementwise_fma(a, b, 
 AUM_DEV vf2 vexp2_2(vf2 x) { return vf2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
 AUM_DEV vf2 vsel2(vm m, vf2 a, vf2 b) { return m ? a : b; }
 
-template <class T> AUM_DEV vf gload(const T* p, vi idx, vm m) { return m ? elem_to_f32(p[idx]) : 0.f; }
-template <class T> AUM_DEV void gstore(T* p, vi idx, vf v, vm m) { if (m) f32_to_elem(v, p[idx]); }
+// Element offsets are taken as UNSIGNED 32-bit values (every caller clamps them into the row): the access then is
+// `global_* v, v_offset, s[base]` -- an SGPR base plus a 32-bit VGPR offset -- instead of a sign-extended 64-bit per-lane address
+// (two VGPRs and a v_lshl_add_u64 per access, and they get hoisted out of loops and spilled).
+template <class T> AUM_DEV vf gload(const T* p, vi idx, vm m) { return m ? elem_to_f32(p[(uint32_t)idx]) : 0.f; }
+template <class T> AUM_DEV void gstore(T* p, vi idx, vf v, vm m) { if (m) f32_to_elem(v, p[(uint32_t)idx]); }
 // unconditional load (caller clamps idx into range): no exec-mask branch, so several can be in flight
-template <class T> AUM_DEV vf gload_u(const T* p, vi idx) { return elem_to_f32(p[idx]); }
+template <class T> AUM_DEV vf gload_u(const T* p, vi idx) { return elem_to_f32(p[(uint32_t)idx]); }
 AUM_DEV void gatomic_add(float* p, vi idx, vf v, vm m) { if (m) atomicAdd(p + idx, v); }
 // 8 consecutive elements per lane as ONE (2-byte types) or TWO (fp32) 16-byte vector accesses.  Rows of the
 // (batch, dim, len) tensors start at arbitrary element offsets (len = 513), so the address is only element-aligned:
@@ -134,14 +138,14 @@ template <int BYTES> struct __attribute__((packed, aligned(BYTES))) pk16_t { uin
 template <class T> AUM_DEV void gload8(const T* p, vi idx, vm m, vf (&o)[8]) {
     if (m) {
         if constexpr (sizeof(T) == 2) {
-            const pk16_t<2> raw = *reinterpret_cast<const pk16_t<2>*>(p + idx);
+            const pk16_t<2> raw = *reinterpret_cast<const pk16_t<2>*>(p + (uint32_t)idx);
             T e[8];
             __builtin_memcpy(e, &raw, 16);
             AUM_UNROLL
             for (int j = 0; j < 8; ++j) o[j] = elem_to_f32(e[j]);
         } else {
-            const pk16_t<4> r0 = *reinterpret_cast<const pk16_t<4>*>(p + idx);
-            const pk16_t<4> r1 = *reinterpret_cast<const pk16_t<4>*>(p + idx + 4);
+            const pk16_t<4> r0 = *reinterpret_cast<const pk16_t<4>*>(p + (uint32_t)idx);
+            const pk16_t<4> r1 = *reinterpret_cast<const pk16_t<4>*>(p + (uint32_t)idx + 4);
             float e[8];
             __builtin_memcpy(e, &r0, 16);
             __builtin_memcpy(e + 4, &r1, 16);
@@ -153,15 +157,28 @@ template <class T> AUM_DEV void gload8(const T* p, vi idx, vm m, vf (&o)[8]) {
         for (int j = 0; j < 8; ++j) o[j] = 0.f;
     }
 }
+// two fp32 -> one packed pair of 16-bit elements.  bf16: v_cvt_pk_bf16_f32 (gfx950; round-to-nearest-even, quiet NaN -- the
+// same result as f32_to_elem(bf16_t), which costs ~5 VALU instructions per element)
+typedef __bf16 aum_bf16x2 __attribute__((ext_vector_type(2)));
+template <class T> AUM_DEV uint32_t f32x2_to_elem2(float a, float b) {
+    if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t)) {
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(vf2_raw{a, b}, aum_bf16x2));
+    } else {
+        T ea, eb;
+        f32_to_elem(a, ea);
+        f32_to_elem(b, eb);
+        return (uint32_t)ea.bits | ((uint32_t)eb.bits << 16);
+    }
+}
 template <class T> AUM_DEV void gstore8(T* p, vi idx, const vf (&v)[8], vm m) {
     if (m) {
         if constexpr (sizeof(T) == 2) {
-            T e[8];
+            uint32_t e[4];
             AUM_UNROLL
-            for (int j = 0; j < 8; ++j) f32_to_elem(v[j], e[j]);
+            for (int j = 0; j < 4; ++j) e[j] = f32x2_to_elem2<T>(v[2 * j], v[2 * j + 1]);
             pk16_t<2> raw;
             __builtin_memcpy(&raw, e, 16);
-            *reinterpret_cast<pk16_t<2>*>(p + idx) = raw;
+            *reinterpret_cast<pk16_t<2>*>(p + (uint32_t)idx) = raw;
         } else {
             float e[8];
             AUM_UNROLL
@@ -169,8 +186,8 @@ template <class T> AUM_DEV void gstore8(T* p, vi idx, const vf (&v)[8], vm m) {
             pk16_t<4> r0, r1;
             __builtin_memcpy(&r0, e, 16);
             __builtin_memcpy(&r1, e + 4, 16);
-            *reinterpret_cast<pk16_t<4>*>(p + idx) = r0;
-            *reinterpret_cast<pk16_t<4>*>(p + idx + 4) = r1;
+            *reinterpret_cast<pk16_t<4>*>(p + (uint32_t)idx) = r0;
+            *reinterpret_cast<pk16_t<4>*>(p + (uint32_t)idx + 4) = r1;
         }
     }
 }
@@ -215,6 +232,11 @@ AUM_DEV vf dpp_wave_shl1(vf x, vf old) { return dpp_mov<0x130>(x, old); }  // la
 AUM_DEV float readlane(vf x, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
 }
+// lane `lane` (wave-uniform) of v <- the wave-uniform value s.  (clang has no v_writelane_b32 builtin and inline asm would hide the
+// SGPR-lane-select hazard from the compiler: a compare + select, two VALU instructions.)
+AUM_DEV vf writelane(vf v, float s, int lane) { return (int)(threadIdx.x & 63u) == lane ? s : v; }
+// wave-uniform element of a row (every lane reads the same address)
+template <class T> AUM_DEV float gload_s(const T* p, int idx) { return elem_to_f32(p[idx]); }
 #define AUM_LDS(type, name, count) __shared__ type name[count]
 
 #else
@@ -228,6 +250,7 @@ struct vm { bool v[WAVE]; };
 #define AUM_LANES for (int l = 0; l < WAVE; ++l)
 inline vi lane_id() { vi r; AUM_LANES r.v[l] = l; return r; }
 inline vf splat(float x) { vf r; AUM_LANES r.v[l] = x; return r; }
+inline vf splat(const vf& x) { return x; }      // a value that is already per-lane (wave-uniform by construction at the call site)
 inline vi spl_i(int x) { vi r; AUM_LANES r.v[l] = x; return r; }
 
 #define AUM_BINOP_F(op)                                                                         \
@@ -339,6 +362,8 @@ template <int N> inline vf dpp_row_shl(const vf& x, float old) { return dpp_row_
 inline vf dpp_wave_shr1(const vf& x, float old) { return dpp_wave_shr1(x, splat(old)); }
 inline vf dpp_wave_shl1(const vf& x, float old) { return dpp_wave_shl1(x, splat(old)); }
 inline float readlane(const vf& x, int lane) { return x.v[lane]; }
+inline vf writelane(const vf& v, float s, int lane) { vf r = v; r.v[lane] = s; return r; }
+template <class T> inline float gload_s(const T* p, int idx) { return elem_to_f32(p[idx]); }
 #define AUM_LDS(type, name, count) type name[count]
 #endif  // AUM_EMU
 
@@ -369,6 +394,25 @@ AUM_DEV vf vsoftplus(vf x) {
     vf r = vsel(d == 0.0f, e, lg * vdiv_nr(e, vsel(d == 0.0f, splat(1.0f), d)));
     return vsel(x > 20.0f, x, r);
 }
+
+#ifdef AUM_EMU
+// wave-uniform (plain float) forms for the lane-array build; on the device vf IS float and the functions above serve both
+inline float vexp(float x) { return vexp2(x * LOG2E); }
+inline float vsigmoid(float x) { return vrcp(1.0f + vexp2(x * (-LOG2E))); }
+inline float vdiv_nr(float a, float b) {
+    const float r = vrcp(b);
+    const float q = a * r;
+    return vfma(vfma(-q, b, a), r, q);
+}
+inline float vsoftplus(float x) {
+    const float e = vexp(x);
+    const float w = e + 1.0f;
+    const float d = w - 1.0f;
+    const float lg = vlog2(w) * LN2;
+    const float r = d == 0.0f ? e : lg * vdiv_nr(e, d == 0.0f ? 1.0f : d);
+    return x > 20.0f ? x : r;
+}
+#endif
 
 // Packed-pair forms of the two element-wise functions of the scan prologues/epilogues: the adds, multiplies and the
 // residual step run as v_pk_* on both halves, only v_exp_f32 / v_log_f32 / v_rcp_f32 and the selects stay per half.

@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define AUM_ABI_VERSION 2   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs */
+#define AUM_ABI_VERSION 3   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
+                               3: x_lane (lane-entry state checkpoint of the L = 513 row kernels) appended after it */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 
@@ -89,6 +90,7 @@ typedef struct AumScanFwdArgs {
     int32_t dtype;
     uint32_t flags;
     float *x_ck;                /* ABI 2 */
+    float *x_lane;              /* ABI 3 (optional, output): see aum_selective_scan_lane_ckpt_bytes */
 } AumScanFwdArgs;
 
 /*
@@ -117,6 +119,7 @@ typedef struct AumScanBwdArgs {
     int32_t dtype;
     uint32_t flags;
     const float *x_ck;          /* ABI 2: the forward's checkpoint of the same call shape and direction, or NULL */
+    const float *x_lane;        /* ABI 3: the forward's lane-entry checkpoint of the same call (shape, direction mode), or NULL */
 } AumScanBwdArgs;
 
 int aum_selective_scan_fwd(const AumScanFwdArgs* args, void* stream);
@@ -127,6 +130,15 @@ int64_t aum_selective_scan_workspace_bytes(int32_t batch, int32_t dim, int32_t l
                                            int32_t backward);
 /* bytes of the x_ck checkpoint for this shape (one direction), 0 when the shape has none */
 int64_t aum_selective_scan_ckpt_bytes(int32_t batch, int32_t dim, int32_t len, int32_t dstate);
+/*
+ * x_lane: the second form of the `x` tensor selective_scan_cuda.fwd returns for its backward (SSI:37-45), at the granularity
+ * this library's L = 513 row kernels want it: the state entering every lane's 8-step block, per (row, direction, state) --
+ * (batch, dim, directions, dstate, 64) fp32, directions = 2 for the fused bidirectional call.  Rows the row kernels take
+ * (len == 513, dstate <= 16, neither AUM_SCAN_GENERIC nor AUM_SCAN_ROWPAIR) have one; bytes = 0 otherwise, and passing x_lane for
+ * such a call is AUM_E_UNSUPPORTED.  Handed to the backward of the same call it replaces the recomputation of the forward scan
+ * (the backward without it runs the previous-generation kernels).
+ */
+int64_t aum_selective_scan_lane_ckpt_bytes(int32_t batch, int32_t dim, int32_t len, int32_t dstate, int32_t bidirectional);
 
 /*
  * Depthwise causal conv1d + bias + SiLU (causal_conv1d_cuda.causal_conv1d_fwd / _bwd).

@@ -27,6 +27,13 @@ SCAN_WIDE_CASES = [
     ("l513_d70_n8_noz", 1, 70, 513, 8, False, True, False, True),
 ]
 
+# L = 513 rows for the row kernels with the lane-entry checkpoint (scan_row_kernels.h): the wide cases above plus a row with no
+# gate / D / bias / softplus and a single ragged group; live oracle only
+SCAN_ROW_CASES = SCAN_WIDE_CASES + [
+    ("l513_d5_plain", 2, 5, 513, 16, False, False, False, False),
+    ("l513_d3_n5_nod", 1, 3, 513, 5, True, False, True, True),
+]
+
 # long rows of 512*m (+1) steps: the backward is the chunked one-row kernel (one launch per direction, carries between the
 # 512-step chunks, the tail step owned by the last chunk); live oracle only.  Two row groups with idle waves / fewer states /
 # no gate, no D, no bias, no softplus / three chunks

@@ -27,8 +27,10 @@ def rq(a, dtype):
 
 
 def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, tol=None, strided=False, generic=False,
-               rowpair=False, ckpt=False):
-    """ckpt: hand the forward's chunk-entry-state checkpoint to the backward (long rows; the backward then skips its pre-pass)"""
+               rowpair=False, ckpt=False, lane_ckpt=False):
+    """lane_ckpt: L = 513 rows -- let the forward fill the lane-entry checkpoint and hand it to the backward (the row kernels of
+    scan_row_kernels.h; without it the backward runs the previous-generation kernels).
+    ckpt: hand the forward's chunk-entry-state checkpoint to the backward (long rows; the backward then skips its pre-pass)"""
     name, batch, dim, length, dstate, has_z, has_D, has_bias, softplus = case
     d = cases.scan_inputs(*case)
     tol = tol or (TOL_F32 if dtype == torch.float32 else TOL_BF16)
@@ -44,9 +46,13 @@ def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, 
     A, D, bias = T(d["A"], dev), T(d["D"], dev), T(d["delta_bias"], dev)
     x_ck = aum_hip.scan_ckpt(u, dstate, lib=lib) if ckpt else None
     assert not ckpt or x_ck is not None
+    x_lane = aum_hip.scan_lane_ckpt(u, dstate, bidir, lib=lib) if lane_ckpt else None
+    assert not lane_ckpt or x_lane is not None
+    if x_lane is not None:
+        x_lane.fill_(float("nan"))      # every entry the backward reads must have been written by the forward
     out, out_pre, last = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, softplus, reverse, T(A_b, dev),
                                           want_out_pre=True, want_last_state=not bidir, generic=generic, rowpair=rowpair,
-                                          x_ck=x_ck, lib=lib)
+                                          x_ck=x_ck, x_lane=x_lane, lib=lib)
     ref = O.scan_fwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], softplus,
                      reverse, "f64")
     ref_out, ref_pre = ref["out"], ref["y_pre"]
@@ -59,7 +65,7 @@ def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, 
     # backward
     dout = act(d["dout"])
     g = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, out_pre if has_z else None, softplus, reverse,
-                         T(A_b, dev), generic=generic, rowpair=rowpair, x_ck=x_ck, lib=lib)
+                         T(A_b, dev), generic=generic, rowpair=rowpair, x_ck=x_ck, x_lane=x_lane, lib=lib)
     gr = O.scan_bwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus,
                     reverse, "f64")
     if bidir:

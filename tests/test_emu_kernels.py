@@ -46,6 +46,30 @@ def test_scan_one_row_backward_vs_row_pair(emu, case, mode):
     KC.check_scan(emu, "cpu", case, torch.bfloat16, reverse=(mode == "rev"), bidir=(mode == "bidir"))
 
 
+@pytest.mark.parametrize("case", [c for c in cases.SCAN_CASES if c[0] == "l513"] + cases.SCAN_ROW_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+def test_scan_row_kernels_lane_checkpoint(emu, case, mode):
+    """L = 513: scan_row_kernels.h -- the forward fills the lane-entry checkpoint, the backward reads it instead of recomputing the
+    forward scan; the tail step of all (direction, state) pairs is one lane-parallel block per row"""
+    kw = dict(reverse=(mode == "rev"), bidir=(mode == "bidir"), lane_ckpt=True)
+    KC.check_scan(emu, "cpu", case, torch.float32, **kw)
+    KC.check_scan(emu, "cpu", case, torch.bfloat16, **kw)
+    KC.check_scan(emu, "cpu", case, torch.float32, strided=True, **kw)
+    KC.check_scan(emu, "cpu", case, torch.float16, tol=2e-3, **kw)
+
+
+def test_scan_lane_checkpoint_contract(emu):
+    """x_lane exists only for rows the row kernels take; handing one to any other call is refused, not ignored"""
+    assert aum_hip.scan_lane_ckpt(torch.zeros(2, 4, 65), 16, False, lib=emu) is None
+    assert aum_hip.scan_lane_ckpt(torch.zeros(2, 4, 1025), 16, False, lib=emu) is None
+    ck = aum_hip.scan_lane_ckpt(torch.zeros(2, 4, 513), 16, True, lib=emu)
+    assert ck.shape == (2, 4, 2, 16, 64) and emu.c.aum_selective_scan_lane_ckpt_bytes(2, 4, 513, 16, 1) == ck.numel() * 4
+    z = lambda *s: torch.zeros(*s)
+    with pytest.raises(RuntimeError):       # the row-pair kernels have no use for it
+        aum_hip.scan_fwd(z(2, 4, 513), z(2, 4, 513), -torch.ones(4, 16), z(2, 16, 513), z(2, 16, 513),
+                         x_lane=torch.empty(2, 4, 1, 16, 64), rowpair=True, lib=emu)
+
+
 @pytest.mark.parametrize("case", cases.SCAN_LONG_CASES + [c for c in cases.SCAN_CASES if c[0] == "l2049"], ids=lambda c: c[0])
 @pytest.mark.parametrize("mode", ["fwd", "rev"])
 def test_scan_chunked_one_row_backward(emu, case, mode):
@@ -96,7 +120,7 @@ def test_scan_chunked_one_row_backward_row_groupings(emu, monkeypatch):
     """the chunked kernel sizes its workgroups (16..64 rows) to the grid; small test shapes always get 16 rows, so the
     64-row grouping (four rows per wave, a ragged second group) is forced through the debug bit"""
     case = [c for c in cases.SCAN_LONG_CASES if c[0] == "l1024_d70_n8"][0]
-    monkeypatch.setenv("AUM_ABLATE", str(1 << 5))
+    monkeypatch.setattr(aum_hip.debug, "ablate", 1 << 5)
     for reverse in (False, True):
         KC.check_scan(emu, "cpu", case, torch.float32, reverse=reverse)
 

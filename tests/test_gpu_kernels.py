@@ -49,6 +49,49 @@ def test_scan_one_row_backward_vs_row_pair(lib, case, mode, dtype):
         KC.check_scan(lib, "cuda", case, dtype, reverse=(mode == "rev"), bidir=(mode == "bidir"), rowpair=rowpair)
 
 
+@pytest.mark.parametrize("case", [c for c in cases.SCAN_CASES if c[0] == "l513"] + cases.SCAN_ROW_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_scan_row_kernels_lane_checkpoint(lib, case, mode, dtype):
+    """L = 513, scan_row_kernels.h: forward fills the lane-entry checkpoint, backward reads it (no recomputed forward scan)"""
+    kw = dict(reverse=(mode == "rev"), bidir=(mode == "bidir"), lane_ckpt=True, tol=2e-3 if dtype == torch.float16 else None)
+    KC.check_scan(lib, "cuda", case, dtype, **kw)
+    KC.check_scan(lib, "cuda", case, dtype, strided=True, **kw)
+
+
+def test_scan_row_kernels_full_size(lib):
+    """AuM-Base block shape (B=8 of the 64, E=1536, L=513, N=16, bf16, d-major rows): the checkpointed row-kernel backward
+    against the previous-generation backward (which recomputes the forward scan) on the same inputs -- same gradients up to
+    fp32 reassociation -- and bitwise repeatable from launch to launch (no atomics; race screen for the tile updates)"""
+    torch.manual_seed(0)
+    Bsz, E, L, N = 8, 1536, 513, 16
+    dt = torch.bfloat16
+    mk = lambda: torch.randn(E, Bsz, L, device="cuda").to(dt).permute(1, 0, 2)
+    u, z, dout = mk(), mk(), mk()
+    delta = (0.5 * torch.randn(E, Bsz, L, device="cuda")).to(dt).permute(1, 0, 2)
+    Bm, Cm = torch.randn(Bsz, 1, N, L, device="cuda").to(dt), torch.randn(Bsz, 1, N, L, device="cuda").to(dt)
+    A = -torch.arange(1, N + 1, device="cuda", dtype=torch.float32).repeat(E, 1) * (1 + 0.1 * torch.rand(E, N, device="cuda"))
+    A_b = A * 1.05
+    D, bias = torch.ones(E, device="cuda"), torch.full((E,), -4.0, device="cuda") + torch.rand(E, device="cuda")
+    for kw in (dict(A_b=A_b), dict(reverse=False), dict(reverse=True)):
+        bidir = "A_b" in kw
+        ck = aum_hip.scan_lane_ckpt(u, N, bidir, lib=lib)
+        ck.fill_(float("nan"))
+        out, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, want_out_pre=True, x_lane=ck, lib=lib, **kw)
+        out_rp, pre_rp, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, want_out_pre=True, rowpair=True, lib=lib, **kw)
+        assert torch.isfinite(ck).all()
+        assert (out.float() - out_rp.float()).abs().max() <= 2e-2 * out_rp.float().abs().max()
+        g = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, x_lane=ck, lib=lib, **kw)
+        g2 = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, x_lane=ck, lib=lib, **kw)
+        gold = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, lib=lib, **kw)
+        for k, v in g.items():
+            if v is None:
+                continue
+            assert torch.equal(v, g2[k]), (kw.keys(), k)
+            a, b = v.float(), gold[k].float()
+            assert (a - b).abs().max() <= 1e-2 * b.abs().max() + 1e-6, (list(kw), k, float((a - b).abs().max()), float(b.abs().max()))
+
+
 @pytest.mark.parametrize("case", cases.SCAN_LONG_CASES + [c for c in cases.SCAN_CASES if c[0] == "l2049"], ids=lambda c: c[0])
 @pytest.mark.parametrize("mode", ["fwd", "rev"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

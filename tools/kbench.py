@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--len", type=int, default=513)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", default="")
+    ap.add_argument("--layout", default="dmajor", help="dmajor: [E][B][L] storage (the package's layout); bmajor: [B][E][L]")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
     s = 2 if dt != torch.float32 else 4
@@ -42,8 +43,10 @@ def main():
     torch.manual_seed(0)
     # d-major layout [E][B][L] viewed as (B,E,L), as the host package stores it
     mk = lambda: torch.randn(E, Bsz, L, device=dev).to(dt).permute(1, 0, 2)
+    if a.layout == "bmajor":
+        mk = lambda: torch.randn(Bsz, E, L, device=dev).to(dt)
     u, z, dout = mk(), mk(), mk()
-    delta = (0.5 * torch.randn(E, Bsz, L, device=dev)).to(dt).permute(1, 0, 2)
+    delta = 0.5 * mk()
     Bm = torch.randn(Bsz, 1, N, L, device=dev).to(dt)
     Cm = torch.randn(Bsz, 1, N, L, device=dev).to(dt)
     A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(E, 1) * (1 + 0.1 * torch.rand(E, N, device=dev))
@@ -82,6 +85,25 @@ def main():
         rec("scan_bwd_uni", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True), iters=10), bw_bytes)
     if want("scan_bwd") and not fused:
         rec("scan_bwd_rev", timeit(lambda: aum_hip.scan_bwd(u, delta, A_b, Bm, Cm, D, z, bias, dout, pre, True, True), iters=10), bw_bytes)
+    if want("scan_ck") and fused and L == 513:      # row kernels with the lane-entry checkpoint (+ its bytes in the algorithmic count)
+        ck2, ck1 = aum_hip.scan_lane_ckpt(u, N, True), aum_hip.scan_lane_ckpt(u, N, False)
+        rec("scan_fwd_bidir_train_ck", timeit(lambda: aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, x_lane=ck2)),
+            5 * T * s + bc + ck2.numel() * 4)
+        rec("scan_fwd_uni_train_ck", timeit(lambda: aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, want_out_pre=True, x_lane=ck1)),
+            5 * T * s + bc + ck1.numel() * 4)
+        _, pre2, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, x_lane=ck2)
+        bw_bytes = 8 * T * s + bc + 2 * Bsz * N * L * 4
+        rec("scan_bwd_bidir_ck", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre2, True, A_b=A_b, x_lane=ck2), iters=10),
+            bw_bytes + ck2.numel() * 4)
+        _, pre1, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, want_out_pre=True, x_lane=ck1)
+        rec("scan_bwd_uni_ck", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre1, True, x_lane=ck1), iters=10),
+            bw_bytes + ck1.numel() * 4)
+        for bits, label in ((1, "no_states"), (2, "no_rmw"), (16, "no_step_barrier")):
+            aum_hip.debug.ablate = bits
+            rec(f"ablate_bwd_bidir_ck_{label}", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre2, True, A_b=A_b, x_lane=ck2), iters=5), 1)
+        aum_hip.debug.ablate = 1
+        rec("ablate_fwd_bidir_ck_no_states", timeit(lambda: aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, x_lane=ck2), iters=5), 1)
+        aum_hip.debug.ablate = 0
     if want("scan_bwd") and fused:
         rec("scan_bwd_bidir", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, A_b=A_b), iters=10), bw_bytes)
     if want("conv"):
@@ -126,12 +148,12 @@ def main():
         _, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True)
         for bits, label in ((0, "full"), (1, "no_states"), (2, "no_lds_atomics"), (4, "no_partials"), (8, "no_epilogue"),
                             (3, "no_states_no_atomics"), (15, "loads_only"), (16, "no_step_barrier")):
-            os.environ["AUM_ABLATE"] = str(bits)
+            aum_hip.debug.ablate = bits
             rec(f"ablate_bwd_bidir_{label}", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, A_b=A_b), iters=5), 1)
         for bits, label in ((0, "full"), (1, "no_states")):
-            os.environ["AUM_ABLATE"] = str(bits)
+            aum_hip.debug.ablate = bits
             rec(f"ablate_fwd_bidir_{label}", timeit(lambda: aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b), iters=5), 1)
-        os.environ["AUM_ABLATE"] = "0"
+        aum_hip.debug.ablate = 0
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"kbench_{a.dtype}_B{a.batch}.json"), "w") as f:
         json.dump(res, f, indent=1)
