@@ -55,6 +55,7 @@ def read_audio(path):
 
 class WaveformDataset(Dataset):
     """item -> (waveform zero-padded/cut to max_samples, n_valid_samples, label vector, path)."""
+    MAX_RETRIES = 20
 
     def __init__(self, dataset_json_file, label_csv, max_samples, mixup=0.0, sample_rate=16000):
         with open(dataset_json_file, "r") as fp:
@@ -78,6 +79,7 @@ class WaveformDataset(Dataset):
 
     def __getitem__(self, index):
         labels = np.zeros(self.label_num, np.float32)
+        tries = 0
         while True:                                                    # DL:160-171, 189-199: retry another clip
             datum = self.data[index]
             try:
@@ -91,8 +93,13 @@ class WaveformDataset(Dataset):
                     self._labels(datum, 1.0, labels)
                     labels = np.minimum(labels, 1.0)                   # DL:203 assigns, duplicates do not add
                 break
-            except (OSError, EOFError, _wave.Error) as e:
-                print(f"dataloading failed ({e}), retrying...")
+            except (OSError, EOFError, ValueError, _wave.Error) as e:
+                # ValueError: unsupported container / sample width / sample rate (read_audio); the reference retries another
+                # clip on any load failure (DL:160-171).  Bounded, so a list of unreadable files fails instead of spinning.
+                tries += 1
+                print(f"dataloading failed for {datum['wav']} ({e}), retrying ({tries}/{self.MAX_RETRIES})...")
+                if tries >= self.MAX_RETRIES:
+                    raise RuntimeError(f"{self.MAX_RETRIES} consecutive clips could not be loaded; last: {datum['wav']}") from e
                 index = random.randint(0, len(self.data) - 1)
                 labels[:] = 0
         n = min(len(w), self.max_samples)

@@ -148,8 +148,6 @@ def _init_weights(module, n_layer):
     """MM:146-176: zero Linear biases (unless _no_reinit), rescale out_proj by 1/sqrt(n_layer)."""
     if isinstance(module, nn.Linear) and module.bias is not None and not getattr(module.bias, "_no_reinit", False):
         nn.init.zeros_(module.bias)
-    for name, p in module.named_parameters(recurse=False):
-        pass
     if isinstance(module, Mamba):
         nn.init.kaiming_uniform_(module.out_proj.weight, a=math.sqrt(5))
         with torch.no_grad():

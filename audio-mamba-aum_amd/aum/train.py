@@ -200,8 +200,17 @@ def make_loader(args, path, train, D):
         sampler = torch.utils.data.WeightedRandomSampler(w, len(w) // D.world, replacement=True, generator=g)
     elif D.world > 1:
         sampler = torch.utils.data.distributed.DistributedSampler(ds, D.world, D.rank, shuffle=train, drop_last=False)
+    g = torch.Generator().manual_seed(EXP_SEED + 1000 * D.rank + (1 if train else 0))    # worker base seeds differ per rank
     return torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=(train and sampler is None), sampler=sampler,
-                                       num_workers=args.num_workers, pin_memory=D.cuda, drop_last=False)
+                                       num_workers=args.num_workers, pin_memory=D.cuda, drop_last=False,
+                                       generator=g, worker_init_fn=_seed_worker)
+
+
+def _seed_worker(worker_id):
+    """python / numpy generators of a loader worker follow torch's per-worker seed (mix-up partners and lambdas, DL:104-129)"""
+    seed = torch.initial_seed() % (2 ** 32)
+    random.seed(seed)
+    np.random.seed(seed)
 
 
 def _autocast(args, D):
@@ -221,6 +230,18 @@ def _loss(loss_fn, out, labels):
     if isinstance(loss_fn, nn.CrossEntropyLoss):
         return loss_fn(out, torch.argmax(labels.long(), dim=1))
     return loss_fn(out, labels)
+
+
+def _gather_order(n_steps, batch_size, per_rank, world):
+    """Sampler position (0 .. world*per_rank-1, positions >= len(dataset) are padding) of every row of the concatenated
+    per-step gathers: step s, rank r, row j holds sample number (s*batch_size + j) of rank r, i.e. position (.)*world + r."""
+    rows = []
+    for s_ in range(n_steps):
+        n_here = min(batch_size, per_rank - s_ * batch_size)
+        for r in range(world):
+            j = np.arange(n_here)
+            rows.append((s_ * batch_size + j) * world + r)
+    return np.concatenate(rows) if rows else np.zeros(0, np.int64)
 
 
 def validate(model, loader, frontend, args, D, epoch, save_pred=True):
@@ -253,6 +274,16 @@ def validate(model, loader, frontend, args, D, epoch, save_pred=True):
     if not D.main:
         return None, None
     output, target = torch.cat(preds).numpy(), torch.cat(tgts).numpy()
+    # DistributedSampler pads every rank to the same length by repeating leading samples; the reference's plain gather keeps
+    # those duplicates in the metrics (TT:285-287).  They skew mAP/AUC on small evaluation sets, so only len(dataset) rows count
+    # here (rank-interleaved order restored first).
+    n_data = len(loader.dataset)
+    if D.world > 1 and output.shape[0] > n_data and isinstance(loader.sampler, torch.utils.data.distributed.DistributedSampler):
+        per = output.shape[0] // D.world
+        # batches were gathered rank-major per step; the sampler deals indices rank-minor: recover dataset order
+        order = _gather_order(len(loader), loader.batch_size, per, D.world)
+        keep_rows = order < n_data
+        output, target = output[keep_rows], target[keep_rows]
     stats = calculate_stats(output, target)
     if save_pred:
         pdir = os.path.join(args.exp_dir, "predictions")
@@ -273,7 +304,8 @@ def train(model, train_loader, val_loader, args, D):
     k = args.bs_scale_factor
     if args.optim == "adam":
         optimizer = torch.optim.Adam(trainables, args.lr, weight_decay=args.weight_decay,
-                                     betas=(1 - (1 - 0.95) * k, 1 - (1 - 0.999) * k), eps=1e-8 / (k ** 0.5))
+                                     betas=(1 - (1 - 0.95) * k, 1 - (1 - 0.999) * k), eps=1e-8 / (k ** 0.5),
+                                     fused=True if D.cuda else None)     # one multi-tensor launch, step counters on the device
     else:
         optimizer = torch.optim.SGD(trainables, args.lr, momentum=0.9, weight_decay=args.weight_decay)
     if args.optim_path:
@@ -292,7 +324,7 @@ def train(model, train_loader, val_loader, args, D):
 
     progress, result = [], np.zeros([args.n_epochs, 8])
     best_epoch, best_mAP, best_acc = 0, -np.inf, -np.inf
-    loss_sum, loss_cnt = 0.0, 0
+    loss_acc = torch.zeros(2, device=D.device, dtype=torch.float32)          # [sum of loss * clips, clips] of this rank, this epoch
     global_step, epoch = 0, 1
     warm_steps, warm_every = 1000 // k, max(1, 50 // k)
     while epoch < args.n_epochs + 1:
@@ -319,26 +351,35 @@ def train(model, train_loader, val_loader, args, D):
             loss = _loss(loss_fn, out.float(), labels)
             if args.if_nan2num:
                 loss = torch.nan_to_num(loss)
-            loss_value = loss.item()
-            if not math.isfinite(loss_value):
-                if args.if_continue_inf:
-                    print("Loss is {}, continuing training".format(loss_value))
-                    optimizer.zero_grad()
-                    continue
-                print("Loss is {}, stopping training".format(loss_value))
-                sys.exit(1)
+            else:
+                # non-default (--if_nan2num False, TT:153-164): the decision to skip or stop must be the SAME on every rank --
+                # a rank that skipped alone would leave the others waiting in the gradient all-reduce -- so the finite flag is
+                # reduced (MIN) first.  This is the only per-step host sync of the loop and it is off by default.
+                finite = torch.isfinite(loss.detach()).to(torch.float32)
+                if D.world > 1:
+                    dist.all_reduce(finite, op=dist.ReduceOp.MIN)
+                if finite.item() == 0.0:
+                    if args.if_continue_inf:
+                        D.print("Loss is not finite on some rank, continuing training")
+                        optimizer.zero_grad()
+                        continue
+                    D.print("Loss is not finite on some rank, stopping training")
+                    sys.exit(1)
             optimizer.zero_grad(set_to_none=True)
             scaler.scale(loss).backward()
             scaler.step(optimizer)
             scaler.update()
-            stat = D.gather(torch.tensor([loss_value * wave.shape[0], wave.shape[0]], device=D.device)[None]).sum(0)
-            loss_sum += float(stat[0])
-            loss_cnt += int(stat[1])
+            # running loss stays on the device: no .item() and no collective per step (the reference's per-step gather + print,
+            # TT:157-174, is what SURVEY 5 flags as the scaling hazard); ranks exchange it every n_print_steps and per epoch
+            loss_acc += torch.stack([loss.detach().float() * wave.shape[0], loss_acc.new_tensor(float(wave.shape[0]))])
             global_step += 1
+            HOST_SYNCS["steps"] += 1
             if global_step % args.n_print_steps == 0:
+                loss_sum, loss_cnt = _sync_loss(loss_acc, D)
                 D.print("Epoch {} step {} T_Loss {:.5f} ({:.1f} clips/s)".format(
                     epoch, global_step, loss_sum / max(1, loss_cnt), loss_cnt / (time.time() - t0)))
 
+        loss_sum, loss_cnt = _sync_loss(loss_acc, D)
         D.print("start validation")
         stats, valid_loss = validate(net, val_loader, fe_val, args, D, epoch)
         if D.main:
@@ -373,11 +414,25 @@ def train(model, train_loader, val_loader, args, D):
             progress.append([epoch, global_step, best_epoch, best_mAP, best_acc])
             with open("%s/progress.pkl" % args.exp_dir, "wb") as f:
                 pickle.dump(progress, f)
-        loss_sum, loss_cnt = 0.0, 0
+        loss_acc.zero_()
         D.barrier()
         scheduler.step()
         epoch += 1
     return model
+
+
+HOST_SYNCS = {"steps": 0, "loss_syncs": 0}      # counted so that tests can assert the hot loop's host-sync budget
+
+
+def _sync_loss(loss_acc, D):
+    """(sum, count) of the running training loss over all ranks: one all-reduce + one device->host copy, called every
+    --n-print-steps steps and at the end of an epoch -- never per step."""
+    t = loss_acc.clone()
+    if D.world > 1:
+        dist.all_reduce(t)
+    HOST_SYNCS["loss_syncs"] += 1
+    v = t.tolist()
+    return float(v[0]), int(round(v[1]))
 
 
 def evaluate(model, val_loader, args, D, tag):
@@ -407,7 +462,11 @@ def main(argv=None):
         from . import tunable
         tunable.enable(D.local_rank)
     print("I am process %s, running on %s: starting (%s)" % (os.getpid(), os.uname()[1], time.asctime()))
-    model = build_model(args)
+    model = build_model(args)            # same initial weights on every rank (EXP_SEED); DDP broadcasts rank 0's anyway
+    # from here on every rank draws its OWN random stream: SpecAug masks, noise and roll come from the device generator and the
+    # loader workers from the base seed below -- with one shared seed all ranks would apply identical augmentation to their
+    # i-th sample every step
+    random.seed(EXP_SEED + D.rank), np.random.seed(EXP_SEED + D.rank), torch.manual_seed(EXP_SEED + D.rank)
     val_loader = make_loader(args, args.data_val, False, D)
     if args.run_type == "train":
         train_loader = make_loader(args, args.data_train, True, D)

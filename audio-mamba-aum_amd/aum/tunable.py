@@ -7,6 +7,7 @@ issued (env vars are read lazily at first use): it points TunableOp at the solut
 leaves online tuning ON, so a shape that is missing -- or a library version whose validators reject the file -- is tuned
 during the first (warm-up) step instead of silently running the slow default.
 """
+import atexit
 import os
 import shutil
 import tempfile
@@ -20,6 +21,7 @@ def enable(local_rank=0, tuning=True):
     src = os.environ.get("AUM_TUNABLEOP_CSV", os.path.join(_HERE, "tunableop_gfx950.csv"))
     d = os.path.join(tempfile.gettempdir(), f"aum_tunableop_{os.getuid()}_{os.getpid()}")
     os.makedirs(d, exist_ok=True)
+    atexit.register(shutil.rmtree, d, ignore_errors=True)       # per-process scratch copy of the solution file
     if os.path.exists(src):
         # ordinal = local rank on a full node, 0 when the launcher masks each rank to one visible device
         for ordinal in {0, local_rank}:

@@ -194,6 +194,8 @@ MODEL_CASES = [
     ("d64_v1_endcls_tr", "v1", 2, 64, (128, 128), 10, 2, {"use_middle_cls_token": False, "use_end_cls_token": True,
                                                            "transpose_token_sequence": True}),
     ("d64_v2_headcls", "v2", 2, 64, (128, 128), 10, 2, {"use_middle_cls_token": False}),
+    # BASELINE config 1 at its full depth: AuM-Tiny, 12 Fo-Bi blocks, SpeechCommands shape (L = 65), batch 4
+    ("tiny_v1_d12", "v1", 12, 192, (128, 128), 35, 4),
 ]
 
 

@@ -11,5 +11,9 @@ import build_emu  # noqa: E402
 
 if __name__ == "__main__":
     aum_hip._product = aum_hip.Lib(build_emu.build(), host=True)
+    import json
     from aum import train
     train.main(sys.argv[1:])
+    exp = sys.argv[sys.argv.index("--exp-dir") + 1]
+    with open(os.path.join(exp, f"host_syncs_rank{os.environ.get('RANK', '0')}.json"), "w") as f:
+        json.dump(train.HOST_SYNCS, f)

@@ -196,6 +196,56 @@ def test_launcher_train_then_eval(toy_dataset, tmp_path):
     assert r2.shape == (6,) and abs(r2[0] - res[1, 0]) < 1e-6 and abs(r2[5] - res[1, 6]) < 1e-5
 
 
+def test_hot_loop_has_no_per_step_host_sync(toy_dataset, tmp_path, monkeypatch):
+    """SURVEY 5 / TT:157-174: the reference reads the loss back and gathers it every step.  Here the running loss stays on the
+    device; the loop touches the host only every --n-print-steps steps and once per epoch."""
+    from aum import train as T
+    calls = {"item": 0, "tolist": 0, "at_validate": None, "fe_calls": 0, "at_step2": None}
+    real_item, real_tolist, real_validate = torch.Tensor.item, torch.Tensor.tolist, T.validate
+    pkg = os.sep + "audio-mamba-aum_amd" + os.sep
+
+    def spy(real, name):      # only calls made by the package itself count (torch's CPU Adam reads its host-side step counters)
+        def f(self):
+            if pkg in sys._getframe(1).f_code.co_filename:
+                calls[name] += 1
+            return real(self)
+        return f
+    monkeypatch.setattr(torch.Tensor, "item", spy(real_item, "item"))
+    monkeypatch.setattr(torch.Tensor, "tolist", spy(real_tolist, "tolist"))
+
+    def validate_spy(*a, **kw):
+        if calls["at_validate"] is None:
+            calls["at_validate"] = (calls["item"], calls["tolist"])
+        return real_validate(*a, **kw)
+    monkeypatch.setattr(T, "validate", validate_spy)
+    real_fe = T.Frontend.__call__
+
+    def fe_spy(self, *a, **kw):          # the training frontend runs once per step: the second call marks the steady state
+        calls["fe_calls"] += 1
+        if calls["fe_calls"] == 2:
+            calls["at_step2"] = (calls["item"], calls["tolist"])
+        return real_fe(self, *a, **kw)
+    monkeypatch.setattr(T.Frontend, "__call__", fe_spy)
+    before = dict(T.HOST_SYNCS)
+    T.main(["--model", "aum", "--model_type", "tiny", "--depth", "1", "--n_class", "4", "--label-csv", str(toy_dataset / "labels.csv"),
+            "--data-train", str(toy_dataset / "train.json"), "--data-val", str(toy_dataset / "val.json"), "--audio_length", "64",
+            "--num-workers", "0", "-b", "2", "--mixed_precision", "no", "--exp-dir", str(tmp_path / "exp"), "--n-epochs", "1",
+            "--n-print-steps", "1000", "--freqm", "0", "--timem", "0", "--mixup", "0"])
+    assert T.HOST_SYNCS["steps"] - before["steps"] == 5                  # 10 clips / batch 2
+    assert T.HOST_SYNCS["loss_syncs"] - before["loss_syncs"] == 1         # the end-of-epoch exchange only
+    # steps 2..5 and the end-of-epoch exchange: no .item() at all, one .tolist() (the exchange)
+    assert (calls["at_validate"][0] - calls["at_step2"][0], calls["at_validate"][1] - calls["at_step2"][1]) == (0, 1), calls
+
+
+def test_validation_drops_sampler_padding():
+    """rows gathered from world ranks, DistributedSampler order: positions >= len(dataset) are the sampler's padding"""
+    from aum.train import _gather_order
+    # 7 samples, 2 ranks -> 4 per rank (one pad), batch 3: steps of 3 + 1 rows per rank
+    order = _gather_order(2, 3, 4, 2)
+    assert order.tolist() == [0, 2, 4, 1, 3, 5, 6, 7]
+    assert (order < 7).sum() == 7 and sorted(order[order < 7].tolist()) == list(range(7))
+
+
 def test_launcher_rejects_out_of_scope():
     from aum import train as T
     for extra in (["--model", "ast"], ["--dataset", "epic_sounds"], ["--flexible_training", "True"]):
@@ -226,6 +276,9 @@ def test_launcher_two_ranks_gloo(toy_dataset, tmp_path):
     assert np.loadtxt(exp + "/predictions/target.csv", delimiter=",").shape == (6, 4)    # 6 clips over 2 ranks, all kept
     sd = torch.load(exp + "/models/best_audio_model.pth")
     assert all(k.startswith("module.") for k in sd)                          # what the reference's DDP runs save
+    for r_ in (0, 1):    # 5 clips per rank / batch 2 = 3 steps; the loss crossed ranks once (end of epoch), never per step
+        hs = json.load(open(exp + f"/host_syncs_rank{r_}.json"))
+        assert hs == {"steps": 3, "loss_syncs": 1}, hs
 
 
 def test_tunableop_solution_file_is_seeded_per_rank(monkeypatch, tmp_path):
