@@ -84,6 +84,36 @@ def cpu_baseline(target_seconds=20.0):
                       f"(L=513), median of {reps} runs = {t_block:.2f} s/block, scaled x24 blocks"}
 
 
+def cpu_baseline_torch_ref():
+    """The baseline north_star names: the reference's pure-PyTorch `selective_scan_ref` (SSI:86-152: an O(L) Python loop over a
+    materialised [B,E,L,N] tensor) -- here the package's restatement of it, same loop -- forward + autograd backward on the host
+    cores, both directions of one AuM-Base Fo-Bi block, scaled by the 24 blocks.  The scans only (no projections, conv, norm)."""
+    import torch as T
+    from mamba_ssm.ops.selective_scan_interface import selective_scan_ref
+    T.manual_seed(0)
+    Bc, E, L, N = 1, 1536, 513, 16
+    mk = lambda *s: T.randn(*s, requires_grad=True)
+    u, delta, z = mk(Bc, E, L), (0.5 * T.randn(Bc, E, L)).requires_grad_(True), mk(Bc, E, L)
+    Bm, Cm = mk(Bc, 1, N, L), mk(Bc, 1, N, L)
+    A = (-T.arange(1, N + 1, dtype=T.float32).repeat(E, 1)).requires_grad_(True)
+    D, bias = T.ones(E, requires_grad=True), T.full((E,), -4.0, requires_grad=True)
+    t0 = time.time()
+    selective_scan_ref(u, delta, A, Bm, Cm, D, z, bias, True).sum().backward()       # one direction, forward + autograd backward
+    t_dir = time.time() - t0
+    return {"value": round(Bc / (24 * 2 * t_dir), 5), "unit": "clips/s", "cores": T.get_num_threads(), "kind": "port",
+            "sample": f"torch selective_scan_ref loop (package restatement of SSI:86-152, fp32, torch {T.__version__}, "
+                      f"{T.get_num_threads()} threads): ONE scan direction of 1 of 24 AuM-Base Fo-Bi blocks, forward + autograd "
+                      f"backward on {Bc} clip (E=1536, L=513, N=16), single run = {t_dir:.2f} s, scaled x2 directions x24 blocks; "
+                      "scans only (no projections, conv, norm)"}
+
+
+def step_alg_bytes(batch, length, d_model, depth, s=2):
+    """SURVEY.md 8(d) whole-layer estimate under an op-boundary decomposition (norm, in_proj, conv, x_proj, dt_proj, bidirectional
+    scan, out_proj): forward 26 H s + 8 H bytes, backward 47 H s + 12 H bytes per layer, H = batch * length * d_model."""
+    H = batch * length * d_model
+    return depth * ((26 + 47) * H * s + (8 + 12) * H)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +206,20 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     aum_hip.timer.enabled = False
+    # the same step without the optimizer (SURVEY 8d asks for both figures); a few extra steps, not part of `value`
+    def step_no_opt():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            l_ = loss_fn(net(spec()).float(), y)
+        l_.backward()
+        opt.zero_grad(set_to_none=True)
+    n_extra = max(2, min(5, args.steps))
+    step_no_opt()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n_extra):
+        step_no_opt()
+    torch.cuda.synchronize()
+    ms_no_opt = (time.perf_counter() - t1) / n_extra * 1e3
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -204,6 +248,8 @@ def main():
         vb = os.path.join(ROOT, "profiles", "valu_busy.json")
         if os.path.exists(vb) and dom in json.load(open(vb)):
             roof["valu"] = json.load(open(vb))[dom]             # vector-ALU occupancy of the same kernel (SQ PMC pass)
+        if isinstance(roof.get("valu"), dict) and "valu_busy_frac" in roof["valu"]:
+            roof["valu_frac"] = roof["valu"]["valu_busy_frac"]
         if dom.startswith("scan"):
             roof["note"] = ("VALU-bound kernel (16 states x 2 directions x v_exp_f32 per element, ~6100 vector instructions per "
                             "513-step row): SQ_ACTIVE_INST_VALU shows the vector ALU 74% (backward) / 77% (forward) busy "
@@ -220,11 +266,20 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}" + (" (DDP, RCCL all-reduce overlapped with backward)" if world > 1 else "")},
             "roofline": roof,
+            # whole step against the HBM roofline: SURVEY 8(d)'s algorithmic bytes of the 24 layers / measured step time
+            "step_roofline": {"bound": "hbm", "alg_bytes_per_step": step_alg_bytes(args.batch, 513, model.embed_dim, args.depth),
+                              "achieved": round(step_alg_bytes(args.batch, 513, model.embed_dim, args.depth) / (elapsed / args.steps) / 1e9, 1),
+                              "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": round(step_alg_bytes(args.batch, 513, model.embed_dim, args.depth) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, 4)},
+            "ms_per_step_without_optimizer": round(ms_no_opt, 3),
+            "dist": {"world_size": world, "backend": (dist.get_backend() if dist is not None else None),
+                     "rccl": bool(dist is not None and dist.get_backend() == "nccl")},
             "kernel_ms_per_step": {k: round(v, 3) for k, v in sorted(per_step.items())},
             "final_loss": round(final_loss, 5),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline_torch_ref"] = cpu_baseline_torch_ref()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
