@@ -243,3 +243,34 @@ PROJ_CASES = [
     ("tiny_ranks", 64, 12, 16, 2, 33),       # AuM-Tiny: R = 12 (k-groups straddle R), one staging step pair
     ("n8", 64, 8, 8, 5, 13),                 # d_state 8, ntok = 65 (one full tile + 1 token)
 ]
+
+
+# ---- launcher and checkpoint (8f2) fixtures: the reference's own traintest.train / AudioMamba(aum_pretrain=True) ----
+# tiny Fo-Bi model on 64-frame clips, 16 training clips in batches of 4 (4 steps per epoch), 2 epochs; bs_scale_factor 16 makes
+# the 50-step warm-up stairs of TT:118-124 three steps wide (lr changes at steps 0, 3, 6), scales Adam's betas to (0.2, 0.984)
+# and eps to 2.5e-9 (TT:25-33), and the MultiStepLR milestone falls on epoch 2
+TRAIN_CASE = dict(depth=1, embed_dim=32, spec=(128, 64), n_class=4, batch=4, n_train=16, n_val=6, n_epochs=2, lr=2e-3,
+                  bs_scale_factor=16, weight_decay=5e-7, lrscheduler_start=1, lrscheduler_step=1, lrscheduler_decay=0.5)
+
+
+def train_inputs():
+    r = _rng("train_data")
+    c = TRAIN_CASE
+    f = np.float32
+    mk = lambda n: dict(x=(0.5 * r.normal(0, 1, (n, c["spec"][1], c["spec"][0]))).astype(f),
+                        y=(r.random((n, c["n_class"])) < 0.35).astype(f))
+    tr, va = mk(c["n_train"]), mk(c["n_val"])
+    va["y"][:c["n_class"]] = np.eye(c["n_class"], dtype=f)        # every class has a positive in the validation set (AP defined)
+    va["y"][c["n_class"]:] = 0
+    va["y"][c["n_class"]:, 0] = 1
+    return tr, va
+
+
+# checkpoint re-grid: a (128 x 256)-frame model with 7 classes loaded into a (128 x 512)-frame model with 3 classes
+CKPT_CASE = dict(depth=1, embed_dim=32, src_spec=(128, 256), src_classes=7, dst_spec=(128, 512), dst_classes=3, batch=2)
+
+
+def ckpt_inputs():
+    r = _rng("ckpt_in")
+    c = CKPT_CASE
+    return dict(x=(0.5 * r.normal(0, 1, (c["batch"], c["dst_spec"][1], c["dst_spec"][0]))).astype(np.float32))

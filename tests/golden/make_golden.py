@@ -264,8 +264,106 @@ def model_goldens(torch, ssi, ln):
     print("model.npz", len(out))
 
 
+def launcher_goldens(torch, ssi, ln):
+    """the reference's own training loop (src/traintest.py `train`, run unmodified on CPU through
+    accelerate) and its own checkpoint loading (`AudioMamba(aum_pretrain=True)`, MM:397-446 + TOK:26-66) on the seeded toy
+    problems of cases.py.  Stored: learning rate at every optimizer step, Adam's hyper-parameters, result.csv (train / valid loss,
+    metrics, lr per epoch), the parameters after training; the re-gridded position embedding and the logits of the loaded model."""
+    import contextlib
+    import importlib.util
+    import io
+    import tempfile
+    from argparse import Namespace
+    mm = import_reference_model(torch, ssi, ln)
+    out = {}
+    quiet = lambda: contextlib.redirect_stdout(io.StringIO())
+
+    # ---------------- f2: checkpoint with a different clip length and class count ----------------
+    c = cases.CKPT_CASE
+    kw = dict(depth=c["depth"], embed_dim=c["embed_dim"], bimamba_type="v1")
+    with quiet():
+        src = mm.AudioMamba(spectrogram_size=c["src_spec"], num_classes=c["src_classes"], **kw)
+    vals = cases.model_state({k: tuple(v.shape) for k, v in src.state_dict().items()}, "ckpt_src")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "src.pth")
+        torch.save({"module." + k: torch.tensor(v) for k, v in vals.items()}, path)       # as a DDP run saves it
+        with quiet():
+            dst = mm.AudioMamba(spectrogram_size=c["dst_spec"], num_classes=c["dst_classes"], aum_pretrain=True,
+                                aum_pretrain_path=path, **kw)
+    head = cases.model_state({k: tuple(v.shape) for k, v in dst.state_dict().items() if k.startswith("head.")}, "ckpt_dst_head")
+    dst.load_state_dict({k: torch.tensor(v) for k, v in head.items()}, strict=False)       # the head is not in the checkpoint's shape
+    with torch.no_grad():
+        logits = dst(torch.tensor(cases.ckpt_inputs()["x"]))
+    out["ckpt.pos_embed"] = npy(dst.pos_embed.pos_embed)
+    out["ckpt.logits"] = npy(logits)
+    out["ckpt.checksum"] = cases.checksum(dict(vals, **cases.ckpt_inputs()))
+
+    # ---------------- f1: traintest.train ----------------
+    import accelerate
+    sys.path.insert(0, REF + "/src")
+    sys.modules.pop("utilities", None)
+    spec = importlib.util.spec_from_file_location("ref_traintest", REF + "/src/traintest.py")
+    tt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tt)
+    t = cases.TRAIN_CASE
+    tr, va = cases.train_inputs()
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self, d):
+            self.d = d
+
+        def __len__(self):
+            return len(self.d["x"])
+
+        def __getitem__(self, i):
+            return torch.tensor(self.d["x"][i]), torch.tensor(self.d["y"][i]), f"clip{i}"
+
+    with quiet():
+        model = mm.AudioMamba(spectrogram_size=t["spec"], depth=t["depth"], embed_dim=t["embed_dim"], num_classes=t["n_class"],
+                              bimamba_type="v1")
+    init = cases.model_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, "train_init")
+    model.load_state_dict({k: torch.tensor(v) for k, v in init.items()})
+    lrs, hyper = [], {}
+    RealAdam = torch.optim.Adam
+
+    class SpyAdam(RealAdam):
+        def __init__(self, params, lr, **kwargs):
+            hyper.update(dict(lr=lr, **kwargs))
+            super().__init__(params, lr, **kwargs)
+
+        def step(self, *a, **k):
+            lrs.append(self.param_groups[0]["lr"])
+            return super().step(*a, **k)
+
+    with tempfile.TemporaryDirectory() as exp:
+        os.makedirs(exp + "/models")
+        args = Namespace(accelerator=accelerate.Accelerator(cpu=True), lr=t["lr"], weight_decay=t["weight_decay"],
+                         bs_scale_factor=t["bs_scale_factor"], optim_path=None, exp_dir=exp, n_epochs=t["n_epochs"], metrics="mAP",
+                         loss="BCE", warmup=True, dataset="audioset", lrscheduler_start=t["lrscheduler_start"],
+                         lrscheduler_step=t["lrscheduler_step"], lrscheduler_decay=t["lrscheduler_decay"], model="aum",
+                         flexible_training=False, if_random_cls_token_position=False, if_nan2num=True, if_continue_inf=False,
+                         save_model=True)
+        torch.optim.Adam = SpyAdam
+        try:
+            with quiet(), contextlib.redirect_stderr(io.StringIO()):
+                tt.train(model, torch.utils.data.DataLoader(DS(tr), batch_size=t["batch"], shuffle=False),
+                         torch.utils.data.DataLoader(DS(va), batch_size=2 * t["batch"], shuffle=False), args)
+        finally:
+            torch.optim.Adam = RealAdam
+        out["train.result"] = np.loadtxt(exp + "/result.csv", delimiter=",")
+        out["train.predictions"] = np.loadtxt(exp + f"/predictions/predictions_{t['n_epochs']}.csv", delimiter=",")
+    out["train.lr_per_step"] = np.array(lrs, np.float64)
+    out["train.adam"] = np.array([hyper["betas"][0], hyper["betas"][1], hyper["eps"], hyper["weight_decay"], hyper["lr"]], np.float64)
+    for k, p_ in model.state_dict().items():
+        out["train.final." + k] = npy(p_)
+    out["train.checksum"] = cases.checksum(dict(init, tx=tr["x"], ty=tr["y"], vx=va["x"], vy=va["y"]))
+    np.savez_compressed(os.path.join(HERE, "launcher.npz"), **out)
+    print("launcher.npz", len(out))
+
+
 if __name__ == "__main__":
     main()
     if os.path.isdir(REF) and "--no-model" not in sys.argv:
         torch_, ssi_, ln_, _ = import_reference()
         model_goldens(torch_, ssi_, ln_)
+        launcher_goldens(torch_, ssi_, ln_)
