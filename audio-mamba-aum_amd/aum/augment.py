@@ -33,6 +33,30 @@ def spec_augment(fbank, freqm, timem, fill=0.0, generator=None):
     return fbank
 
 
+def draw_augmentation(batch, n_time, n_mel, freqm, timem, noise, device, generator=None):
+    """The random numbers of spec_augment + noise_roll for one batch, in THEIR draw order (so a seeded generator gives the same
+    augmentation either way), packed for the log-mel kernel's fused epilogue (aum_hip.fbank_fwd aug= / noise=):
+    returns (aug (batch, 8) fp32 with column 0 -- the frame count -- left at -1, noise (batch, n_time, n_mel) or None)."""
+    aug = torch.zeros((batch, 8), dtype=torch.float32, device=device)
+    aug[:, 0] = -1.0
+
+    def band(size, param):
+        value = torch.rand(batch, device=device, generator=generator) * param
+        start = torch.rand(batch, device=device, generator=generator) * (size - value)
+        lo = start.long()
+        return lo.float(), (lo + value.long()).float()
+    if freqm:
+        aug[:, 1], aug[:, 2] = band(n_mel, freqm)
+    if timem:
+        aug[:, 3], aug[:, 4] = band(n_time, timem)
+    nz = None
+    if noise:
+        aug[:, 6] = torch.rand(batch, 1, 1, device=device, generator=generator).flatten() / 10
+        nz = torch.rand((batch, n_time, n_mel), device=device, generator=generator)
+        aug[:, 5] = torch.randint(-10, 10, (batch,), device=device, generator=generator).float()
+    return aug, nz
+
+
 def noise_roll(fbank, generator=None):
     Bsz, T, Fd = fbank.shape
     dev = fbank.device

@@ -53,11 +53,12 @@ class FbankTables:
                            win=win, shift=shift, padded=padded)
 
 
-def wav2fbank(wave, tables, target_length=1024, norm_mean=AUDIOSET_MEAN, norm_std=AUDIOSET_STD):
+def wav2fbank(wave, tables, target_length=1024, norm_mean=AUDIOSET_MEAN, norm_std=AUDIOSET_STD, aug=None, noise=None):
     """wave: (batch, n_samples) fp32 on the GPU -> (batch, target_length, num_mel) normalised log-mel, what
-    AudiosetDataset.__getitem__ returns per clip (without SpecAug / mixup)."""
+    AudiosetDataset.__getitem__ returns per clip (without mixup).  aug / noise: the per-clip augmentation table and noise
+    field of aum.augment.draw_augmentation, applied inside the kernel's store."""
     wave = wave - wave.mean(dim=1, keepdim=True)                # dataloader.py:101
-    return aum_hip.fbank_fwd(wave.contiguous(), tables.tables, target_length, norm_mean, norm_std)
+    return aum_hip.fbank_fwd(wave.contiguous(), tables.tables, target_length, norm_mean, norm_std, aug=aug, noise=noise)
 
 
 def pad_fill(norm_mean=AUDIOSET_MEAN, norm_std=AUDIOSET_STD):
@@ -65,13 +66,16 @@ def pad_fill(norm_mean=AUDIOSET_MEAN, norm_std=AUDIOSET_STD):
     return (0.0 - norm_mean) / (2.0 * norm_std)
 
 
-def wav2fbank_ragged(wave, n_valid, tables, target_length=1024, norm_mean=AUDIOSET_MEAN, norm_std=AUDIOSET_STD):
+def wav2fbank_ragged(wave, n_valid, tables, target_length=1024, norm_mean=AUDIOSET_MEAN, norm_std=AUDIOSET_STD, aug=None,
+                     noise=None):
     """Clips of different lengths in one launch: wave (batch, max_samples) zero-padded, n_valid (batch,) samples.
     Kaldi's snip_edges framing only emits frames that lie inside the clip, so frames past 1 + (n - win)//shift are
-    the reference's ZeroPad2d rows (dataloader.py:139-145)."""
-    out = wav2fbank(wave, tables, target_length, norm_mean, norm_std)
+    the reference's ZeroPad2d rows (dataloader.py:139-145) -- written by the kernel itself (column 0 of the per-clip table).
+    aug / noise: SpecAug bands, noise and roll of aum.augment.draw_augmentation, applied in the same store."""
     win, shift = tables.tables["win"], tables.tables["shift"]
-    n_valid = torch.as_tensor(n_valid, device=out.device)
+    n_valid = torch.as_tensor(n_valid, device=wave.device)
     frames = torch.where(n_valid >= win, 1 + (n_valid - win) // shift, torch.zeros_like(n_valid))
-    pad = torch.arange(target_length, device=out.device)[None, :] >= frames[:, None]
-    return out.masked_fill(pad[:, :, None], pad_fill(norm_mean, norm_std))
+    if aug is None:
+        aug = torch.zeros((wave.shape[0], aum_hip.FBANK_AUG), dtype=torch.float32, device=wave.device)
+    aug[:, 0] = frames.to(torch.float32)
+    return wav2fbank(wave, tables, target_length, norm_mean, norm_std, aug=aug, noise=noise)

@@ -176,14 +176,12 @@ class Frontend:
 
     def __call__(self, wave, n_valid):
         from .frontend import wav2fbank_ragged
-        from .augment import spec_augment, noise_roll
+        from .augment import draw_augmentation
         a = self.args
-        x = wav2fbank_ragged(wave, n_valid, self.tables, a.audio_length, a.dataset_mean, a.dataset_std)
-        if self.train:
-            x = spec_augment(x, a.freqm, a.timem, self.fill)
-            if a.noise:
-                x = noise_roll(x)
-        return x
+        aug = nz = None
+        if self.train and (a.freqm or a.timem or a.noise):       # DL:206-228, applied in the log-mel kernel's own store
+            aug, nz = draw_augmentation(wave.shape[0], a.audio_length, a.melbins, a.freqm, a.timem, a.noise, wave.device)
+        return wav2fbank_ragged(wave, n_valid, self.tables, a.audio_length, a.dataset_mean, a.dataset_std, aug=aug, noise=nz)
 
 
 def make_loader(args, path, train, D):

@@ -25,7 +25,7 @@ _ERR = {-1: "AUM_E_NULL", -2: "AUM_E_SHAPE", -3: "AUM_E_DTYPE", -4: "AUM_E_UNSUP
         -6: "AUM_E_LAUNCH"}
 
 _i64, _i32, _u32, _vp, _fp = C.c_int64, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class _Debug:
@@ -87,7 +87,8 @@ class FbankArgs(C.Structure):
                 + [(n, _i64) for n in ("wave_bs", "out_bs")]
                 + [(n, _i32) for n in ("batch", "n_samples", "win", "shift", "padded", "num_frames", "target_length",
                                        "num_mel", "mel_wstride")]
-                + [(n, C.c_float) for n in ("preemph", "norm_mean", "norm_inv2std", "log_floor")])
+                + [(n, C.c_float) for n in ("preemph", "norm_mean", "norm_inv2std", "log_floor")]
+                + [("aug", _vp), ("noise", _vp)])
 
 
 class ProjArgs(C.Structure):
@@ -508,9 +509,14 @@ def rmsnorm_bwd(dy, x_saved, weight, rstd, dresidual=None, has_residual=False, x
     return dx, dw, dres_in
 
 
-def fbank_fwd(wave, tables, target_length, norm_mean, norm_std, preemph=0.97, lib=None):
+FBANK_AUG = 8     # columns of the per-clip augmentation table (include/aum_hip.h AUM_FBANK_AUG)
+
+
+def fbank_fwd(wave, tables, target_length, norm_mean, norm_std, preemph=0.97, aug=None, noise=None, lib=None):
     """Log-mel frontend.  wave: (batch, n_samples) fp32 mean-removed; tables: dict(window, twiddle, mel_start_f,
-    mel_count_f, mel_w [num_mel, stride], win, shift, padded) of device tensors built by aum.frontend.FbankTables."""
+    mel_count_f, mel_w [num_mel, stride], win, shift, padded) of device tensors built by aum.frontend.FbankTables.
+    aug: optional (batch, 8) fp32 per-clip table [frames, f_lo, f_hi, t_lo, t_hi, roll, noise_amp, 0] applied in the kernel's
+    store (ragged padding, SpecAug bands, noise, roll); noise: (batch, target_length, num_mel) fp32 uniform numbers."""
     lib = lib or get()
     lib.check_tensor(wave)
     assert wave.dtype == torch.float32 and wave.stride(1) == 1
@@ -528,6 +534,14 @@ def fbank_fwd(wave, tables, target_length, norm_mean, norm_std, preemph=0.97, li
     a.num_frames, a.target_length, a.num_mel, a.mel_wstride = num_frames, target_length, num_mel, stride
     a.preemph, a.norm_mean, a.norm_inv2std = preemph, norm_mean, 1.0 / (2.0 * norm_std)
     a.log_floor = 1.1920928955078125e-07
+    if aug is not None:
+        assert aug.dtype == torch.float32 and aug.is_contiguous() and aug.shape == (batch, FBANK_AUG)
+        lib.check_tensor(aug)
+        a.aug = _ptr(aug)
+    if noise is not None:
+        assert aug is not None and noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape == out.shape
+        lib.check_tensor(noise)
+        a.noise = _ptr(noise)
     _launch(lib.c.aum_fbank_fwd, a, wave, lib, "fbank_fwd", (batch, target_length, num_mel))
     return out
 

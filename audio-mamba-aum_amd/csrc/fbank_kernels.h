@@ -29,12 +29,31 @@ AUM_DEV void fbank_frame(const AumFbankArgs& p, int wg, float* lds) {
     float* im = lds + FBANK_MAX_FFT;
     float* pw = lds + 2 * FBANK_MAX_FFT;
     float* part = pw + FBANK_MAX_FFT / 2 + 1;
-    float* out = p.out + (int64_t)b * p.out_bs + (int64_t)frame * p.num_mel;
     const float pad_value = (0.f - p.norm_mean) * p.norm_inv2std;
-    if (frame >= p.num_frames) {            // reference zero-pads the fbank to target_length, then normalises
+    // per-clip augmentation table (ABI 4): ragged frame count, SpecAug bands, noise amplitude, roll -- all applied in the store
+    int n_frames = p.num_frames, f_lo = 0, f_hi = 0, t_lo = 0, t_hi = 0, roll = 0;
+    float amp = 0.f;
+    if (p.aug) {
+        const float* a = p.aug + (int64_t)b * AUM_FBANK_AUG;
+        if (a[0] >= 0.f) n_frames = (int)a[0] < p.num_frames ? (int)a[0] : p.num_frames;
+        f_lo = (int)a[1]; f_hi = (int)a[2]; t_lo = (int)a[3]; t_hi = (int)a[4];
+        roll = (int)a[5];
+        amp = a[6];
+    }
+    int frame_out = (frame + roll) % p.target_length;
+    if (frame_out < 0) frame_out += p.target_length;
+    float* out = p.out + (int64_t)b * p.out_bs + (int64_t)frame_out * p.num_mel;
+    const float* nz = (p.noise && amp != 0.f) ? p.noise + ((int64_t)b * p.target_length + frame) * p.num_mel : nullptr;
+    const bool t_masked = frame >= t_lo && frame < t_hi;
+    if (frame >= n_frames || t_masked) {    // zero padding of the reference (DL:139-145) / SpecAug time band: 0 before normalisation
         AUM_FOR_EACH_WAVE(w, FBANK_NW) {
-            const vi m = lane_id() + w * WAVE;
-            gstore(out, m, splat(pad_value), m < p.num_mel);
+            for (int m0 = w * WAVE; m0 < p.num_mel; m0 += FBANK_THREADS) {
+                const vi m = lane_id() + m0;
+                const vm ok = m < p.num_mel;
+                vf v = splat(pad_value);
+                if (nz) v = vfma(gload(nz, vmin_i(m, p.num_mel - 1), ok), splat(amp), v);
+                gstore(out, m, v, ok);
+            }
         }
         return;
     }
@@ -116,7 +135,10 @@ AUM_DEV void fbank_frame(const AumFbankArgs& p, int wg, float* lds) {
                 e = vfma(gload(p.mel_w, mc * p.mel_wstride + c, use), vsel(use, lds_read(pw, bin), splat(0.f)), e);
             }
             const vf v = vlog2(vmax(e, splat(p.log_floor))) * LN2;
-            gstore(out, m, (v - p.norm_mean) * p.norm_inv2std, ok);
+            vf o = (v - p.norm_mean) * p.norm_inv2std;
+            o = vsel((m >= f_lo) && (m < f_hi), splat(pad_value), o);          // SpecAug frequency band
+            if (nz) o = vfma(gload(nz, mc, ok), splat(amp), o);
+            gstore(out, m, o, ok);
         }
     }
 }

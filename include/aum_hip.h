@@ -27,8 +27,9 @@
 extern "C" {
 #endif
 
-#define AUM_ABI_VERSION 3   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
-                               3: x_lane (lane-entry state checkpoint of the L = 513 row kernels) appended after it */
+#define AUM_ABI_VERSION 4   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
+                               3: x_lane (lane-entry state checkpoint of the L = 513 row kernels) appended after it;
+                               4: aug / noise (per-clip augmentation in the log-mel kernel's epilogue) appended to AumFbankArgs */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 
@@ -200,7 +201,15 @@ typedef struct AumFbankArgs {
     int64_t wave_bs, out_bs;
     int32_t batch, n_samples, win, shift, padded, num_frames, target_length, num_mel, mel_wstride;
     float preemph, norm_mean, norm_inv2std, log_floor;
+    /* ABI 4, both optional.  aug: (batch, AUM_FBANK_AUG) fp32 per-clip table applied in the kernel's store (the training-time
+     * chain of src/dataloader.py:139-145, 206-228 without extra passes over the spectrogram):
+     *   [0] frames of this clip (ragged batches: frames >= it are the reference's zero padding; < 0: use num_frames)
+     *   [1],[2] frequency band [lo, hi) and [3],[4] time band [lo, hi) set to 0 BEFORE normalisation (SpecAug; empty when lo >= hi)
+     *   [5] roll along time (torch.roll shift, applied last)   [6] noise amplitude: out += noise[b][t][m] * amp, before the roll
+     * noise: (batch, target_length, num_mel) fp32 uniform numbers from the caller's generator, or NULL (no noise). */
+    const float *aug, *noise;
 } AumFbankArgs;
+#define AUM_FBANK_AUG 8
 int aum_fbank_fwd(const AumFbankArgs* args, void* stream);
 
 /*

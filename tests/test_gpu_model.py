@@ -11,11 +11,14 @@ from conftest import load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-# bf16 autocast vs the reference's fp32 goldens (test_audio_mamba_bf16_autocast_vs_reference_model); set from the measured errors
-# in profiles/r02_autocast_errors.json
-BF16_LOGIT_TOL = 3e-2
-BF16_GNORM_TOL = 1e-1
-BF16_GRAD_TOL = 1e-1
+# bf16 autocast vs the reference's FP32 goldens (test_audio_mamba_bf16_autocast_vs_reference_model), set from the measured errors
+# in profiles/r02_autocast_errors.json: logits 0.003-0.010 of the logit scale for the 2-4 block models -- north_star's 1e-2 bar -- and
+# 0.014 for the 12-block model (config 1): every block rounds its activations to bf16 (2^-9 relative), the errors add like a random
+# walk, so the bar scales with sqrt(depth / 4) beyond 4 blocks.  Gradient norms within 1.7 %, single gradient elements within 5.3 %
+# of the tensor's largest element (worst: dt_proj.bias, whose gradient is a sum over every token of a softplus' term).
+BF16_LOGIT_TOL = 1e-2
+BF16_GNORM_TOL = 2.5e-2
+BF16_GRAD_TOL = 7e-2
 
 
 @pytest.mark.parametrize("case", cases.MODEL_CASES, ids=lambda c: c[0])
@@ -82,7 +85,7 @@ def test_audio_mamba_bf16_autocast_vs_reference_model(case):
             e_elem[k] = rel_err(p_.grad.cpu().numpy(), g[f"{name}.grad.{k}"])
     worst_n, worst_e = max(e_norm, key=e_norm.get), max(e_elem, key=e_elem.get)
     _err_report(name, {"logits": e_logits, "gnorm_max": [worst_n, e_norm[worst_n]], "grad_elem_max": [worst_e, e_elem[worst_e]]})
-    assert e_logits < BF16_LOGIT_TOL, e_logits
+    assert e_logits < BF16_LOGIT_TOL * max(1.0, (depth / 4) ** 0.5), e_logits
     assert e_norm[worst_n] < BF16_GNORM_TOL, (worst_n, e_norm[worst_n])
     assert e_elem[worst_e] < BF16_GRAD_TOL, (worst_e, e_elem[worst_e])
 

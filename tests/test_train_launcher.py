@@ -124,7 +124,35 @@ def test_ragged_frontend_matches_per_clip():
     for i, n in enumerate(lens):
         ref = wav2fbank(wave_b[i:i + 1, :n].contiguous(), tabs, target_length=32)[0]
         assert torch.allclose(out[i], ref, atol=2e-4), i
-    assert torch.all(out[2] == pad_fill())                              # shorter than one window: all padding
+    assert torch.allclose(out[2], torch.full_like(out[2], pad_fill()), atol=1e-6)     # shorter than one window: all padding
+
+
+def test_fused_augmentation_matches_separate_ops():
+    """SpecAug bands, noise and roll applied inside the log-mel kernel's store (aug= / noise= of aum_fbank_fwd) give
+    the spectrogram the separate torch ops give after the kernel, for the same generator stream; ragged clips included."""
+    from aum.frontend import FbankTables, wav2fbank, wav2fbank_ragged, pad_fill
+    from aum.augment import spec_augment, noise_roll, draw_augmentation
+    tabs = FbankTables("cpu")
+    g = torch.Generator().manual_seed(3)
+    lens = [5200, 3000, 4100, 5200, 300]
+    wave_b = torch.zeros(5, 5200)
+    for i, n in enumerate(lens):
+        w = torch.randn(n, generator=g) * 0.1
+        wave_b[i, :n] = w - w.mean()
+    T_, F_ = 32, 128
+    # separate ops (what the launcher did before): kernel -> pad ragged -> masks -> noise + roll
+    plain = wav2fbank(wave_b, tabs, target_length=T_)
+    frames = torch.tensor([0 if n < 400 else min(T_, 1 + (n - 400) // 160) for n in lens])
+    plain = plain.masked_fill((torch.arange(T_)[None, :] >= frames[:, None])[:, :, None], pad_fill())
+    g1 = torch.Generator().manual_seed(11)
+    want = noise_roll(spec_augment(plain, 24, 10, pad_fill(), generator=g1), generator=g1)
+    g2 = torch.Generator().manual_seed(11)
+    aug, nz = draw_augmentation(5, T_, F_, 24, 10, True, "cpu", generator=g2)
+    got = wav2fbank_ragged(wave_b, torch.tensor(lens), tabs, target_length=T_, aug=aug, noise=nz)
+    assert torch.allclose(got, want, atol=1e-5), float((got - want).abs().max())
+    assert (aug[:, 2] > aug[:, 1]).any() and (aug[:, 4] > aug[:, 3]).any() and (aug[:, 5] != 0).any()
+    # no augmentation: the plain ragged result
+    assert torch.allclose(wav2fbank_ragged(wave_b, torch.tensor(lens), tabs, target_length=T_), plain, atol=1e-6)
 
 
 def test_stats_against_sklearn():
