@@ -474,7 +474,9 @@ AUM_DEV void scanr_bwd(const AumScanBwdArgs& p, int wg, float* lds, int rows_per
                         }
                     }
                 }
-                if ((j & BARRIER_MASK) == BARRIER_MASK && !(p.flags & AUM_DBG_NO_STEP_BARRIER)) AUM_WG_BARRIER_IN_PHASE();
+                // LDS-only barrier: the tiles are all the waves share, and __syncthreads() would drain vmcnt -- wait at every step
+                // for the checkpoint prefetch issued a few instructions earlier
+                if ((j & BARRIER_MASK) == BARRIER_MASK && !(p.flags & AUM_DBG_NO_STEP_BARRIER)) AUM_WG_BARRIER_LDS();
             }
             // ---- tail step: adjoint, gradients of u_512 / delta_512 / z_512, tail dB / dC / dA ----
             const vf x_t = vsel(tfwd, vfma(a_t, xm, b_t), b_t);

@@ -237,6 +237,9 @@ AUM_DEV float readlane(vf x, int lane) {
 AUM_DEV vf writelane(vf v, float s, int lane) { return (int)(threadIdx.x & 63u) == lane ? s : v; }
 // wave-uniform element of a row (every lane reads the same address)
 template <class T> AUM_DEV float gload_s(const T* p, int idx) { return elem_to_f32(p[idx]); }
+// a value the optimiser must treat as unknown at this point: address arithmetic that depends on it is not hoisted out of
+// the enclosing loop (where it would occupy registers for the whole loop)
+AUM_DEV vi opaque_i(vi x) { asm volatile("" : "+v"(x)); return x; }
 #define AUM_LDS(type, name, count) __shared__ type name[count]
 
 #else
@@ -364,6 +367,7 @@ inline vf dpp_wave_shl1(const vf& x, float old) { return dpp_wave_shl1(x, splat(
 inline float readlane(const vf& x, int lane) { return x.v[lane]; }
 inline vf writelane(const vf& v, float s, int lane) { vf r = v; r.v[lane] = s; return r; }
 template <class T> inline float gload_s(const T* p, int idx) { return elem_to_f32(p[idx]); }
+inline vi opaque_i(const vi& x) { return x; }
 #define AUM_LDS(type, name, count) type name[count]
 #endif  // AUM_EMU
 

@@ -58,6 +58,16 @@ def test_scan_row_kernels_lane_checkpoint(emu, case, mode):
     KC.check_scan(emu, "cpu", case, torch.float16, tol=2e-3, **kw)
 
 
+@pytest.mark.parametrize("case", [c for c in cases.SCAN_CASES if c[0] == "l513"] + cases.SCAN_ROW_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+def test_scan_state_kernel_backward(emu, case, mode, monkeypatch):
+    """scan_state_kernels.h (opt-in): waves own states, the workgroup's rows stream past them in a three-stage pipeline"""
+    monkeypatch.setattr(aum_hip.debug, "ablate", 64)
+    kw = dict(reverse=(mode == "rev"), bidir=(mode == "bidir"), lane_ckpt=True)
+    KC.check_scan(emu, "cpu", case, torch.float32, **kw)
+    KC.check_scan(emu, "cpu", case, torch.bfloat16, strided=True, **kw)
+
+
 def test_scan_lane_checkpoint_contract(emu):
     """x_lane exists only for rows the row kernels take; handing one to any other call is refused, not ignored"""
     assert aum_hip.scan_lane_ckpt(torch.zeros(2, 4, 65), 16, False, lib=emu) is None

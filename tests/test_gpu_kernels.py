@@ -59,6 +59,16 @@ def test_scan_row_kernels_lane_checkpoint(lib, case, mode, dtype):
     KC.check_scan(lib, "cuda", case, dtype, strided=True, **kw)
 
 
+@pytest.mark.parametrize("case", [c for c in cases.SCAN_CASES if c[0] == "l513"] + cases.SCAN_ROW_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_state_kernel_backward(lib, case, mode, dtype, monkeypatch):
+    """scan_state_kernels.h (opt-in: waves own states, rows stream through the workgroup) against the oracle"""
+    monkeypatch.setattr(aum_hip.debug, "ablate", 64)
+    KC.check_scan(lib, "cuda", case, dtype, reverse=(mode == "rev"), bidir=(mode == "bidir"), lane_ckpt=True)
+    KC.check_scan(lib, "cuda", case, dtype, reverse=(mode == "rev"), bidir=(mode == "bidir"), lane_ckpt=True, strided=True)
+
+
 def test_scan_row_kernels_full_size(lib):
     """AuM-Base block shape (B=8 of the 64, E=1536, L=513, N=16, bf16, d-major rows): the checkpointed row-kernel backward
     against the previous-generation backward (which recomputes the forward scan) on the same inputs -- same gradients up to
