@@ -20,14 +20,16 @@
 // lane-entry checkpoint (scan_row_kernels.h).
 //
 // STATUS (round 2, measured on MI355X, B = 64, bf16): parity-green (emulator + GPU, all three direction modes) but NOT the default --
-// opt-in through AUM_DBG_STATE_BWD.  One direction: 113 VGPRs, no scratch, 1.38 ms (scanh_bwd: 0.92 ms); with the state work ablated
-// away still 1.0 ms = 2.6 us per row: the row pipeline is latency-bound.  The listing shows why: the registers that carry the
-// prefetched rows across the loop are PHI-merged at the role branches and at the back edge of the two-row trip, hipcc materialises
-// the merges as v_mov copies at the end of the branch and puts `s_waitcnt vmcnt(0)` in front of them -- every iteration waits for
-// the loads it has just issued.  Both directions fused: the two direction bodies cost ~50 VGPRs more than one (183 wanted), 100
-// bytes of scratch per lane at the 128 of a 16-wave workgroup, 3.0 ms.  What the design needs next: prefetch through
-// LDS-DMA (global_load ... lds: no registers, no copies, counted vmcnt) instead of registers, and the second direction in 128 VGPRs.
-// Reference: SSI:62-65 / 541-561 (selective_scan_cuda.bwd call sites), SSI:86-152 (selective_scan_ref) for the math.
+// opt-in through AUM_DBG_STATE_BWD.  One direction: 107 VGPRs, no scratch, 1.16 ms (scanh_bwd: 0.92 ms); both directions fused: the
+// second direction body costs ~25 VGPRs more than the 128 of a 16-wave workgroup (36 B of scratch per lane), 2.08 ms (scanh_bwd
+// 1.41 ms).  Phase stamps (tools/scans_trace.py, profiles/r02_state_kernel_phase_trace.txt): an iteration takes 7.7 k cycles where
+// the state work of four waves per SIMD is ~2.3 k at full VALU rate -- the waves that carry a tail role reach the first barrier last
+// (3.0 k state work + 1.7 k of serial, wave-uniform tail arithmetic), and barrier + share hand-off + barrier add ~2 k.  What fixed
+// the first version (1.38 ms, 2.6 us per row with the state work ablated): one definition point for every prefetch register (per-role
+// branches around the loads made hipcc merge them through v_mov copies behind `s_waitcnt vmcnt(0)`), row parameters in LDS
+// instead of per-row parameter loads, batched LDS reads in P3, opaque lane ids in the role code (hoisted 64-bit addresses cost 20
+// VGPRs).  Next: tail roles off the critical path, one barrier per row (counter instead of barrier 1), the second
+// direction inside 128 VGPRs.
 #pragma once
 #include "scan_row_kernels.h"
 
@@ -48,13 +50,19 @@ constexpr int SCANS_OFF_TIN = SCANS_OFF_PART + SCANS_NW * 2 * SCANS_ROWBUF;     
 constexpr int SCANS_TOUT = 2 * SCANS_TC + 4 * SCANS_TC;                         // [TC] x_last | [TC] ga_last | [TC][4] dA shares
 constexpr int SCANS_OFF_TOUT = SCANS_OFF_TIN + 3 * 4 * SCANS_TC;                // [2][TOUT]
 constexpr int SCANS_OFF_TCONST = SCANS_OFF_TOUT + 2 * SCANS_TOUT;               // [TC] B_512 | [TC] C_512 | [TC] tail dB | [TC] tail dC
-constexpr int SCANS_LDS_FLOATS = SCANS_OFF_TCONST + 4 * SCANS_TC;
+// per-row parameters of the workgroup's rows, loaded once: no wave waits for a parameter load inside the row loop
+constexpr int SCANS_OFF_ROWC = SCANS_OFF_TCONST + 4 * SCANS_TC;                 // [rows][2]          delta_bias | D
+constexpr int SCANS_OFF_ATAB = SCANS_OFF_ROWC + 2 * 64;                         // [rows][2][16]      A | A_b
+constexpr int SCANS_LDS_FLOATS = SCANS_OFF_ATAB + 64 * 2 * 16;
 enum { SCANS_TS_DL = 0, SCANS_TS_U = 1, SCANS_TS_DY = 2, SCANS_TS_DSP = 3 };   // scalars of the tail step, P1-tail -> P3-tail
 AUM_HOSTDEV constexpr int scans_rows() { return 64; }   // rows per workgroup (a row costs every wave one P2 step)
 constexpr int SCANS_NSLICE = 5;                         // dD / ddelta_bias partials per (batch, row): 4 P3 slices + the tail
 
 // workspace of this kernel (floats): per-workgroup dB/dC partial rows, per-batch dA, per-(batch, slice) dD / ddelta_bias
-struct ScanSWs { int64_t pB, pC, pA, pAb, pD, pbias, total; int gpb; };
+// debug trace (AUM_DBG_TRACE, workgroup 0): shader-clock stamps of the pipeline phases, [wave][iteration][8 slots] uint32
+constexpr int SCANS_TRACE_ITERS = 24, SCANS_TRACE_SLOTS = 8;
+constexpr int SCANS_TRACE_FLOATS = SCANS_NW * SCANS_TRACE_ITERS * SCANS_TRACE_SLOTS;
+struct ScanSWs { int64_t pB, pC, pA, pAb, pD, pbias, trace, total; int gpb; };
 AUM_HOSTDEV ScanSWs scans_ws_layout(int batch, int dim, int len, int N, bool bidir) {
     ScanSWs w;
     w.gpb = (dim + scans_rows() - 1) / scans_rows();
@@ -66,6 +74,7 @@ AUM_HOSTDEV ScanSWs scans_ws_layout(int batch, int dim, int len, int N, bool bid
     w.pAb = o; o += bidir ? (int64_t)batch * dim * N : 0;
     w.pD = o; o += (int64_t)batch * SCANS_NSLICE * dim;
     w.pbias = o; o += (int64_t)batch * SCANS_NSLICE * dim;
+    w.trace = o; o += SCANS_TRACE_FLOATS;
     w.total = o;
     return w;
 }
@@ -76,9 +85,8 @@ template <class T> struct __attribute__((packed, aligned(sizeof(T) < 4 ? sizeof(
 #ifdef AUM_EMU
 template <class T> struct ScansRaw2 { vf2 v; };
 template <class T> AUM_DEV ScansRaw2<T> scans_fetch2(const T* rp, vi t0) { return ScansRaw2<T>{mk2(gload_u(rp, t0), gload_u(rp, t0 + 1))}; }
-template <class T> AUM_DEV ScansRaw2<T> scans_fetch1(const T* rp, int t) { return ScansRaw2<T>{mk2(splat(gload_s(rp, t)), splat(0.f))}; }
 template <class T> AUM_DEV vf2 scans_unpack(const ScansRaw2<T>& r) { return r.v; }
-template <class T> AUM_DEV float scans_unpack1(const ScansRaw2<T>& r) { return r.v.x.v[0]; }
+template <class T> AUM_DEV float scans_unpack_hi(const ScansRaw2<T>& r) { return r.v.y.v[0]; }
 template <class T> AUM_DEV void scans_store2(T* rp, vi t0, vf2 v) {
     gstore(rp, t0, lo2(v), lane_id() >= 0);
     gstore(rp, t0 + 1, hi2(v), lane_id() >= 0);
@@ -100,12 +108,6 @@ template <class T> AUM_DEV ScansRaw2<T> scans_fetch2(const T* rp, vi t0) {
     }
     return r;
 }
-template <class T> AUM_DEV ScansRaw2<T> scans_fetch1(const T* rp, int t) {
-    ScansRaw2<T> r;
-    if constexpr (sizeof(T) == 2) r.w0 = (uint32_t)rp[t].bits; else r.w0 = __builtin_bit_cast(uint32_t, rp[t]);
-    r.w1 = 0;
-    return r;
-}
 template <class T> AUM_DEV float scans_bits_to_f32(uint32_t lo16) {
     if constexpr (__is_same(T, bf16_t)) return bits_to_f32(lo16 << 16);
     else return (float)__builtin_bit_cast(_Float16, (uint16_t)lo16);
@@ -118,8 +120,10 @@ template <class T> AUM_DEV vf2 scans_unpack(const ScansRaw2<T>& r) {
         return mk2(bits_to_f32(r.w0), bits_to_f32(r.w1));
     }
 }
-template <class T> AUM_DEV float scans_unpack1(const ScansRaw2<T>& r) {
-    if constexpr (sizeof(T) == 2) return scans_bits_to_f32<T>(r.w0 & 0xffffu); else return bits_to_f32(r.w0);
+// second element of a fetched pair as a wave-uniform value (the tail wave fetches steps 511 | 512 in every lane)
+template <class T> AUM_DEV float scans_unpack_hi(const ScansRaw2<T>& r) {
+    const vf2 v = scans_unpack<T>(r);
+    return readlane(hi2(v), 0);
 }
 template <class T> AUM_DEV void scans_store2(T* rp, vi t0, vf2 v) {
     scans_pair_t<T> r;
@@ -173,11 +177,9 @@ template <bool V> struct ScansBool { static constexpr bool value = V; };
 template <class T> struct ScansWave {
     vf2 Bn[4], Cn[4], dBacc[4], dCacc[4];   // this wave's state: B, C of the batch entry; dB, dC summed over the workgroup's rows
     vf2 G[4], DA[4];                        // this state's shares of the current row, between the state work and their hand-off
-    vf xin[2][2];                           // lane-entry states of the next two rows (row parity, direction slot)
-    float An[2][2];                         // A (A_b) of this wave's state for the next two rows
-    ScansRaw2<T> raw[5];                    // P1 waves: u, delta, dout, z, out_pre of the next row, two steps per lane
-                                            // (the P1-tail wave keeps step 512 of the same five rows in the first halves)
-    vf tA;                                  // tail waves: A of the next row (lane 16*d + n)
+    vf xin[1][2];                           // lane-entry states of the next row (direction slot)
+    ScansRaw2<T> raw[5];                    // u, delta, dout, z, out_pre of the next row, two steps per lane (P1 waves: their
+                                            // slice; the P1-tail wave: steps 511 | 512 in every lane)
 };
 
 template <class T, int MODE>
@@ -199,6 +201,11 @@ AUM_DEV void scans_bwd(const AumScanBwdArgs& p, int wg, float* lds) {
     float* tin = lds + SCANS_OFF_TIN;
     float* tout = lds + SCANS_OFF_TOUT;
     float* tconst = lds + SCANS_OFF_TCONST;
+    float* rowc = lds + SCANS_OFF_ROWC;
+    float* atab = lds + SCANS_OFF_ATAB;
+    static_assert(scans_rows() == 64, "row tables are sized for 64 rows per workgroup");
+    auto row_bias = [&](int r) { return readlane(lds_read(rowc, spl_i(2 * r)), 0); };
+    auto row_D = [&](int r) { return readlane(lds_read(rowc, spl_i(2 * r + 1)), 0); };
     ScansWave<T> st[AUM_PER_WAVE(NW)];
 
     auto urow = [&](int r) { return row_ptr<T>(p.u, (int64_t)b * p.u_bs + (int64_t)(eb + r) * p.u_ds); };
@@ -206,10 +213,14 @@ AUM_DEV void scans_bwd(const AumScanBwdArgs& p, int wg, float* lds) {
     auto grow = [&](int r) { return row_ptr<T>(p.dout, (int64_t)b * p.dout_bs + (int64_t)(eb + r) * p.dout_ds); };
     auto zrow = [&](int r) { return row_ptr<T>(p.z, (int64_t)b * p.z_bs + (int64_t)(eb + r) * p.z_ds); };
     auto yrow = [&](int r) { return row_ptr<T>(p.out_pre, (int64_t)b * p.out_bs + (int64_t)(eb + r) * p.out_ds); };
-    // raw data of row r for the P1 roles (clamped row index: the loads of rows past the end are harmless and never used)
-    auto fetch_slice = [&](ScansWave<T>& S, int w, int r) {
+    // Prefetch of row r for the P1 roles.  EVERY wave executes the same five loads (waves 0-3: their 128-step slice, two steps per
+    // lane; wave 8: steps 511 | 512 in every lane; the others repeat a slice and never look at the result): the registers that
+    // carry the data to the next iteration then have ONE definition per iteration -- with per-role branches around the loads hipcc
+    // merges the variants through v_mov copies at the end of the branch, behind an s_waitcnt vmcnt(0) for the loads just issued.
+    auto fetch_raw = [&](ScansWave<T>& S, int w, int r) {
         const int rc = r < R ? r : R - 1;
-        const vi t0 = opaque_i(lane_id()) * 2 + w * 128;
+        const vi lane = opaque_i(lane_id());
+        const vi t0 = w == 8 ? spl_i(SCANR_LEN - 2) : lane * 2 + (w & 3) * 128;
         S.raw[0] = scans_fetch2<T>(urow(rc), t0);
         S.raw[1] = scans_fetch2<T>(drow(rc), t0);
         S.raw[2] = scans_fetch2<T>(grow(rc), t0);
@@ -218,34 +229,21 @@ AUM_DEV void scans_bwd(const AumScanBwdArgs& p, int wg, float* lds) {
             S.raw[4] = scans_fetch2<T>(yrow(rc), t0);
         }
     };
-    auto fetch_tailA = [&](ScansWave<T>& S, int r) {
-        const int rc = r < R ? r : R - 1;
-        const vi lane = opaque_i(lane_id());
-        const vi tn = vmin_i(lane & 15, N - 1);
+    // A of row r for the tail roles, lane 16*d + n, from the workgroup's table
+    auto tail_A = [&](int r) {
+        const vi lane = lane_id();
+        const vi tl = vmin_i(lane, SCANS_TC - 1);
         const vm tvalid = (lane < 16 * ND) && ((lane & 15) < N);
-        S.tA = gload(p.A + (int64_t)(eb + rc) * N, tn, tvalid && (lane < 16));
-        if (BI) S.tA = S.tA + gload(p.A_b + (int64_t)(eb + rc) * N, tn, tvalid && (lane >= 16));
+        return vsel(tvalid, lds_read(atab, tl + r * 32), splat(0.f));
     };
-    auto fetch_tail = [&](ScansWave<T>& S, int r) {
-        const int rc = r < R ? r : R - 1;
-        fetch_tailA(S, r);
-        S.raw[0] = scans_fetch1<T>(urow(rc), SCANR_LEN - 1);
-        S.raw[1] = scans_fetch1<T>(drow(rc), SCANR_LEN - 1);
-        S.raw[2] = scans_fetch1<T>(grow(rc), SCANR_LEN - 1);
-        if (p.z) {
-            S.raw[3] = scans_fetch1<T>(zrow(rc), SCANR_LEN - 1);
-            S.raw[4] = scans_fetch1<T>(yrow(rc), SCANR_LEN - 1);
-        }
-    };
-    auto fetch_xin = [&](auto par_tag, ScansWave<T>& S, int w, int r) {       // into the slot of row parity PAR == r & 1
-        constexpr int PAR = decltype(par_tag)::value ? 1 : 0;
+    auto fetch_xin = [&](ScansWave<T>& S, int w, int r) {
+        constexpr int PAR = 0;
         const int rc = r < R ? r : R - 1;
         const int n = w < N ? w : 0;
         const float* ck = p.x_lane + ((int64_t)b * p.dim + eb + rc) * ND * N * WAVE;
         AUM_UNROLL
         for (int d = 0; d < ND; ++d) {
             S.xin[PAR][d] = gload(ck + ((int64_t)d * N + n) * WAVE, opaque_i(lane_id()), lane_id() >= 0);
-            S.An[PAR][d] = (d == 0 ? p.A : p.A_b)[(int64_t)(eb + rc) * N + n];
         }
     };
     // ---- P1: prepare row r (slice w of the main steps) ----
@@ -253,7 +251,7 @@ AUM_DEV void scans_bwd(const AumScanBwdArgs& p, int wg, float* lds) {
         const vi t0 = opaque_i(lane_id()) * 2 + w * 128;
         const vi word = scans_word(t0);
         float* pb = prep + (r % 3) * SCANS_NPREP * SCANS_ROWBUF;
-        const float bias = p.delta_bias ? p.delta_bias[eb + r] : 0.f;
+        const float bias = row_bias(r);
         const vf2 one2 = spl2(splat(1.f));
         const vf2 uu = scans_unpack<T>(S.raw[0]);
         const vf2 dr = scans_unpack<T>(S.raw[1]) + spl2(splat(bias));
@@ -283,20 +281,20 @@ AUM_DEV void scans_bwd(const AumScanBwdArgs& p, int wg, float* lds) {
         const vi tlc = vmin_i(lane, SCANS_TC - 1);
         const vf B_t = lds_read(tconst, tlc), C_t = lds_read(tconst + SCANS_TC, tlc);
         float* tb = tin + (r % 3) * 4 * SCANS_TC;
-        const float bias = p.delta_bias ? p.delta_bias[eb + r] : 0.f;
-        const float u_t = scans_unpack1<T>(S.raw[0]), raw_t = scans_unpack1<T>(S.raw[1]) + bias;
-        float go_t = scans_unpack1<T>(S.raw[2]);
+        const float bias = row_bias(r);
+        const float u_t = scans_unpack_hi<T>(S.raw[0]), raw_t = scans_unpack_hi<T>(S.raw[1]) + bias;
+        float go_t = scans_unpack_hi<T>(S.raw[2]);
         const float dl_t = softplus ? vsoftplus(raw_t) : raw_t;
         const float dsp_t = (softplus && !(raw_t > 20.f)) ? vsigmoid(raw_t) : 1.f;
         if (p.z) {
-            const float z_t = scans_unpack1<T>(S.raw[3]), yp_t = scans_unpack1<T>(S.raw[4]);
+            const float z_t = scans_unpack_hi<T>(S.raw[3]), yp_t = scans_unpack_hi<T>(S.raw[4]);
             const float sg = vsigmoid(z_t);
             const float dz_t = go_t * yp_t * sg * vfma(z_t, 1.f - sg, 1.f);
             go_t = go_t * z_t * sg;
             gstore(row_ptr_w<T>(p.dz, (int64_t)b * p.dz_bs + (int64_t)(eb + r) * p.dz_ds), spl_i(SCANR_LEN - 1), splat(dz_t), lane == 0);
         }
         const vm tl = lane < SCANS_TC;
-        lds_write_m(tb + 0 * SCANS_TC, tlc, vexp2(S.tA * splat(dl_t * LOG2E)), tl);
+        lds_write_m(tb + 0 * SCANS_TC, tlc, vexp2(tail_A(r) * splat(dl_t * LOG2E)), tl);
         lds_write_m(tb + 1 * SCANS_TC, tlc, B_t * splat(dl_t * u_t), tl);
         lds_write_m(tb + 2 * SCANS_TC, tlc, C_t * splat(go_t), tl);
         vf sc = splat(0.f);
@@ -307,20 +305,25 @@ AUM_DEV void scans_bwd(const AumScanBwdArgs& p, int wg, float* lds) {
         lds_write_m(tb + 3 * SCANS_TC, tlc, sc, tl);
     };
     // ---- P2: state w of row r, every direction slot ----
-    auto p2_state = [&](auto par_tag, ScansWave<T>& S, int w, int r) {       // PAR == r & 1 (the row loop is unrolled by two)
-        constexpr int PAR = decltype(par_tag)::value ? 1 : 0;
+    auto p2_state = [&](ScansWave<T>& S, int w, int r) {
+        constexpr int PAR = 0;
         const vi lane = lane_id();
         const float* pb = prep + (r % 3) * SCANS_NPREP * SCANS_ROWBUF;
         const float* tb = tin + (r % 3) * 4 * SCANS_TC;
         float* to = tout + (r & 1) * SCANS_TOUT;
         AUM_UNROLL
         for (int i = 0; i < 4; ++i) { S.G[i] = spl2(splat(0.f)); S.DA[i] = spl2(splat(0.f)); }
-        if (w >= N || (p.flags & AUM_DBG_SKIP_STATES)) return;
         vf xin_cur[ND];
         float Acur[ND];
         AUM_UNROLL
-        for (int d = 0; d < ND; ++d) { xin_cur[d] = S.xin[PAR][d]; Acur[d] = S.An[PAR][d]; }
-        fetch_xin(par_tag, S, w, r + 2);     // entry states and A two rows ahead (into the slot just read)
+        for (int d = 0; d < ND; ++d) {
+            xin_cur[d] = S.xin[PAR][d];
+            Acur[d] = readlane(lds_read(atab, spl_i((r * 2 + d) * 16 + (w < N ? w : 0))), 0);
+        }
+        AUM_SCHED_FENCE();
+        fetch_xin(S, w, r + 1);              // entry states and A of the next row: one row of arithmetic ahead, every wave
+        AUM_SCHED_FENCE();
+        if (w >= N || (p.flags & AUM_DBG_SKIP_STATES)) return;
         vf2 cc[4];
         {   // c_t = dy_t C_t serves both directions; delta, delta*u and dy themselves are read from LDS again where they are
             // needed (LDS reads are cheap here, registers are not: 128 VGPRs = 16 waves per CU)
@@ -413,14 +416,25 @@ AUM_DEV void scans_bwd(const AumScanBwdArgs& p, int wg, float* lds) {
         const vi word = scans_word(t0);
         const float* pb = prep + (r % 3) * SCANS_NPREP * SCANS_ROWBUF;
         const int e = eb + r;
+        // the 16 shares (idle states publish zeros), eight 8-byte reads in flight at a time: one read per s_waitcnt -- what the
+        // compiler makes of the plain loop -- is 32 serial LDS round trips, ~4000 cycles per row on the critical path
         vf2 G = spl2(splat(0.f)), DA = spl2(splat(0.f));
-        for (int s = 0; s < N; ++s) {
-            G = G + scans_lds_read2(part + (s * 2 + 0) * SCANS_ROWBUF, word);
-            DA = DA + scans_lds_read2(part + (s * 2 + 1) * SCANS_ROWBUF, word);
+        AUM_UNROLL
+        for (int s0 = 0; s0 < SCANS_NW; s0 += 4) {
+            vf2 tg[4], td[4];
+            AUM_UNROLL
+            for (int k = 0; k < 4; ++k) {
+                tg[k] = scans_lds_read2(part + ((s0 + k) * 2 + 0) * SCANS_ROWBUF, word);
+                td[k] = scans_lds_read2(part + ((s0 + k) * 2 + 1) * SCANS_ROWBUF, word);
+            }
+            AUM_SCHED_FENCE();
+            G = G + ((tg[0] + tg[1]) + (tg[2] + tg[3]));
+            DA = DA + ((td[0] + td[1]) + (td[2] + td[3]));
+            AUM_SCHED_FENCE();
         }
         const vf2 dl = scans_lds_read2(pb + 0 * SCANS_ROWBUF, word), dy = scans_lds_read2(pb + 2 * SCANS_ROWBUF, word);
         const vf2 uu = scans_lds_read2(pb + 3 * SCANS_ROWBUF, word), dsp = scans_lds_read2(pb + 4 * SCANS_ROWBUF, word);
-        const float Dn = p.D ? ndir * p.D[e] : 0.f;
+        const float Dn = ndir * row_D(r);
         const vf2 du = vfma2(dl, G, dy * spl2(splat(Dn)));
         const vf2 dd = vfma2(uu, G, DA) * dsp;
         scans_store2<T>(row_ptr_w<T>(p.du, (int64_t)b * p.du_bs + (int64_t)e * p.du_ds), t0, du);
@@ -435,17 +449,16 @@ AUM_DEV void scans_bwd(const AumScanBwdArgs& p, int wg, float* lds) {
     auto p3_tail = [&](ScansWave<T>& S, int r) {
         const vi lane = opaque_i(lane_id());
         const vi tlc = vmin_i(lane, SCANS_TC - 1);
-        const vf A_t = S.tA, B_t = lds_read(tconst, tlc);
+        const vf A_t = tail_A(r), B_t = lds_read(tconst, tlc);
         const float* to = tout + (r & 1) * SCANS_TOUT;
         const float* tb = tin + (r % 3) * 4 * SCANS_TC;
         const int e = eb + r;
         const vm tvalid = (lane < 16 * ND) && ((lane & 15) < N);
         const vm tfwd = MODE == 0 ? (lane >= 0) : MODE == 1 ? (lane < 0) : (lane < 16);
         const vf a_t = lds_read(tb + 0 * SCANS_TC, tlc), b_t = lds_read(tb + 1 * SCANS_TC, tlc), cc_t = lds_read(tb + 2 * SCANS_TC, tlc);
-        const float dl_t = readlane(lds_read(tb + 3 * SCANS_TC, spl_i(SCANS_TS_DL)), 0);
-        const float u_t = readlane(lds_read(tb + 3 * SCANS_TC, spl_i(SCANS_TS_U)), 0);
-        const float dy_t = readlane(lds_read(tb + 3 * SCANS_TC, spl_i(SCANS_TS_DY)), 0);
-        const float dsp_t = readlane(lds_read(tb + 3 * SCANS_TC, spl_i(SCANS_TS_DSP)), 0);
+        const vf sc = lds_read(tb + 3 * SCANS_TC, tlc);          // the four scalars of the tail step: one LDS round trip
+        const float dl_t = readlane(sc, SCANS_TS_DL), u_t = readlane(sc, SCANS_TS_U);
+        const float dy_t = readlane(sc, SCANS_TS_DY), dsp_t = readlane(sc, SCANS_TS_DSP);
         const vf xm = lds_read(to, tlc), gm = lds_read(to + SCANS_TC, tlc);
         const vf x_t = vsel(tfwd, vfma(a_t, xm, b_t), b_t);
         const vf g_t = vsel(tfwd, cc_t, cc_t + gm);
@@ -464,7 +477,7 @@ AUM_DEV void scans_bwd(const AumScanBwdArgs& p, int wg, float* lds) {
             gstore(ws + L.pA + ((int64_t)b * p.dim + e) * N, tn, dAv, tvalid && (lane < 16));
             if (BI) gstore(ws + L.pAb + ((int64_t)b * p.dim + e) * N, tn, dAv, tvalid && (lane >= 16));
         }
-        const float Dn = p.D ? ndir * p.D[e] : 0.f;
+        const float Dn = ndir * row_D(r);
         const float du_t = vfma(dl_t, G_t, dy_t * Dn);
         const float dd_t = vfma(u_t, G_t, DA_t) * dsp_t;
         gstore(row_ptr_w<T>(p.du, (int64_t)b * p.du_bs + (int64_t)e * p.du_ds), spl_i(SCANR_LEN - 1), splat(du_t), lane == 0);
@@ -489,11 +502,21 @@ AUM_DEV void scans_bwd(const AumScanBwdArgs& p, int wg, float* lds) {
         for (int i = 0; i < 4; ++i) { S.dBacc[i] = spl2(splat(0.f)); S.dCacc[i] = spl2(splat(0.f)); S.G[i] = spl2(splat(0.f)); S.DA[i] = spl2(splat(0.f)); }
         AUM_UNROLL
         for (int i = 0; i < 5; ++i) S.raw[i] = ScansRaw2<T>{};
-        S.tA = splat(0.f);
-        S.xin[0][0] = S.xin[0][1] = S.xin[1][0] = S.xin[1][1] = splat(0.f);
-        S.An[0][0] = S.An[0][1] = S.An[1][0] = S.An[1][1] = 0.f;
-        fetch_xin(ScansBool<false>{}, S, w, 0);
-        fetch_xin(ScansBool<true>{}, S, w, 1);
+        S.xin[0][0] = S.xin[0][1] = splat(0.f);
+        fetch_xin(S, w, 0);
+        {   // the row tables: delta_bias, D and A (A_b) of this workgroup's rows
+            const vi i = lane_id() + w * WAVE;               // 16 waves x 64 lanes = 1024 >= 64 rows x 16 states
+            const vi rr = vmin_i(i >> 4, R - 1), nn = vmin_i(i & 15, N - 1);
+            const vm ok = (i < 64 * 16) && ((i & 15) < N) && ((i >> 4) < R);
+            lds_write_m(atab, (i >> 4) * 32 + (i & 15), gload(p.A + (int64_t)eb * N, rr * N + nn, ok), i < 64 * 16);
+            if (BI) lds_write_m(atab, (i >> 4) * 32 + 16 + (i & 15), gload(p.A_b + (int64_t)eb * N, rr * N + nn, ok), i < 64 * 16);
+            if (w == 0) {
+                const vi rl = vmin_i(lane_id(), R - 1);
+                const vm okr = lane_id() < R;
+                lds_write(rowc, lane_id() * 2, p.delta_bias ? gload(p.delta_bias + eb, rl, okr) : splat(0.f));
+                lds_write(rowc, lane_id() * 2 + 1, p.D ? gload(p.D + eb, rl, okr) : splat(0.f));
+            }
+        }
         if (w == 8) {       // constants and accumulators of the two tail roles; the tail-out areas start at zero (idle states stay zero)
             const vi tlc = vmin_i(lane_id(), SCANS_TC - 1);
             const vm tl = lane_id() < SCANS_TC;
@@ -504,63 +527,65 @@ AUM_DEV void scans_bwd(const AumScanBwdArgs& p, int wg, float* lds) {
             for (int i0 = 0; i0 < 2 * SCANS_TOUT; i0 += WAVE) lds_write_m(tout, lane_id() + i0, splat(0.f), lane_id() + i0 < 2 * SCANS_TOUT);
             wave_lds_fence();
         }
-        if (w < 4) {
-            fetch_slice(S, w, 0);
-            p1_slice(S, w, 0);
-            fetch_slice(S, w, 1);
-        } else if (w == 8) {
-            fetch_tail(S, 0);
-            p1_tail(S, 0);
-            fetch_tail(S, 1);
-        } else if (w == 9) {
-            fetch_tailA(S, 0);
-        }
+        fetch_raw(S, w, 0);
+    }
+    AUM_WG_BARRIER();              // row tables and tail constants are in LDS
+    AUM_FOR_EACH_WAVE(w, NW) {
+        ScansWave<T>& S = st[AUM_W(w)];
+        if (w < 4) p1_slice(S, w, 0);
+        else if (w == 8) p1_tail(S, 0);
+        AUM_SCHED_FENCE();
+        fetch_raw(S, w, 1);
     }
     AUM_WG_BARRIER();
     // ---- the rows: iteration r runs P2(r) on all waves, P1(r+1) on waves 0-3 and 8 (AFTER their P2: the raw loads of row r+1
     // were issued an iteration ago and get the whole P2 to land), P3(r-1) on waves 4-7 and 9 (BEFORE their P2: its inputs are
     // complete at the barrier) ----
-    auto iteration = [&](auto par_tag, int r) {
+#ifdef AUM_EMU
+#define SCANS_STAMP(w, r, slot) do { } while (0)
+#else
+    const bool tracing = (p.flags & AUM_DBG_TRACE) && wg == 0;
+    uint32_t* trace = (uint32_t*)(ws + L.trace);
+#define SCANS_STAMP(w, r, slot)                                                                                              \
+    do {                                                                                                                      \
+        if (tracing && (r) < SCANS_TRACE_ITERS && (threadIdx.x & 63) == 0)                                                    \
+            trace[((w) * SCANS_TRACE_ITERS + (r)) * SCANS_TRACE_SLOTS + (slot)] = (uint32_t)__builtin_readcyclecounter();    \
+    } while (0)
+#endif
+    for (int r = 0; r <= R; ++r) {
         AUM_FOR_EACH_WAVE(w, NW) {
             ScansWave<T>& S = st[AUM_W(w)];
+            SCANS_STAMP(w, r, 0);
             if (w >= 4 && w < 8) {
                 if (r >= 1) p3_slice(w - 4, r - 1);
             } else if (w == 9) {
-                if (r >= 1) {
-                    p3_tail(S, r - 1);
-                    fetch_tailA(S, r);
-                }
+                if (r >= 1) p3_tail(S, r - 1);
             }
-            if (r < R) p2_state(par_tag, S, w, r);
+            SCANS_STAMP(w, r, 1);
+            if (r < R) p2_state(S, w, r);
+            SCANS_STAMP(w, r, 2);
             if (w < 4) {
-                if (r + 1 < R) {
-                    p1_slice(S, w, r + 1);
-                    // the fetch must not be scheduled above the last use of the registers it refills: the compiler would load
-                    // into fresh registers and copy them over at the end of the branch -- with an s_waitcnt vmcnt(0) right there
-                    AUM_SCHED_FENCE();
-                    fetch_slice(S, w, r + 2);
-                    AUM_SCHED_FENCE();
-                }
+                if (r + 1 < R) p1_slice(S, w, r + 1);
             } else if (w == 8) {
-                if (r + 1 < R) {
-                    p1_tail(S, r + 1);
-                    AUM_SCHED_FENCE();
-                    fetch_tail(S, r + 2);
-                    AUM_SCHED_FENCE();
-                }
+                if (r + 1 < R) p1_tail(S, r + 1);
             }
+            SCANS_STAMP(w, r, 3);
+            // the fetch must not be scheduled above the last use of the registers it refills
+            AUM_SCHED_FENCE();
+            fetch_raw(S, w, r + 2);
+            AUM_SCHED_FENCE();
+            SCANS_STAMP(w, r, 4);
         }
         // LDS-only barriers: everything the waves exchange per row lives in LDS, and __syncthreads() would also drain vmcnt --
         // i.e. wait at every barrier for the prefetches issued this iteration, putting the HBM latency back on the critical path
         AUM_WG_BARRIER_LDS();      // P3(r-1) has read the shares of row r-1; P1(r+1) is complete
-        if (r < R) {
-            AUM_FOR_EACH_WAVE(w, NW) { p2_publish(st[AUM_W(w)], w); }
+        AUM_FOR_EACH_WAVE(w, NW) {
+            SCANS_STAMP(w, r, 5);
+            if (r < R) p2_publish(st[AUM_W(w)], w);
+            SCANS_STAMP(w, r, 6);
         }
         AUM_WG_BARRIER_LDS();      // the shares of row r are visible
-    };
-    for (int r = 0; r <= R; r += 2) {      // two rows per trip: the parity of the prefetch slots is a compile-time constant
-        iteration(ScansBool<false>{}, r);
-        if (r + 1 <= R) iteration(ScansBool<true>{}, r + 1);
+        AUM_FOR_EACH_WAVE(w, NW) { SCANS_STAMP(w, r, 7); }
     }
     // ---- dB / dC of this workgroup: one partial row per state, the tail column from the P3-tail wave ----
     AUM_FOR_EACH_WAVE(w, NW) {

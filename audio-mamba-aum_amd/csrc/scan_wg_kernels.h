@@ -32,7 +32,8 @@ constexpr int SCANWG_MAX_K = 9;       // <= 577 steps per chunk keeps the backwa
 constexpr uint32_t AUM_DBG_SKIP_STATES = 1u << 16, AUM_DBG_SKIP_LDS_ATOMICS = 1u << 17, AUM_DBG_SKIP_PARTIALS = 1u << 18,
                    AUM_DBG_SKIP_EPILOGUE = 1u << 19, AUM_DBG_NO_STEP_BARRIER = 1u << 20,
                    AUM_DBG_CHUNKED_MAX_ROWS = 1u << 21,
-                   AUM_DBG_STATE_BWD = 1u << 22;          // checkpointed L = 513 backward: scan_state_kernels.h instead of scan_row_kernels.h   // tests: 64-row workgroups in the chunked one-row backward whatever the grid
+                   AUM_DBG_STATE_BWD = 1u << 22,
+                   AUM_DBG_TRACE = 1u << 23;              // scan_state_kernels.h: phase time stamps of workgroup 0 into the workspace          // checkpointed L = 513 backward: scan_state_kernels.h instead of scan_row_kernels.h   // tests: 64-row workgroups in the chunked one-row backward whatever the grid
 
 template <int K, int TAIL> struct ScanGeo {
     static constexpr int KT = K + TAIL;                    // slots per lane
