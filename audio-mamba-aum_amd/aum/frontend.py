@@ -53,6 +53,34 @@ class FbankTables:
                            win=win, shift=shift, padded=padded)
 
 
+class WaveInput:
+    """What AudioMamba.forward(wave, frontend=...) needs besides the waveform to run waveform -> tokens in one launch
+    (aum_frontend_tokens_fwd): the filterbank tables, the normalisation and this batch's augmentation draw."""
+
+    def __init__(self, tables, target_length=1024, norm_mean=AUDIOSET_MEAN, norm_std=AUDIOSET_STD, aug=None, noise=None):
+        self.tables, self.target_length = tables, target_length
+        self.norm_mean, self.norm_std, self.aug, self.noise = norm_mean, norm_std, aug, noise
+
+    def spectrogram(self, wave):
+        """the same clips through the stand-alone log-mel kernel (configurations the one-launch path does not cover)"""
+        return aum_hip.fbank_fwd(wave, self.tables.tables, self.target_length, self.norm_mean, self.norm_std, aug=self.aug,
+                                 noise=self.noise)
+
+
+def prepare_wave(wave, n_valid, tables, aug=None):
+    """Mean removal (dataloader.py:101) and, for ragged batches, the per-clip frame counts in column 0 of the augmentation
+    table: the host-side half of wav2fbank / wav2fbank_ragged, shared with the one-launch path."""
+    wave = (wave - wave.mean(dim=1, keepdim=True)).contiguous()
+    if n_valid is not None:
+        win, shift = tables.tables["win"], tables.tables["shift"]
+        n_valid = torch.as_tensor(n_valid, device=wave.device)
+        frames = torch.where(n_valid >= win, 1 + (n_valid - win) // shift, torch.zeros_like(n_valid))
+        if aug is None:
+            aug = torch.zeros((wave.shape[0], aum_hip.FBANK_AUG), dtype=torch.float32, device=wave.device)
+        aug[:, 0] = frames.to(torch.float32)
+    return wave, aug
+
+
 def wav2fbank(wave, tables, target_length=1024, norm_mean=AUDIOSET_MEAN, norm_std=AUDIOSET_STD, aug=None, noise=None):
     """wave: (batch, n_samples) fp32 on the GPU -> (batch, target_length, num_mel) normalised log-mel, what
     AudiosetDataset.__getitem__ returns per clip (without mixup).  aug / noise: the per-clip augmentation table and noise
@@ -72,10 +100,5 @@ def wav2fbank_ragged(wave, n_valid, tables, target_length=1024, norm_mean=AUDIOS
     Kaldi's snip_edges framing only emits frames that lie inside the clip, so frames past 1 + (n - win)//shift are
     the reference's ZeroPad2d rows (dataloader.py:139-145) -- written by the kernel itself (column 0 of the per-clip table).
     aug / noise: SpecAug bands, noise and roll of aum.augment.draw_augmentation, applied in the same store."""
-    win, shift = tables.tables["win"], tables.tables["shift"]
-    n_valid = torch.as_tensor(n_valid, device=wave.device)
-    frames = torch.where(n_valid >= win, 1 + (n_valid - win) // shift, torch.zeros_like(n_valid))
-    if aug is None:
-        aug = torch.zeros((wave.shape[0], aum_hip.FBANK_AUG), dtype=torch.float32, device=wave.device)
-    aug[:, 0] = frames.to(torch.float32)
-    return wav2fbank(wave, tables, target_length, norm_mean, norm_std, aug=aug, noise=noise)
+    wave, aug = prepare_wave(wave, n_valid, tables, aug)
+    return aum_hip.fbank_fwd(wave, tables.tables, target_length, norm_mean, norm_std, aug=aug, noise=noise)

@@ -41,6 +41,42 @@ class PatchEmbed(nn.Module):
         return out.reshape(Bsz, nf * nt, -1)
 
 
+class FrontendTokensFn(torch.autograd.Function):
+    """Waveform -> (B, N+1, Dm) token sequence in one launch (aum_frontend_tokens_fwd): log-mel frames, patch GEMM, bias,
+    position rows and the cls row, with the arithmetic of the autocast reference (16-bit conv output, fp32 position add;
+    DL:134-147 -> TOK:278-310 -> MM:509-541).  Backward: the patch matrix saved by the kernel gives the weight gradient."""
+
+    @staticmethod
+    def forward(ctx, wave, weight, bias, pos_embed, cls_token, fe, dtype, cls_pos, time_major):
+        import aum_hip
+        Dm = weight.shape[0]
+        w16 = weight.detach().reshape(Dm, -1).to(dtype).contiguous()
+        pe = pos_embed.detach().float()
+        cls_row = (cls_token.detach().float() + pe[:, :1]).reshape(Dm).contiguous()
+        need = any(ctx.needs_input_grad[1:5])
+        tokens, patches = aum_hip.frontend_tokens(
+            wave, fe.tables.tables, fe.target_length, fe.norm_mean, fe.norm_std, w16, bias.detach().float().contiguous(),
+            pe[0, 1:].contiguous(), cls_row, cls_pos, time_major=time_major, save_patches=need, aug=fe.aug, noise=fe.noise)
+        ctx.save_for_backward(patches)
+        ctx.cfg = (weight.shape, weight.dtype, dtype, cls_pos, time_major, fe.target_length // 16)
+        return tokens
+
+    @staticmethod
+    def backward(ctx, g):
+        (patches,) = ctx.saved_tensors
+        wshape, wdtype, dtype, cls_pos, time_major, nt = ctx.cfg
+        Bsz, _, Dm = g.shape
+        gp = torch.cat((g[:, :cls_pos], g[:, cls_pos + 1:]), dim=1)              # (B, N, Dm) in sequence order
+        if time_major:                                                          # back to the cell order f * n_t + t
+            gp = gp.reshape(Bsz, nt, -1, Dm).transpose(1, 2).reshape(Bsz, -1, Dm)
+        g16 = gp.to(dtype).reshape(-1, Dm)                                      # gradient of the 16-bit conv output
+        dweight = (g16.t() @ patches).to(wdtype).reshape(wshape)
+        dbias = g16.sum(0).to(wdtype)
+        dcls = g[:, cls_pos].sum(0)
+        dpos = torch.cat((dcls[None], gp.sum(0)), dim=0)[None]
+        return None, dweight, dbias, dpos.to(wdtype), dcls.reshape(1, 1, Dm).to(wdtype), None, None, None, None
+
+
 class PosEmbed(nn.Module):
     """FlexiPosEmbed with pos_embed_prefix=True (TOK:330-451): row 0 belongs to the cls token, rows 1.. to the patches."""
 
@@ -124,8 +160,24 @@ class AudioMamba(nn.Module):
             x = x.reshape(Bsz, nf, nt, -1).transpose(1, 2).reshape(Bsz, nt * nf, -1)
         return torch.cat((x[:, :pos], cls.to(x.dtype), x[:, pos:]), dim=1), pos
 
-    def forward_features(self, x):
-        hidden, pos = self.tokens(x)
+    def tokens_from_wave(self, wave, fe):
+        """(B, n_samples) mean-removed waveform + aum.frontend.WaveInput -> the same token sequence as tokens(spectrogram), in one
+        launch when the configuration is the 16 kHz / 128-mel / 16 x 16 autocast one; otherwise log-mel kernel + tokens()."""
+        import aum_hip
+        dtype = torch.get_autocast_dtype(wave.device.type) if torch.is_autocast_enabled(wave.device.type) else None
+        ps = self.patch_embed.proj
+        if (dtype is None or tuple(ps.kernel_size) != (16, 16) or ps.in_channels != 1 or self.patch_grid_size[0] != 8
+                or self.patch_grid_size[1] * 16 != fe.target_length
+                or not aum_hip.frontend_tokens_supported(fe.tables.tables, fe.target_length, self.embed_dim, dtype)):
+            return self.tokens(fe.spectrogram(wave))
+        Np = self.num_patches
+        pos = Np // 2 if self.use_middle_cls_token else (Np if self.use_end_cls_token else 0)
+        tok = FrontendTokensFn.apply(wave, ps.weight, ps.bias, self.pos_embed.pos_embed, self.cls_token, fe, dtype, pos,
+                                     self.transpose_token_sequence)
+        return tok, pos
+
+    def forward_features(self, x, frontend=None):
+        hidden, pos = self.tokens(x) if frontend is None else self.tokens_from_wave(x, frontend)
         residual = None
         if not self.if_bidirectional:
             for layer in self.layers:
@@ -139,8 +191,9 @@ class AudioMamba(nn.Module):
                              prenorm=False, residual_in_fp32=True)                            # MM:646-657
         return hidden[:, pos]
 
-    def forward(self, x, return_features=False):
-        f = self.forward_features(x)
+    def forward(self, x, return_features=False, frontend=None):
+        """x: (B, T, F) normalised log-mel spectrogram, or -- with frontend=aum.frontend.WaveInput -- (B, n_samples) waveform"""
+        f = self.forward_features(x, frontend)
         return f if return_features else self.head(f)
 
 

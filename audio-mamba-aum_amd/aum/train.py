@@ -165,7 +165,9 @@ def build_model(args):
 
 
 class Frontend:
-    """waveform batch on the device -> augmented, normalised (B, T, F) log-mel"""
+    """waveform batch on the device -> (model input, frontend= argument of AudioMamba.forward): the mean-removed waveform plus
+    this batch's augmentation draw (waveform -> tokens runs inside the model, one launch), or -- fused=False -- the augmented,
+    normalised (B, T, F) log-mel and None."""
 
     def __init__(self, args, device, train):
         from .frontend import FbankTables, pad_fill
@@ -174,14 +176,16 @@ class Frontend:
                                   frame_shift_ms=float(args.fshift))
         self.fill = pad_fill(args.dataset_mean, args.dataset_std)
 
-    def __call__(self, wave, n_valid):
-        from .frontend import wav2fbank_ragged
+    def __call__(self, wave, n_valid, fused=True):
+        from .frontend import WaveInput, prepare_wave
         from .augment import draw_augmentation
         a = self.args
         aug = nz = None
         if self.train and (a.freqm or a.timem or a.noise):       # DL:206-228, applied in the log-mel kernel's own store
             aug, nz = draw_augmentation(wave.shape[0], a.audio_length, a.melbins, a.freqm, a.timem, a.noise, wave.device)
-        return wav2fbank_ragged(wave, n_valid, self.tables, a.audio_length, a.dataset_mean, a.dataset_std, aug=aug, noise=nz)
+        wave, aug = prepare_wave(wave, n_valid, self.tables, aug)
+        fe = WaveInput(self.tables, a.audio_length, a.dataset_mean, a.dataset_std, aug, nz)
+        return (wave, fe) if fused else (fe.spectrogram(wave), None)
 
 
 def make_loader(args, path, train, D):
@@ -253,7 +257,8 @@ def validate(model, loader, frontend, args, D, epoch, save_pred=True):
         for wave, n_valid, labels, _ in loader:
             wave, labels = wave.to(D.device, non_blocking=True), labels.to(D.device, non_blocking=True)
             with _autocast(args, D):
-                out = model(frontend(wave, n_valid.to(D.device)))
+                x, fe = frontend(wave, n_valid.to(D.device))
+                out = model(x, frontend=fe)
             out = out.float()
             if args.if_nan2num:
                 out = torch.nan_to_num(out)
@@ -343,9 +348,9 @@ def train(model, train_loader, val_loader, args, D):
                     g["lr"] = warm_lr
                 D.print("warm-up learning rate is {:f}".format(warm_lr))
             with torch.no_grad():
-                x = fe_train(wave, n_valid.to(D.device))
+                x, fe = fe_train(wave, n_valid.to(D.device))
             with _autocast(args, D):
-                out = net(x)
+                out = net(x, frontend=fe)
             loss = _loss(loss_fn, out.float(), labels)
             if args.if_nan2num:
                 loss = torch.nan_to_num(loss)

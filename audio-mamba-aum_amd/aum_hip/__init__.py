@@ -25,7 +25,7 @@ _ERR = {-1: "AUM_E_NULL", -2: "AUM_E_SHAPE", -3: "AUM_E_DTYPE", -4: "AUM_E_UNSUP
         -6: "AUM_E_LAUNCH"}
 
 _i64, _i32, _u32, _vp, _fp = C.c_int64, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class _Debug:
@@ -91,6 +91,11 @@ class FbankArgs(C.Structure):
                 + [("aug", _vp), ("noise", _vp)])
 
 
+class FrontendArgs(C.Structure):
+    _fields_ = ([("fbank", FbankArgs)] + [(n, _vp) for n in ("weight", "bias", "pos", "cls_row", "tokens", "patches")]
+                + [("tokens_bs", _i64)] + [(n, _i32) for n in ("dim", "cls_pos", "dtype", "out_dtype")] + [("flags", _u32)])
+
+
 class ProjArgs(C.Structure):
     _fields_ = ([(n, _vp) for n in ("act", "w_x", "w_dt", "x_dbl", "out_act", "dB", "dC")]
                 + [(n, _i64) for n in ("dB_bs", "dB_ns", "dC_bs", "dC_ns", "ntok")]
@@ -102,7 +107,7 @@ class ProjWArgs(C.Structure):
                 + [(n, _i32) for n in ("dim", "nrows", "nsplit", "transpose_out", "dtype")])
 
 
-EXPORTS = ["aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
+EXPORTS = ["aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy"]
 
@@ -125,6 +130,7 @@ class Lib:
                   "aum_rmsnorm_fwd", "aum_rmsnorm_bwd"):
             getattr(self.c, n).argtypes = [_vp, _vp]
         self.c.aum_fbank_fwd.argtypes = [_vp, _vp]
+        self.c.aum_frontend_tokens_fwd.argtypes = [_vp, _vp]
         for n in ("aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight"):
             getattr(self.c, n).argtypes = [_vp, _vp]
         self.c.aum_proj_bwd_weight_splits.argtypes = [_i32, _i64]
@@ -518,18 +524,26 @@ def fbank_fwd(wave, tables, target_length, norm_mean, norm_std, preemph=0.97, au
     aug: optional (batch, 8) fp32 per-clip table [frames, f_lo, f_hi, t_lo, t_hi, roll, noise_amp, 0] applied in the kernel's
     store (ragged padding, SpecAug bands, noise, roll); noise: (batch, target_length, num_mel) fp32 uniform numbers."""
     lib = lib or get()
+    batch, num_mel = wave.shape[0], tables["mel_w"].shape[0]
+    out = torch.empty((batch, target_length, num_mel), dtype=torch.float32, device=wave.device)
+    a = FbankArgs()
+    _fill_fbank(a, lib, wave, tables, target_length, norm_mean, norm_std, preemph, aug, noise)
+    a.out, a.out_bs = _ptr(out), out.stride(0)
+    _launch(lib.c.aum_fbank_fwd, a, wave, lib, "fbank_fwd", (batch, target_length, num_mel))
+    return out
+
+
+def _fill_fbank(a, lib, wave, tables, target_length, norm_mean, norm_std, preemph, aug, noise):
     lib.check_tensor(wave)
     assert wave.dtype == torch.float32 and wave.stride(1) == 1
     batch, n = wave.shape
     win, shift, padded = tables["win"], tables["shift"], tables["padded"]
     num_frames = 0 if n < win else min(target_length, 1 + (n - win) // shift)
     num_mel, stride = tables["mel_w"].shape
-    out = torch.empty((batch, target_length, num_mel), dtype=torch.float32, device=wave.device)
-    a = FbankArgs()
-    a.wave, a.out = _ptr(wave), _ptr(out)
+    a.wave = _ptr(wave)
     a.window, a.twiddle = _ptr(tables["window"]), _ptr(tables["twiddle"])
     a.mel_start_f, a.mel_count_f, a.mel_w = _ptr(tables["mel_start_f"]), _ptr(tables["mel_count_f"]), _ptr(tables["mel_w"])
-    a.wave_bs, a.out_bs = wave.stride(0), out.stride(0)
+    a.wave_bs = wave.stride(0)
     a.batch, a.n_samples, a.win, a.shift, a.padded = batch, n, win, shift, padded
     a.num_frames, a.target_length, a.num_mel, a.mel_wstride = num_frames, target_length, num_mel, stride
     a.preemph, a.norm_mean, a.norm_inv2std = preemph, norm_mean, 1.0 / (2.0 * norm_std)
@@ -539,11 +553,51 @@ def fbank_fwd(wave, tables, target_length, norm_mean, norm_std, preemph=0.97, au
         lib.check_tensor(aug)
         a.aug = _ptr(aug)
     if noise is not None:
-        assert aug is not None and noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape == out.shape
+        assert aug is not None and noise.dtype == torch.float32 and noise.is_contiguous()
+        assert noise.shape == (batch, target_length, num_mel)
         lib.check_tensor(noise)
         a.noise = _ptr(noise)
-    _launch(lib.c.aum_fbank_fwd, a, wave, lib, "fbank_fwd", (batch, target_length, num_mel))
-    return out
+
+
+FRONTEND_TIME_MAJOR = 1
+
+
+def frontend_tokens_supported(tables, target_length, dim, dtype):
+    """the limits of aum_frontend_tokens_fwd (include/aum_hip.h); outside them callers run fbank_fwd and a GEMM"""
+    return (dtype in (torch.bfloat16, torch.float16) and tables["padded"] == 512 and tables["mel_w"].shape[0] == 128
+            and target_length % 64 == 0 and dim % 16 == 0)
+
+
+def frontend_tokens(wave, tables, target_length, norm_mean, norm_std, weight, bias, pos, cls_row, cls_pos, out_dtype=torch.float32,
+                    time_major=False, save_patches=False, preemph=0.97, aug=None, noise=None, lib=None):
+    """Waveform -> token sequence in one launch (aum_frontend_tokens_fwd).  weight: (dim, 256) bf16/f16 (the flattened 16 x 16
+    conv weight); bias (dim), pos (n_patches, dim), cls_row (dim) or None: fp32.  Returns (tokens (batch, n_patches [+1], dim)
+    in out_dtype, patches (batch * n_patches, 256) in weight.dtype or None)."""
+    lib = lib or get()
+    batch = wave.shape[0]
+    dim = weight.shape[0]
+    n_patches = target_length // 16 * 8
+    assert weight.shape == (dim, 256) and weight.is_contiguous() and weight.dtype in (torch.bfloat16, torch.float16)
+    assert bias.shape == (dim,) and bias.dtype == torch.float32 and bias.is_contiguous()
+    assert pos.shape == (n_patches, dim) and pos.dtype == torch.float32 and pos.is_contiguous()
+    for t in (weight, bias, pos):
+        lib.check_tensor(t)
+    n_tok = n_patches + (cls_row is not None)
+    tokens = torch.empty((batch, n_tok, dim), dtype=out_dtype, device=wave.device)
+    patches = torch.empty((batch * n_patches, 256), dtype=weight.dtype, device=wave.device) if save_patches else None
+    a = FrontendArgs()
+    _fill_fbank(a.fbank, lib, wave, tables, target_length, norm_mean, norm_std, preemph, aug, noise)
+    a.weight, a.bias, a.pos, a.tokens = _ptr(weight), _ptr(bias), _ptr(pos), _ptr(tokens)
+    if cls_row is not None:
+        assert cls_row.shape == (dim,) and cls_row.dtype == torch.float32 and cls_row.is_contiguous()
+        lib.check_tensor(cls_row)
+        a.cls_row, a.cls_pos = _ptr(cls_row), cls_pos
+    if patches is not None:
+        a.patches = _ptr(patches)
+    a.tokens_bs, a.dim, a.dtype, a.out_dtype = tokens.stride(0), dim, _DT[weight.dtype], _DT[out_dtype]
+    a.flags = FRONTEND_TIME_MAJOR if time_major else 0
+    _launch(lib.c.aum_frontend_tokens_fwd, a, wave, lib, "frontend_tokens", (batch, target_length, dim))
+    return tokens, patches
 
 
 def proj_supported(dim, dt_rank, dstate, ntok, dtype):

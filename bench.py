@@ -168,18 +168,20 @@ def main():
     if args.no_frontend:
         x = torch.randn(args.batch, 1024, 128, device=dev, generator=g) * 0.5   # SURVEY 8d synthetic spectrograms
         spec = lambda: x
+        fe = None
     else:   # 10 s / 16 kHz synthetic waveforms; the fused log-mel frontend runs inside the timed step (config 2)
-        from aum.frontend import FbankTables, wav2fbank
+        from aum.frontend import FbankTables, WaveInput, prepare_wave
         tabs = FbankTables(dev)
         wave = (torch.randn(args.batch, 160000, device=dev, generator=g) * 0.1).clamp_(-1, 1)
-        spec = lambda: wav2fbank(wave, tabs, target_length=1024)
+        spec = lambda: prepare_wave(wave, None, tabs)[0]          # mean removal; log-mel + patch embedding run inside the model
+        fe = WaveInput(tabs, 1024)
     y = torch.zeros(args.batch, n_class, device=dev)
     y.scatter_(1, torch.randint(0, n_class, (args.batch, 2), device=dev, generator=g), 1.0)
 
     def step():
         xin = spec()
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            logits = net(xin)
+            logits = net(xin, frontend=fe)
             loss = loss_fn(logits.float(), y)
         loss.backward()
         opt.step()
@@ -215,7 +217,7 @@ def main():
     # the same step without the optimizer (SURVEY 8d asks for both figures); a few extra steps, not part of `value`
     def step_no_opt():
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            l_ = loss_fn(net(spec()).float(), y)
+            l_ = loss_fn(net(spec(), frontend=fe).float(), y)
         l_.backward()
         opt.zero_grad(set_to_none=True)
     n_extra = max(2, min(5, args.steps))

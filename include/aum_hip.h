@@ -27,9 +27,10 @@
 extern "C" {
 #endif
 
-#define AUM_ABI_VERSION 4   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
+#define AUM_ABI_VERSION 5   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
                                3: x_lane (lane-entry state checkpoint of the L = 513 row kernels) appended after it;
-                               4: aug / noise (per-clip augmentation in the log-mel kernel's epilogue) appended to AumFbankArgs */
+                               4: aug / noise (per-clip augmentation in the log-mel kernel's epilogue) appended to AumFbankArgs;
+                               5: aum_frontend_tokens_fwd (waveform -> token sequence in one launch) */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 
@@ -211,6 +212,34 @@ typedef struct AumFbankArgs {
 } AumFbankArgs;
 #define AUM_FBANK_AUG 8
 int aum_fbank_fwd(const AumFbankArgs* args, void* stream);
+
+/*
+ * Waveform -> token sequence in one launch (ABI 5): the log-mel frontend above, the 16 x 16 patch embedding, its bias, the
+ * position rows and the cls row, i.e. src/dataloader.py:134-147, 206-228 -> src/models/mamba_models.py:509-541 with
+ * src/utilities/tokenization.py:278-310 (FlexiPatchEmbed, kernel = stride = 16) -- without the spectrogram or an im2col copy
+ * of it in HBM.
+ *   fbank   : as for aum_fbank_fwd (aug / noise included); .out is ignored.  Needs padded == 512, num_mel == 128 and
+ *             target_length % 64 == 0 (AUM_E_UNSUPPORTED otherwise: call aum_fbank_fwd and a GEMM instead).
+ *   weight  : (dim, 256) in `dtype` (bf16 / f16) = the conv weight (dim, 1, 16, 16) flattened: k = 16 * mel_row + frame
+ *   bias    : (dim) fp32      pos : (n_patches, dim) fp32, row f_block * n_t + t_block (pos_embed rows 1 ..)
+ *   cls_row : (dim) fp32 = cls_token + pos_embed row 0, written as token `cls_pos` of every clip; NULL = no cls row
+ *   tokens  : (batch, n_patches + (cls_row != NULL), dim) in `out_dtype`, batch stride tokens_bs elements:
+ *             round16(patch . weight + bias) + pos   (the 16-bit conv output of the autocast reference, then the fp32 add)
+ *   patches : optional (batch * n_patches, 256) in `dtype`, rows in f_block * n_t + t_block order: the GEMM's input, saved
+ *             for the weight gradient.
+ *   flags   : AUM_FRONTEND_TIME_MAJOR = patch tokens in time-major order (transpose_token_sequence, MM:545-566).
+ */
+typedef struct AumFrontendArgs {
+    AumFbankArgs fbank;
+    const void *weight;
+    const float *bias, *pos, *cls_row;
+    void *tokens, *patches;
+    int64_t tokens_bs;
+    int32_t dim, cls_pos, dtype, out_dtype;
+    uint32_t flags;
+} AumFrontendArgs;
+#define AUM_FRONTEND_TIME_MAJOR 1u
+int aum_frontend_tokens_fwd(const AumFrontendArgs* args, void* stream);
 
 /*
  * The skinny projections around the scan on CHANNEL-MAJOR activations (token t = b*len + l contiguous):

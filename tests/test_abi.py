@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(so_path):
     lib = ctypes.CDLL(so_path)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.aum_abi_version() == aum_hip.ABI_VERSION == 4
+    assert lib.aum_abi_version() == aum_hip.ABI_VERSION == 5
     assert lib.aum_scan_max_single_pass_len() == 576
     assert lib.aum_rmsnorm_bwd_partials(32832) == 4096
 
@@ -47,6 +47,8 @@ def test_struct_layouts_match_header(tmp_path):
         "AumConvArgs": (aum_hip.ConvArgs, ["x", "weight", "y", "dweight", "x_bs", "dx_ds", "batch", "flags"]),
         "AumNormArgs": (aum_hip.NormArgs, ["x", "weight", "y", "rstd_out", "row_stride_x", "eps", "rows", "flags"]),
         "AumFbankArgs": (aum_hip.FbankArgs, ["wave", "mel_w", "out", "wave_bs", "batch", "mel_wstride", "preemph", "log_floor", "aug", "noise"]),
+        "AumFrontendArgs": (aum_hip.FrontendArgs, ["fbank", "weight", "bias", "pos", "cls_row", "tokens", "patches", "tokens_bs", "dim", "cls_pos",
+                                                   "dtype", "out_dtype", "flags"]),
         "AumProjArgs": (aum_hip.ProjArgs, ["act", "w_dt", "out_act", "dB", "dC_ns", "ntok", "dim", "dtype", "w_ld"]),
         "AumProjWArgs": (aum_hip.ProjWArgs, ["x", "y", "out", "ntok", "dim", "nsplit", "dtype"]),
     }

@@ -81,3 +81,127 @@ def test_oracle_matches_transformers_kaldi_fbank():
     mine = OF.fbank(wave.astype(np.float64))
     assert mine.shape == ref.shape == (198, 128)
     assert np.abs(mine - ref).max() < 2e-5
+
+
+# ---- waveform -> tokens in one launch (aum_frontend_tokens_fwd) vs the two-stage path (aum_fbank_fwd, then a GEMM) --------
+def _tokens_two_stage(spec, w, bias, pos_embed, cls_token, dtype, cls_pos, time_major):
+    """spec (B, T, 128) fp32 from aum_fbank_fwd -> what MM:509-541 computes under autocast: 16-bit conv output, fp32 position add"""
+    B, T, F = spec.shape
+    nf, nt = F // 16, T // 16
+    x = spec.to(dtype).double().transpose(1, 2)                                   # B, F, T
+    cols = x.reshape(B, nf, 16, nt, 16).permute(0, 1, 3, 2, 4).reshape(B, nf * nt, 256)
+    out = cols @ w.reshape(w.shape[0], 256).to(dtype).double().t() + bias.double()
+    out = out.float().to(dtype).float() + pos_embed[0, 1:]
+    if time_major:
+        out = out.reshape(B, nf, nt, -1).transpose(1, 2).reshape(B, nt * nf, -1)
+    cls = (cls_token + pos_embed[:, :1]).expand(B, -1, -1)
+    return torch.cat((out[:, :cls_pos], cls, out[:, cls_pos:]), dim=1), cols.float().to(dtype).reshape(B * nf * nt, 256)
+
+
+def _check_tokens(lib, dev, target, dim, dtype, time_major, augment, batch=2, n_samples=None):
+    from aum.frontend import FbankTables, prepare_wave
+    from aum.augment import draw_augmentation
+    tabs = FbankTables(dev)
+    n = n_samples or (400 + (target - 1) * 160 - 900)                             # a few zero-padded frames at the end
+    waves = torch.tensor(np.stack([_wave(n, 20 + i) for i in range(batch)]), device=dev)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    w = (torch.randn(dim, 1, 16, 16, generator=g) * 0.06).to(dev)
+    bias = (torch.randn(dim, generator=g) * 0.1).to(dev)
+    n_patches = target // 16 * 8
+    pos_embed = (torch.randn(1, n_patches + 1, dim, generator=g) * 0.02).to(dev)
+    cls_token = (torch.randn(1, 1, dim, generator=g) * 0.02).to(dev)
+    aug = nz = None
+    if augment:
+        aug, nz = draw_augmentation(batch, target, 128, 24, target // 5, True, dev, generator=torch.Generator(device=dev).manual_seed(9))
+    n_valid = torch.tensor([n, n - 4000][:batch] if batch > 1 else [n], device=dev)
+    wave, aug = prepare_wave(waves, n_valid, tabs, aug)
+    cls_pos = n_patches // 2
+    old = aum_hip._product
+    aum_hip._product = lib
+    try:
+        spec = aum_hip.fbank_fwd(wave, tabs.tables, target, -4.27, 4.57, aug=aug, noise=nz)
+        tok, patches = aum_hip.frontend_tokens(wave, tabs.tables, target, -4.27, 4.57, w.reshape(dim, 256).to(dtype).contiguous(), bias,
+                                               pos_embed[0, 1:].contiguous(), (cls_token + pos_embed[:, :1]).reshape(dim).contiguous(),
+                                               cls_pos, time_major=time_major, save_patches=True, aug=aug, noise=nz)
+        if dev == "cuda":
+            torch.cuda.synchronize()
+    finally:
+        aum_hip._product = old
+    ref, ref_patches = _tokens_two_stage(spec, w, bias, pos_embed, cls_token, dtype, cls_pos, time_major)
+    assert tok.shape == ref.shape and tok.dtype == torch.float32
+    assert torch.equal(patches.view(torch.int16), ref_patches.view(torch.int16))          # the same log-mel values, bit for bit
+    err = (tok - ref).abs()
+    ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+    # fp32 MFMA accumulation vs fp64: the 16-bit rounding of the conv output may land one step apart on a few values
+    assert err.max() <= 1.01 * ulp * max(1.0, ref.abs().max().item()), err.max()
+    assert (err > 1e-5).float().mean() < 0.02
+    assert torch.equal(tok[:, cls_pos], ref[:, cls_pos])
+
+
+def test_frontend_tokens_emu():
+    import build_emu
+    lib = aum_hip.Lib(build_emu.build(), host=True)
+    _check_tokens(lib, "cpu", 64, 48, torch.bfloat16, False, False, batch=1)
+    _check_tokens(lib, "cpu", 128, 32, torch.float16, True, True)
+
+
+@pytest.mark.gpu
+def test_frontend_tokens_gpu():
+    lib = aum_hip.get()
+    _check_tokens(lib, "cuda", 1024, 768, torch.bfloat16, False, True, batch=4)
+    _check_tokens(lib, "cuda", 1024, 768, torch.bfloat16, False, False, batch=3, n_samples=160000)
+    _check_tokens(lib, "cuda", 128, 192, torch.float16, True, True)
+
+
+def _check_model_tokens(lib, dev, target, dim, time_major):
+    """AudioMamba.tokens_from_wave (one launch + its autograd function) vs AudioMamba.tokens on the stand-alone log-mel output,
+    both under bf16 autocast: token values and the gradients of patch_embed / pos_embed / cls_token."""
+    from aum.model import AudioMamba
+    from aum.frontend import FbankTables, WaveInput, prepare_wave
+    old = aum_hip._product
+    aum_hip._product = lib
+    try:
+        torch.manual_seed(0)
+        model = AudioMamba(spectrogram_size=(128, target), depth=1, embed_dim=dim, num_classes=3, transpose_token_sequence=time_major).to(dev)
+        with torch.no_grad():
+            model.patch_embed.proj.bias.normal_(0, 0.1)
+        tabs = FbankTables(dev)
+        n = 400 + (target - 1) * 160
+        waves = torch.tensor(np.stack([_wave(n, 30 + i) for i in range(2)]), device=dev)
+        wave, aug = prepare_wave(waves, torch.tensor([n, n - 3000], device=dev), tabs)
+        fe = WaveInput(tabs, target, aug=aug)
+        probe = torch.randn(2, target // 16 * 8 + 1, dim, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        grads = []
+        toks = []
+        for fused in (True, False):
+            model.zero_grad()
+            with torch.autocast(dev, dtype=torch.bfloat16):
+                tok, pos = model.tokens_from_wave(wave, fe) if fused else model.tokens(fe.spectrogram(wave))
+            assert tok.dtype == torch.float32 and pos == (target // 16 * 8) // 2
+            (tok * probe).sum().backward()
+            toks.append(tok.detach())
+            grads.append([p.grad.clone() for p in (model.patch_embed.proj.weight, model.patch_embed.proj.bias,
+                                                   model.pos_embed.pos_embed, model.cls_token)])
+    finally:
+        aum_hip._product = old
+    assert (toks[0] - toks[1]).abs().max() <= 2.0 ** -7 * max(1.0, toks[1].abs().max().item())
+    # both sides round an fp32-accumulated GEMM to bf16; the library's summation order differs, so a share of the values lands one
+    # bf16 step apart (never more: the max above) -- on average well under half a step
+    assert (toks[0] - toks[1]).abs().mean() <= 2.0 ** -10 * toks[1].abs().mean()
+    for name, a, b in zip(("weight", "bias", "pos_embed", "cls_token"), *grads):
+        assert a.shape == b.shape
+        tol = 2e-2 if name in ("weight", "bias") else 1e-5          # weight/bias gradients pass through a bf16 GEMM output on both sides
+        assert (a - b).abs().max() <= tol * max(1e-6, b.abs().max().item()), (name, (a - b).abs().max(), b.abs().max())
+
+
+def test_model_tokens_from_wave_emu():
+    import build_emu
+    lib = aum_hip.Lib(build_emu.build(), host=True)
+    _check_model_tokens(lib, "cpu", 64, 32, False)
+    _check_model_tokens(lib, "cpu", 64, 32, True)
+
+
+@pytest.mark.gpu
+def test_model_tokens_from_wave_gpu():
+    _check_model_tokens(aum_hip.get(), "cuda", 1024, 768, False)
+    _check_model_tokens(aum_hip.get(), "cuda", 128, 192, True)

@@ -302,7 +302,7 @@ def test_training_loop_matches_reference_traintest(tmp_path, monkeypatch):
             pass
 
         def __call__(self, wave, n_valid):
-            return wave
+            return wave, None
     monkeypatch.setattr(T, "Frontend", IdentityFrontend)
     lrs, hyper = [], {}
     RealAdam = torch.optim.Adam

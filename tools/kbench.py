@@ -69,6 +69,30 @@ def main():
         rec("hbm_copy_1GiB", timeit(lambda: aum_hip.hbm_copy(src, dst)), 2 * src.numel())
         rec("torch_copy_1GiB", timeit(lambda: dst.copy_(src)), 2 * src.numel())
         del src, dst
+    if want("frontend"):      # waveform -> tokens: log-mel kernel alone, the two-stage path, and the one-launch path
+        from aum.frontend import FbankTables
+        tabs = FbankTables(dev).tables
+        wave = (torch.randn(Bsz, 160000, device=dev) * 0.1).clamp_(-1, 1)
+        Dm = a.dmodel
+        w = torch.randn(Dm, 256, device=dev) * 0.06
+        w16 = w.to(torch.bfloat16)
+        fbias = torch.zeros(Dm, device=dev)
+        pos = torch.randn(512, Dm, device=dev) * 0.02
+        cls_row = torch.zeros(Dm, device=dev)
+        wave_bytes, spec_bytes, tok_bytes = wave.numel() * 4, Bsz * 1024 * 128 * 4, Bsz * 513 * Dm * 4
+        rec("fbank_fwd", timeit(lambda: aum_hip.fbank_fwd(wave, tabs, 1024, -4.27, 4.57)), wave_bytes + spec_bytes)
+
+        def two_stage():
+            spec = aum_hip.fbank_fwd(wave, tabs, 1024, -4.27, 4.57)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                cols = spec.transpose(1, 2).reshape(Bsz, 8, 16, 64, 16).permute(0, 1, 3, 2, 4).reshape(Bsz * 512, 256)
+                x = torch.nn.functional.linear(cols, w, fbias).reshape(Bsz, 512, Dm) + pos
+            return torch.cat((x[:, :256], cls_row.expand(Bsz, 1, Dm), x[:, 256:]), dim=1)
+        rec("frontend_two_stage", timeit(two_stage), wave_bytes + tok_bytes)
+        for save in (False, True):
+            rec("frontend_tokens" + ("_save_patches" if save else ""),
+                timeit(lambda: aum_hip.frontend_tokens(wave, tabs, 1024, -4.27, 4.57, w16, fbias, pos, cls_row, 256, save_patches=save)),
+                wave_bytes + tok_bytes + (Bsz * 512 * 256 * 2 if save else 0))
     bc = 2 * Bsz * N * L * s
     fused = L <= aum_hip.get().max_single_pass_len      # longer rows: chunked kernels, one launch per direction
     if want("scan_fwd"):
