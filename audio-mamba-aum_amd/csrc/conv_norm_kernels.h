@@ -428,22 +428,16 @@ template <class TX, class TR, int NCH> AUM_DEV void rmsnorm_bwd_vec(const AumNor
 
 // float4-style streaming copy used to measure the achievable HBM bandwidth on the box.
 #if !defined(AUM_EMU) && (!defined(AUM_API_PART) || AUM_API_PART == 3 || AUM_API_PART == 0)
-// Four independent 16-byte loads in flight per thread before the first store (the one-load-per-iteration form measured 4.8-5.0
-// TB/s where torch's copy reached 5.1-5.5 on the same boxes).  Plain accesses: the non-temporal form of the same loop measured 4.36 TB/s.
+// One 16-byte element per thread, workgroups dispatched in address order: 6.2 TB/s on 1-2 GiB buffers (the guide's 6.29 TB/s float4
+// copy).  The grid-stride forms of the same copy (2048 x 256 threads walking the buffer with an 8 MiB stride, 1-4 loads in flight)
+// measured 4.5-5.0 TB/s on the same box, hipMemcpyDtoD 5.0-5.2: every wave of the chip then touches a different DRAM page per
+// iteration instead of streaming through consecutive ones (tools/hbm_probe.hip, profiles/r02_hbm_probe.txt).
 typedef float aum_f4 __attribute__((ext_vector_type(4)));
-__global__ void k_hbm_copy(const float4* __restrict__ src4, float4* __restrict__ dst4, int64_t n4) {
+__global__ __launch_bounds__(256) void k_hbm_copy(const float4* __restrict__ src4, float4* __restrict__ dst4, int64_t n4) {
     const aum_f4* __restrict__ src = reinterpret_cast<const aum_f4*>(src4);
     aum_f4* __restrict__ dst = reinterpret_cast<aum_f4*>(dst4);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const aum_f4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a;
-        dst[i + stride] = b;
-        dst[i + 2 * stride] = c;
-        dst[i + 3 * stride] = d;
-    }
-    for (; i < n4; i += stride) dst[i] = src[i];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) dst[i] = src[i];
 }
 #endif
 
