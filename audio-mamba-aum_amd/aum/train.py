@@ -99,6 +99,8 @@ def build_parser():
     a("--mixed_precision", type=str, default="bf16", choices=["no", "bf16", "fp16"],
       help="(new) what `accelerate launch --mixed_precision` selects for the reference")
     a("--depth", type=int, default=24, help="(new) number of blocks; every published AuM size uses 24 (RUN:227-237)")
+    a("--grad_compress", type=str, default="no", choices=["no", "bf16", "fp16"],
+      help="(new) exchange the gradient buckets in 16 bits (DDP communication hook): 368 -> 184 MB per step for AuM-Base")
     a("--max-steps", type=int, default=0, help="(new) stop each epoch after this many steps (smoke runs)")
     return p
 
@@ -162,6 +164,15 @@ def build_model(args):
         from .checkpoint import load_aum_checkpoint
         print(load_aum_checkpoint(model, args.aum_pretrain_path, args.aum_pretrain_fstride, args.aum_pretrain_tstride))
     return model
+
+
+def compress_gradients(ddp, kind):
+    """Optional 16-bit gradient exchange: each fp32 bucket is cast, all-reduced (RCCL ring over xGMI: per-link bound, so half the
+    bytes is close to half the exchange time) and cast back into the bucket view; master weights and Adam stay fp32."""
+    if kind == "no":
+        return
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    ddp.register_comm_hook(None, default_hooks.bf16_compress_hook if kind == "bf16" else default_hooks.fp16_compress_hook)
 
 
 class Frontend:
@@ -317,6 +328,7 @@ def train(model, train_loader, val_loader, args, D):
     if D.world > 1:
         net = nn.parallel.DistributedDataParallel(model, device_ids=[D.dev_index] if D.cuda else None,
                                                   gradient_as_bucket_view=True, static_graph=True, bucket_cap_mb=100)
+        compress_gradients(net, args.grad_compress)
     scaler = torch.amp.GradScaler("cuda", enabled=(args.mixed_precision == "fp16" and D.cuda))
     scheduler = torch.optim.lr_scheduler.MultiStepLR(
         optimizer, list(range(args.lrscheduler_start, 1000, args.lrscheduler_step)), gamma=args.lrscheduler_decay)

@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--size", default="base")
     ap.add_argument("--depth", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grad-compress", default="no", choices=["no", "bf16", "fp16"], help="16-bit gradient exchange (N > 1)")
     ap.add_argument("--no-frontend", action="store_true", help="start from spectrograms instead of waveforms")
     args = ap.parse_args()
 
@@ -163,6 +164,8 @@ def main():
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], gradient_as_bucket_view=True,
                                                         bucket_cap_mb=64, broadcast_buffers=False)
+        from aum.train import compress_gradients
+        compress_gradients(net, args.grad_compress)
     loss_fn = torch.nn.BCEWithLogitsLoss()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     if args.no_frontend:

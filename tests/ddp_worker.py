@@ -24,6 +24,9 @@ def main():
     ref = AudioMamba(spectrogram_size=(128, 128), depth=2, embed_dim=32, num_classes=5)
     ref.load_state_dict(model.state_dict())
     ddp = torch.nn.parallel.DistributedDataParallel(model, gradient_as_bucket_view=True, bucket_cap_mb=1)
+    if os.environ.get("AUM_TEST_COMPRESS"):               # the optional 16-bit gradient exchange of aum.train / bench.py
+        from aum.train import compress_gradients
+        compress_gradients(ddp, os.environ["AUM_TEST_COMPRESS"])
     g = torch.Generator().manual_seed(100)
     x_all = torch.randn(2 * world, 128, 128, generator=g) * 0.5
     y_all = (torch.rand(2 * world, 5, generator=g) > 0.7).float()
