@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from mamba_ssm.modules.mamba_simple import Mamba
+from mamba_ssm.ops.selective_scan_interface import _autocast_dtype, step_cache
 from mamba_ssm.ops.triton.layernorm import RMSNorm, rms_norm_fn
 
 AUM_SIZES = {"base": 768, "small": 384, "tiny": 192}      # embed dims; depth 24 for all three (RUN:227-237)
@@ -178,6 +179,13 @@ class AudioMamba(nn.Module):
 
     def forward_features(self, x, frontend=None):
         hidden, pos = self.tokens(x) if frontend is None else self.tokens_from_wave(x, frontend)
+        with step_cache([layer.mixer for layer in self.layers], _autocast_dtype()):     # all blocks' 16-bit weights and A in a few launches
+            hidden, residual = self._run_layers(hidden)
+        hidden = rms_norm_fn(hidden, self.norm_f.weight, self.norm_f.bias, eps=self.norm_f.eps, residual=residual,
+                             prenorm=False, residual_in_fp32=True)                            # MM:646-657
+        return hidden[:, pos]
+
+    def _run_layers(self, hidden):
         residual = None
         if not self.if_bidirectional:
             for layer in self.layers:
@@ -187,9 +195,7 @@ class AudioMamba(nn.Module):
                 hf, rf = self.layers[2 * i](hidden, residual)
                 hb, rb = self.layers[2 * i + 1](hidden.flip([1]), None if residual is None else residual.flip([1]))
                 hidden, residual = hf + hb.flip([1]), rf + rb.flip([1])
-        hidden = rms_norm_fn(hidden, self.norm_f.weight, self.norm_f.bias, eps=self.norm_f.eps, residual=residual,
-                             prenorm=False, residual_in_fp32=True)                            # MM:646-657
-        return hidden[:, pos]
+        return hidden, residual
 
     def forward(self, x, return_features=False, frontend=None):
         """x: (B, T, F) normalised log-mel spectrogram, or -- with frontend=aum.frontend.WaveInput -- (B, n_samples) waveform"""

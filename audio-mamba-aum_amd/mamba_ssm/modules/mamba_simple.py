@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from mamba_ssm.ops.selective_scan_interface import (InProjFn, bimamba_inner_fn, mamba_inner_fn, mamba_inner_fn_no_out_proj,
-                                                    selective_scan_fn)
+                                                    neg_exp, selective_scan_fn)
 from causal_conv1d import causal_conv1d_fn
 
 
@@ -96,16 +96,16 @@ class Mamba(nn.Module):
         xz = xz.reshape(-1, batch, seqlen).permute(1, 0, 2)
         if self.in_proj.bias is not None:
             xz = xz + self.in_proj.bias.to(xz.dtype)[None, :, None]
-        A = -torch.exp(self.A_log.float())
+        A = neg_exp(self.A_log)
         if self.use_fast_path and inference_params is None:                # MS:190
             if self.bimamba_type == "v1":
-                A_b = -torch.exp(self.A_b_log.float())
+                A_b = neg_exp(self.A_b_log)
                 out = bimamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                        self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A, A_b, None,
                                        None, self.D.float(), delta_bias=self.dt_proj.bias.float(),
                                        delta_softplus=True)
             elif self.bimamba_type == "v2":
-                A_b = -torch.exp(self.A_b_log.float())
+                A_b = neg_exp(self.A_b_log)
                 out_f = mamba_inner_fn_no_out_proj(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                                    self.dt_proj.weight, A, None, None, self.D.float(),
                                                    delta_bias=self.dt_proj.bias.float(), delta_softplus=True)

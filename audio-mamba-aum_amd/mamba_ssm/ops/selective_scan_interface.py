@@ -17,6 +17,7 @@ What is different by design (MI355X-first):
 The *_ref functions are this package's own pure-PyTorch statements of the same arithmetic (public names of the
 reference module; usable on CPU).  They are NOT used by the fused path.
 """
+import contextlib
 import os
 
 import torch
@@ -30,6 +31,84 @@ _custom_bwd = torch.amp.custom_bwd(device_type="cuda")
 
 def _autocast_dtype():
     return torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
+
+
+# =================================================================================================
+# per-forward weight cache
+# =================================================================================================
+# What autocast does per call -- one fp32 -> 16-bit cast kernel per projection weight and layer, plus this package's transposed
+# copies for the data-gradient kernels and the two -exp(A_log) chains -- is ~250 launches of 3-6 us per AuM-Base step.  A model
+# that owns many blocks can do all of it in a handful of launches at the top of its forward (`with step_cache(mixers, dtype)`); the
+# blocks then find their 16-bit weights, the transposes and A here.  Entries live for one forward (the autograd graph keeps what the
+# backward needs); a Mamba block used on its own finds nothing and casts per call, exactly as before.
+_STEP_CACHE = {}
+
+
+@contextlib.contextmanager
+def step_cache(mixers, dtype):
+    groups, a_logs = {}, []
+    if os.environ.get("AUM_STEP_CACHE", "1") == "0":           # A/B switch: per-call casts, as a block used on its own does
+        mixers = []
+    for m in mixers:
+        for name in ("in_proj", "x_proj", "dt_proj", "out_proj", "x_proj_b", "dt_proj_b"):
+            lin = getattr(m, name, None)
+            if lin is not None and dtype is not None and lin.weight.dtype != dtype:
+                groups.setdefault((name in ("x_proj", "dt_proj", "x_proj_b", "dt_proj_b"), tuple(lin.weight.shape), lin.weight.device),
+                                  []).append(lin.weight)
+        a_logs += [p for p in (getattr(m, "A_log", None), getattr(m, "A_b_log", None)) if p is not None]
+    with torch.no_grad():
+        for (want_t, shape, dev), ps in groups.items():
+            bank = torch.empty((len(ps),) + shape, dtype=dtype, device=dev)
+            torch._foreach_copy_(list(bank.unbind(0)), [p.detach() for p in ps])          # one multi-tensor cast
+            bank_t = bank.transpose(1, 2).contiguous() if want_t else None
+            for i, p in enumerate(ps):
+                _STEP_CACHE[id(p)] = (dtype, bank[i], None if bank_t is None else bank_t[i])
+        by_shape = {}
+        for p in a_logs:
+            by_shape.setdefault((tuple(p.shape), p.device), []).append(p)
+        for ps in by_shape.values():
+            A = -torch.exp(torch.stack([p.detach().float() for p in ps]))
+            for i, p in enumerate(ps):
+                _STEP_CACHE[id(p)] = ("A", A[i], None)
+    try:
+        yield
+    finally:
+        _STEP_CACHE.clear()
+
+
+def _cast(w, dtype):
+    """w in `dtype` (None: unchanged): the cached copy of the running forward if there is one, else a cast."""
+    if w is None or dtype is None or w.dtype == dtype:
+        return w
+    c = _STEP_CACHE.get(id(w))
+    return c[1] if c is not None and c[0] == dtype else w.to(dtype)
+
+
+def _cast_t(w, dtype):
+    """contiguous transpose of the 2-D weight w in `dtype` (None: w's own)"""
+    c = _STEP_CACHE.get(id(w))
+    if c is not None and c[0] == dtype and c[2] is not None:
+        return c[2]
+    return (w if dtype is None else w.to(dtype)).t().contiguous()
+
+
+class _NegExpFn(torch.autograd.Function):
+    """A = -exp(A_log) with the value taken from the cache: d A / d A_log = A, one launch in the backward"""
+
+    @staticmethod
+    def forward(ctx, A_log, A):
+        ctx.save_for_backward(A)
+        return A.view_as(A)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.saved_tensors[0], None
+
+
+def neg_exp(A_log):
+    """-exp(A_log.float())  (MS:190, 204, 220)"""
+    c = _STEP_CACHE.get(id(A_log))
+    return _NegExpFn.apply(A_log, c[1]) if c is not None and c[0] == "A" else -torch.exp(A_log.float())
 
 
 # =================================================================================================
@@ -121,19 +200,22 @@ def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
 # =================================================================================================
 # fused inner blocks  (SSI:155-633)
 # =================================================================================================
-def split_k_wgrad(a_mk, b_kn, splits):
+def split_k_wgrad(a_mk, b_kn, splits, out_dtype=None):
     """a_mk [M, K] @ b_kn [K, N] with a long K (= batch*len tokens) and a small [M, N] result: the weight-gradient GEMMs
     of the in/out projections.  hipBLASLt's best single-GEMM solutions keep the matrix pipe 20-31 % busy on these shapes
     (profiles/r01_mfma_busy.txt: 18-48 output tiles for 256 CUs); splitting K into `splits` batched GEMMs on strided
     views (no copies) and summing the partial products in fp32 fills the chip (sweep on one box, in/out splits: 4/8 85.0,
-    8/8 86.1, 16/8 85.5, 4/4 85.8, 4/16 85.4, 2/8 85.9 ms per step; single GEMMs 87.9).  AUM_WGRAD_SPLIT=0 restores the single GEMM."""
+    8/8 86.1, 16/8 85.5, 4/4 85.8, 4/16 85.4, 2/8 85.9 ms per step; single GEMMs 87.9).  AUM_WGRAD_SPLIT=0 restores the single GEMM.
+    out_dtype: the parameter's dtype -- the fp32 sum is handed over as it is instead of being rounded to 16 bits and widened again by
+    autograd (two cast launches per weight; the reference's autocast GEMM rounds its weight gradient to 16 bits, this one does not)."""
     K = a_mk.shape[1]
+    out_dtype = out_dtype or a_mk.dtype
     if splits <= 1 or K % splits or K // splits < 1024 or os.environ.get("AUM_WGRAD_SPLIT", "1") == "0" or not a_mk.is_cuda:
-        return torch.matmul(a_mk, b_kn)
+        return torch.matmul(a_mk, b_kn).to(out_dtype)
     kc = K // splits
     a3 = a_mk.unflatten(1, (splits, kc)).permute(1, 0, 2)          # [S, M, kc], strided view
     b3 = b_kn.unflatten(0, (splits, kc))                            # [S, kc, N]
-    return torch.bmm(a3, b3).sum(0, dtype=torch.float32).to(a_mk.dtype)
+    return torch.bmm(a3, b3).sum(0, dtype=torch.float32).to(out_dtype)
 
 
 class InProjFn(torch.autograd.Function):
@@ -142,8 +224,7 @@ class InProjFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weight, hidden2d):
-        act = _autocast_dtype()
-        w = weight.to(act) if act is not None else weight
+        w = _cast(weight, _autocast_dtype())
         h = hidden2d.to(w.dtype)
         ctx.save_for_backward(w, h)
         ctx.wdtype, ctx.hdtype = weight.dtype, hidden2d.dtype
@@ -154,8 +235,8 @@ class InProjFn(torch.autograd.Function):
         w, h = ctx.saved_tensors
         dxz2d = dxz2d.to(w.dtype)
         dh = torch.matmul(dxz2d.t(), w) if ctx.needs_input_grad[1] else None
-        dw = split_k_wgrad(dxz2d, h, 4) if ctx.needs_input_grad[0] else None
-        return (None if dw is None else dw.to(ctx.wdtype)), (None if dh is None else dh.to(ctx.hdtype))
+        dw = split_k_wgrad(dxz2d, h, 4, ctx.wdtype) if ctx.needs_input_grad[0] else None
+        return dw, (None if dh is None else dh.to(ctx.hdtype))
 
 
 def _dm2d(t):
@@ -174,11 +255,12 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     if A.is_complex():
         raise NotImplementedError("real A only (SSI:502 asserts the same for the bidirectional path)")
     act = _autocast_dtype()
-    if act is not None:                                    # SSI:452-457: only the projection weights are cast
-        x_proj_weight = x_proj_weight.to(act)
-        delta_proj_weight = delta_proj_weight.to(act)
-        out_proj_weight = out_proj_weight.to(act) if out_proj_weight is not None else None
-        out_proj_bias = out_proj_bias.to(act) if out_proj_bias is not None else None
+    ctx.out_proj_wdtype = out_proj_weight.dtype if out_proj_weight is not None else None
+    # SSI:452-457: only the projection weights are cast.  The transposes feed the data-gradient kernel (SSI:587, 590).
+    x_proj_wt = _cast_t(x_proj_weight, act) if any(ctx.needs_input_grad) else None
+    delta_proj_wt = _cast_t(delta_proj_weight, act) if any(ctx.needs_input_grad) else None
+    x_proj_weight, delta_proj_weight = _cast(x_proj_weight, act), _cast(delta_proj_weight, act)
+    out_proj_weight, out_proj_bias = _cast(out_proj_weight, act), _cast(out_proj_bias, act)
     if xz.stride(-1) != 1:
         xz = xz.contiguous()
     Bsz, two_e, L = xz.shape
@@ -234,7 +316,8 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     ctx.out_proj_bias_is_None = out_proj_bias is None
     ctx.B_proj_bias_is_None, ctx.C_proj_bias_is_None = B_proj_bias is None, C_proj_bias is None
     ctx.save_for_backward(xz, conv_w, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight,
-                          conv_out, delta, A, A_b, Bm, Cm, D, delta_bias, out_pre, out_pre_b, out_z, ck_f, ck_b)
+                          conv_out, delta, A, A_b, Bm, Cm, D, delta_bias, out_pre, out_pre_b, out_z, ck_f, ck_b,
+                          x_proj_wt, delta_proj_wt)
     if out_proj_weight is None:
         return out_z                                                                          # SSI:224
     out = torch.matmul(_dm2d(out_z).t(), out_proj_weight.t())                                 # SSI:517
@@ -245,7 +328,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
 
 def _inner_backward(ctx, dout):
     (xz, conv_w, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, A_b, Bm,
-     Cm, D, delta_bias, out_pre, out_pre_b, out_z, ck_f, ck_b) = ctx.saved_tensors
+     Cm, D, delta_bias, out_pre, out_pre_b, out_z, ck_f, ck_b, x_proj_wt, delta_proj_wt) = ctx.saved_tensors
     Bsz, two_e, L = xz.shape
     E = two_e // 2
     R = delta_proj_weight.shape[1]
@@ -257,7 +340,7 @@ def _inner_backward(ctx, dout):
     if ctx.has_out_proj:
         dout2 = dout.reshape(Bsz * L, -1).to(out_proj_weight.dtype)
         dout_z = torch.matmul(out_proj_weight.t(), dout2.t()).reshape(E, Bsz, L).permute(1, 0, 2)   # SSI:540
-        dout_proj_weight = split_k_wgrad(dout2.t(), _dm2d(out_z).t(), 8)                             # SSI:563
+        dout_proj_weight = split_k_wgrad(dout2.t(), _dm2d(out_z).t(), 8, ctx.out_proj_wdtype)        # SSI:563
         dout_proj_bias = dout2.sum(0) if not ctx.out_proj_bias_is_None else None
     else:
         dout_z = dout if dout.stride(-1) == 1 else dout.contiguous()
@@ -288,8 +371,7 @@ def _inner_backward(ctx, dout):
     dconv_out, ddelta = g["du"], g["ddelta"]
     if ctx.proj_kernels:
         ddelta2, dconv2 = _dm2d(ddelta), _dm2d(dconv_out)
-        dx_dbl = aum_hip.proj_bwd_data(ddelta2, delta_proj_weight.t().contiguous(), x_proj_weight.t().contiguous(),
-                                       g["dB"], g["dC"], dconv2, L)                          # SSI:570-574, 587, 590
+        dx_dbl = aum_hip.proj_bwd_data(ddelta2, delta_proj_wt, x_proj_wt, g["dB"], g["dC"], dconv2, L)   # SSI:570-574, 587, 590
         ddelta_proj_weight = aum_hip.proj_bwd_weight(ddelta2, x_dbl[:R], False)              # SSI:586
         dx_proj_weight = aum_hip.proj_bwd_weight(_dm2d(conv_out), dx_dbl, True)              # SSI:589
         _, dconv_w, dconv_b = aum_hip.conv1d_bwd(x, conv_w, conv1d_bias, dconv_out, True, ctx.reverse, dx_out=dx)  # SSI:594

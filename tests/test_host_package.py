@@ -268,3 +268,38 @@ def test_streaming_inference_matches_full_sequence():
     assert c2.shape == (3, 64, 4) and s2.shape == (3, 64, 16) and float(c2.abs().sum()) == 0
     with pytest.raises(NotImplementedError):
         Mamba(32, layer_idx=0, bimamba_type="v1")(x, inference_params=params)
+
+
+def test_step_cache_is_the_per_call_arithmetic(monkeypatch):
+    """The per-forward weight cache (16-bit projection weights, their transposes, A = -exp(A_log) for all blocks in a few launches)
+    holds exactly what each block would compute per call, lives for one forward, and leaves logits and gradients unchanged."""
+    import contextlib
+    from aum.model import AudioMamba
+    from aum import model as M
+    from mamba_ssm.ops import selective_scan_interface as S
+    torch.manual_seed(5)
+    model = AudioMamba(spectrogram_size=(128, 64), depth=2, embed_dim=32, num_classes=3, bimamba_type="v1")
+    mixers = [l.mixer for l in model.layers]
+    with S.step_cache(mixers, torch.bfloat16):
+        for m in mixers:
+            for lin in (m.in_proj, m.x_proj, m.dt_proj, m.out_proj):
+                assert torch.equal(S._cast(lin.weight, torch.bfloat16), lin.weight.to(torch.bfloat16))
+            for lin in (m.x_proj, m.dt_proj):
+                assert torch.equal(S._cast_t(lin.weight, torch.bfloat16), lin.weight.to(torch.bfloat16).t().contiguous())
+                assert S._cast_t(lin.weight, torch.bfloat16).is_contiguous()
+            assert torch.equal(S.neg_exp(m.A_log), -torch.exp(m.A_log.float()))
+            assert torch.equal(S.neg_exp(m.A_b_log), -torch.exp(m.A_b_log.float()))
+        assert S._cast(mixers[0].in_proj.weight, torch.float16).dtype == torch.float16      # another dtype: plain cast
+    assert not S._STEP_CACHE
+    x = torch.randn(2, 64, 128)
+    outs = []
+    for cached in (True, False):
+        if not cached:
+            monkeypatch.setattr(M, "step_cache", lambda *a, **k: contextlib.nullcontext())
+        model.zero_grad()
+        y = model(x)
+        y.square().sum().backward()
+        outs.append((y.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
