@@ -172,7 +172,7 @@ def main():
         x = torch.randn(args.batch, 1024, 128, device=dev, generator=g) * 0.5   # SURVEY 8d synthetic spectrograms
         spec = lambda: x
         fe = None
-    else:   # 10 s / 16 kHz synthetic waveforms; the fused log-mel frontend runs inside the timed step (config 2)
+    else:   # 10 s / 16 kHz synthetic waveforms; waveform -> tokens (aum_frontend_tokens_fwd) runs inside the timed step (config 2)
         from aum.frontend import FbankTables, WaveInput, prepare_wave
         tabs = FbankTables(dev)
         wave = (torch.randn(args.batch, 160000, device=dev, generator=g) * 0.1).clamp_(-1, 1)
@@ -273,7 +273,7 @@ def main():
             "config": {"workload": f"AuM-{args.size.capitalize()} (d_model={model.embed_dim}, {args.depth} Fo-Bi blocks, "
                                    f"d_state=16, {n_params / 1e6:.1f}M params) 128-mel x 1024-frame clips, L=513 tokens, "
                                    "fwd+bwd+Adam, bf16 autocast / fp32 master weights"
-                                   + ("" if args.no_frontend else ", input = 160000-sample waveforms through the HIP log-mel frontend"),
+                                   + ("" if args.no_frontend else ", input = 160000-sample waveforms through the one-launch HIP frontend (log-mel + 16x16 patch embedding + position rows)"),
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}" + (" (DDP, RCCL all-reduce overlapped with backward)" if world > 1 else "")},
             "roofline": roof,

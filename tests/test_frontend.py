@@ -19,11 +19,11 @@ def _wave(n, seed):
     return (0.1 * r.normal(0, 1, n) + 0.3 * np.sin(2 * np.pi * 440 * t) + 0.05 * np.sin(2 * np.pi * 3000 * t * (1 + t))).astype(np.float32)
 
 
-def _check(lib, dev, n_samples, target, batch=2):
+def _check(lib, dev, n_samples, target, batch=2, sr=16000):
     from aum.frontend import FbankTables, wav2fbank
-    tabs = FbankTables(dev)
+    tabs = FbankTables(dev, sample_rate=sr)
     # host tables agree with the oracle's dense filterbank
-    s, c, w = OF.sparse_banks()
+    s, c, w = OF.sparse_banks(padded=tabs.tables["padded"], sr=float(sr))
     assert np.array_equal(tabs.tables["mel_start_f"].cpu().numpy().astype(np.int32), s)
     assert np.array_equal(tabs.tables["mel_count_f"].cpu().numpy().astype(np.int32), c)
     assert np.allclose(tabs.tables["mel_w"].cpu().numpy(), w, atol=1e-7)
@@ -35,7 +35,7 @@ def _check(lib, dev, n_samples, target, batch=2):
     finally:
         aum_hip._product = old
     for i in range(batch):
-        ref = OF.frontend(waves[i].astype(np.float64), target_length=target)
+        ref = OF.frontend(waves[i].astype(np.float64), target_length=target, sr=sr)
         assert out[i].shape == ref.shape
         # log-mel values are O(1) after normalisation; fp32 FFT vs fp64: a few 1e-5 typical, bins with tiny energy larger
         err = np.abs(out[i] - ref)
@@ -48,6 +48,9 @@ def test_fbank_emu():
     lib = aum_hip.Lib(build_emu.build(), host=True)
     _check(lib, "cpu", 16000 + 37, 120)         # 98 frames + zero padding rows
     _check(lib, "cpu", 9000, 40, batch=1)       # cut: more frames than target_length
+    # other sample rates = other FFT sizes: the workgroup-per-frame kernel (the 512-point case above runs one wavefront per frame)
+    _check(lib, "cpu", 4000 + 11, 60, batch=1, sr=8000)        # 25 ms = 200 samples -> 256-point FFT
+    _check(lib, "cpu", 9000, 20, batch=1, sr=32000)            # 800 samples -> 1024-point FFT
 
 
 @pytest.mark.gpu
@@ -55,6 +58,8 @@ def test_fbank_gpu():
     lib = aum_hip.get()
     _check(lib, "cuda", 160000, 1024, batch=4)   # the AudioSet clip: 998 frames padded to 1024
     _check(lib, "cuda", 16000 + 37, 120)
+    _check(lib, "cuda", 8000 * 3, 320, sr=8000)
+    _check(lib, "cuda", 32000 * 2, 200, sr=32000)
 
 
 def test_oracle_matches_transformers_kaldi_fbank():
