@@ -1,0 +1,13 @@
+set -x
+export PYTHONPATH=$PWD/audio-mamba-aum_amd:$PYTHONPATH
+mkdir -p gpurun_out/final
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/final/pytest_gpu.log 2>&1; tail -5 gpurun_out/final/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -3
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/final/run -o bench -- python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
+tail -c 400 gpurun_out/final/bench.json
+db=$(find gpurun_out/final/run -name "*.db" | head -1)
+python tools/rocpd_stats.py $db gpurun_out/final/kernel_stats.txt | head -30
+find gpurun_out/final/run -name "*.db" -delete
+timeout 600 python tools/kbench.py 2>&1 | grep -v amdgpu > gpurun_out/final/kbench.txt; cp gpurun_out/kbench_bf16_B64.json gpurun_out/final/kbench.json
+timeout 300 python bench.py --no-cpu-baseline > gpurun_out/final/bench_plain.json 2>/dev/null; python -c "import json;d=json.load(open('gpurun_out/final/bench_plain.json'));print('plain',d['ms_per_step'],d['value'])"
