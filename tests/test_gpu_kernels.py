@@ -247,3 +247,60 @@ def test_scan_backward_bitwise_repeatable(lib):
                 ref = cur
             for k in ref:
                 assert torch.equal(ref[k], cur[k]), (it, k)
+
+
+@pytest.mark.gpu
+def test_scan_headline_grid_b64(lib):
+    """The bench's own launch shape -- B = 64, E = 1536, L = 513, N = 16, bf16, channel-major rows: 98 304 rows, 1 024 backward
+    workgroups -- checked instead of only timed.  (i) sampled rows of the per-(batch, channel) outputs (out, du, ddelta, dz) against
+    the fp64 oracle run on exactly those rows (a row's result depends only on its own u, delta, z and its batch entry's B, C);
+    (ii) dB / dC of sampled batch entries against a B = 1 launch on that entry (batch independence); (iii) the batch-summed dA, dA_b,
+    dD, ddelta_bias against the sum of eight B = 8 launches; (iv) bitwise repeatable."""
+    from oracle import oracle as O
+    torch.manual_seed(3)
+    Bsz, E, L, N = 64, 1536, 513, 16
+    dt = torch.bfloat16
+    mk = lambda s=1.0: (s * torch.randn(E, Bsz, L, device="cuda")).to(dt).permute(1, 0, 2)
+    u, z, dout, delta = mk(), mk(), mk(), mk(0.5)
+    Bm, Cm = torch.randn(Bsz, 1, N, L, device="cuda").to(dt), torch.randn(Bsz, 1, N, L, device="cuda").to(dt)
+    A = -torch.arange(1, N + 1, device="cuda", dtype=torch.float32).repeat(E, 1) * (1 + 0.1 * torch.rand(E, N, device="cuda"))
+    A_b = A * (1 + 0.1 * torch.rand(E, N, device="cuda"))
+    D, bias = torch.rand(E, device="cuda") + 0.5, torch.full((E,), -4.0, device="cuda") + torch.rand(E, device="cuda")
+    out, pre, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, lib=lib)
+    g = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, A_b=A_b, lib=lib)
+    g2 = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, A_b=A_b, lib=lib)
+    for k, v in g.items():
+        assert v is None or torch.equal(v, g2[k]), k
+    f = lambda t: t.float().cpu().numpy()
+    # (i) sampled rows: first / last workgroup of a batch entry, a wave boundary, the last batch entry
+    rows = [(0, 0), (0, 95), (0, 96), (17, 700), (31, 1535), (63, 0), (63, 1535), (40, 1000)]
+    for b in sorted({r[0] for r in rows}):
+        es = [e for (bb, e) in rows if bb == b]
+        sl = lambda t: f(t[b:b + 1, es])
+        args = (sl(u), sl(delta))
+        Aq, Abq, Dq, bq = f(A[es]), f(A_b[es]), f(D[es]), f(bias[es])
+        Bq, Cq = f(Bm[b:b + 1, 0]), f(Cm[b:b + 1, 0])
+        rf = O.scan_fwd(*args, Aq, Bq, Cq, Dq, sl(z), bq, True, False, "f64")
+        rb = O.scan_fwd(*args, Abq, Bq, Cq, Dq, sl(z), bq, True, True, "f64")
+        assert KC.rel_err(sl(out), rf["out"] + rb["out"]) < KC.TOL_BF16
+        gf = O.scan_bwd(*args, Aq, Bq, Cq, Dq, sl(z), bq, sl(dout), True, False, "f64")
+        gb = O.scan_bwd(*args, Abq, Bq, Cq, Dq, sl(z), bq, sl(dout), True, True, "f64")
+        for k in ("du", "ddelta", "dz"):
+            assert KC.rel_err(sl(g[k]), gf[k] + gb[k]) < 4 * KC.TOL_BF16, (b, k)
+    # (ii) dB / dC of a batch entry do not depend on the other entries
+    for b in (0, 29, 63):
+        s1 = lambda t: t[b:b + 1]
+        o1, p1, _ = aum_hip.scan_fwd(s1(u), s1(delta), A, s1(Bm), s1(Cm), D, s1(z), bias, True, A_b=A_b, want_out_pre=True, lib=lib)
+        g1 = aum_hip.scan_bwd(s1(u), s1(delta), A, s1(Bm), s1(Cm), D, s1(z), bias, s1(dout), p1, True, A_b=A_b, lib=lib)
+        assert torch.equal(o1, out[b:b + 1])
+        for k in ("dB", "dC"):
+            assert torch.equal(g1[k], g[k][b:b + 1]), (b, k)
+    # (iii) batch-summed parameter gradients: the same sum taken over eight B = 8 launches (fp32 reassociation only)
+    acc = {k: torch.zeros_like(g[k]) for k in ("dA", "dA_b", "dD", "ddelta_bias")}
+    for b0 in range(0, Bsz, 8):
+        s8 = lambda t: t[b0:b0 + 8]
+        g8 = aum_hip.scan_bwd(s8(u), s8(delta), A, s8(Bm), s8(Cm), D, s8(z), bias, s8(dout), s8(pre), True, A_b=A_b, lib=lib)
+        for k in acc:
+            acc[k] += g8[k]
+    for k in acc:
+        assert (acc[k] - g[k]).abs().max() <= 1e-4 * g[k].abs().max(), k
