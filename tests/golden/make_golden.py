@@ -361,9 +361,30 @@ def launcher_goldens(torch, ssi, ln):
     print("launcher.npz", len(out))
 
 
+def wav_excerpts():
+    """Real audio for the log-mel frontend tests: 3-second int16 excerpts of the five example clips the reference ships for its
+    inference notebook (examples/inference/data/sample{0..4}.wav, 16 kHz mono; data files, not source).  They hold what synthetic
+    noise + sines do not: near-silent stretches (the log floor), onsets, a real spectral tilt.  No expected outputs are stored --
+    torchaudio is absent, so the frontend's oracle stays parity-unpinned; the tests compare kernel and oracle on these inputs."""
+    import wave
+    out = {}
+    for i in range(5):
+        w = wave.open(os.path.join(REF, "examples", "inference", "data", f"sample{i}.wav"))
+        assert w.getframerate() == 16000 and w.getnchannels() == 1 and w.getsampwidth() == 2
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+        start = (1 + 2 * i) * 16000 - 37 * i                   # different offsets, not frame-aligned
+        out[f"sample{i}"] = pcm[start:start + 3 * 16000].copy()
+    np.savez_compressed(os.path.join(HERE, "wav_excerpts.npz"), **out)
+    print("wav_excerpts.npz", {k: (v.shape, int(np.abs(v).max())) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     main()
+    if os.path.isdir(REF) and "--wav-only" in sys.argv:
+        wav_excerpts()
+        sys.exit(0)
     if os.path.isdir(REF) and "--no-model" not in sys.argv:
         torch_, ssi_, ln_, _ = import_reference()
         model_goldens(torch_, ssi_, ln_)
         launcher_goldens(torch_, ssi_, ln_)
+        wav_excerpts()
