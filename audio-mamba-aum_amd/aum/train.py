@@ -18,7 +18,6 @@ Out of scope here (rejected with an error): --model ast, epic_sounds, flexible p
 import argparse
 import ast as _ast
 import datetime
-import math
 import os
 import pickle
 import random

@@ -15,7 +15,6 @@ import os
 import sys
 import types
 
-import numpy as np
 import pytest
 import torch
 

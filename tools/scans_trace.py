@@ -6,7 +6,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "audio-mamba-aum_amd"))
 import aum_hip
-import ctypes as C
 
 bidir = "--bidir" in sys.argv
 dt = torch.bfloat16
