@@ -25,6 +25,24 @@ namespace aum {
 // the one-direction kernels fit 128 VGPRs -> 16 waves 0.97 ms vs 12 waves 1.05 ms vs 8 waves 1.18 ms.
 AUM_HOSTDEV constexpr int scanh_nw(int mode) { return mode == 2 ? 12 : 16; }
 AUM_HOSTDEV constexpr int scanh_rows(int mode) { return mode == 2 ? 96 : 64; }      // a multiple of the wave count
+// Rows per workgroup sized to the launch.  Only one workgroup fits a CU (four LDS tiles), each pays for the B/C tile load and the
+// dB/dC tile flush of its batch entry, and every workgroup leaves one dB/dC partial for the reduce kernel: so as few, as long
+// workgroups as still cover the chip -- one per CU when the launch is large enough (B = 64, E = 1536: 384 rows, 256 workgroups, 4
+// partials per batch entry instead of 16), down to one row per wave for small batches (B = 8: 48 rows, 256 workgroups, where
+// the fixed 96 left half of the CUs idle).  -DAUM_SCANH_ROWS_FIXED=1 restores the fixed count for A/B runs, =n (> 1) forces n rows.
+#ifndef AUM_SCANH_ROWS_FIXED
+#define AUM_SCANH_ROWS_FIXED 0
+#endif
+constexpr int SCANH_NUM_CU = 256;
+constexpr int SCANH_MAX_ROWS = 384;
+AUM_HOSTDEV inline int scanh_rows_for(int batch, int dim, int mode) {
+    if (AUM_SCANH_ROWS_FIXED) return AUM_SCANH_ROWS_FIXED > 1 ? AUM_SCANH_ROWS_FIXED : scanh_rows(mode);
+    const int nw = scanh_nw(mode);
+    int64_t r = (int64_t)batch * dim / SCANH_NUM_CU / nw * nw;
+    if (r < nw) r = nw;
+    if (r > SCANH_MAX_ROWS) r = SCANH_MAX_ROWS;
+    return (int)r;
+}
 // Opt-in tile layout (-DAUM_SCANH_PAIRED=1, off until measured on the GPU): a lane's steps i and 4+i adjacent in the LDS tiles, so
 // the B/C reads and the dB/dC read-add-write move whole vf2 values (ds_read2_b32 / v_pk_add_f32 / ds_write2_b32) and the 12
 // v_mov_b32 per state that re-pair the default layout's (i, i+1) reads disappear ("next (0)").

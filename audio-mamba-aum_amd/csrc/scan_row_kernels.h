@@ -41,6 +41,20 @@ AUM_HOSTDEV constexpr int scanr_bwd_nw(int mode) { return mode == 2 ? AUM_SCANR_
 AUM_HOSTDEV constexpr int scanr_bwd_rows(int mode) { return 8 * scanr_bwd_nw(mode); }
 constexpr int SCANR_TACC = 128;                        // floats per wave of the tail dB/dC hand-off area
 constexpr int scanr_fwd_lds_floats() { return 2 * ScanGeo<8, 1>::TILE; }
+// Rows per forward workgroup.  Unlike the one-row backward (scanh_rows_for: one workgroup per CU, so fewer and longer is better) the
+// forward has two workgroups per CU and gains from MORE, shorter ones: one workgroup's tile load and row prologues overlap the
+// other's state loops.  Sweep at B = 64, E = 1536 (fused bidirectional, training): 16 / 32 / 64 / 96 / 192 rows = 0.540 / 0.540 /
+// 0.556 / 0.568 / 0.600 ms.  32 rows while that still gives >= 1024 workgroups, fewer for small batches.
+// -DAUM_SCANR_FWD_ROWS=n overrides the count for sweeps.
+#ifndef AUM_SCANR_FWD_ROWS
+#define AUM_SCANR_FWD_ROWS 0
+#endif
+AUM_HOSTDEV inline int scanr_fwd_rows_for(int batch, int dim) {
+    if (AUM_SCANR_FWD_ROWS) return AUM_SCANR_FWD_ROWS;
+    int rows = 32;
+    while (rows > SCANR_FWD_NW && (int64_t)batch * ((dim + rows - 1) / rows) < 1024) rows /= 2;
+    return rows;
+}
 constexpr int scanr_bwd_lds_floats() { return 4 * ScanGeo<8, 1>::TILE + 16 * SCANR_TACC; }
 AUM_HOSTDEV bool scanr_selected(int len, int dstate, uint32_t flags) {
     return len == SCANR_LEN && dstate <= SCANWG_MAX_N && !(flags & (AUM_SCAN_ROWPAIR | AUM_SCAN_GENERIC));

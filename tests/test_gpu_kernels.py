@@ -287,14 +287,14 @@ def test_scan_headline_grid_b64(lib):
         gb = O.scan_bwd(*args, Abq, Bq, Cq, Dq, sl(z), bq, sl(dout), True, True, "f64")
         for k in ("du", "ddelta", "dz"):
             assert KC.rel_err(sl(g[k]), gf[k] + gb[k]) < 4 * KC.TOL_BF16, (b, k)
-    # (ii) dB / dC of a batch entry do not depend on the other entries
+    # (ii) dB / dC of a batch entry do not depend on the other entries (a B = 1 launch groups the rows differently: fp32 reassociation)
     for b in (0, 29, 63):
         s1 = lambda t: t[b:b + 1]
         o1, p1, _ = aum_hip.scan_fwd(s1(u), s1(delta), A, s1(Bm), s1(Cm), D, s1(z), bias, True, A_b=A_b, want_out_pre=True, lib=lib)
         g1 = aum_hip.scan_bwd(s1(u), s1(delta), A, s1(Bm), s1(Cm), D, s1(z), bias, s1(dout), p1, True, A_b=A_b, lib=lib)
         assert torch.equal(o1, out[b:b + 1])
         for k in ("dB", "dC"):
-            assert torch.equal(g1[k], g[k][b:b + 1]), (b, k)
+            assert (g1[k] - g[k][b:b + 1]).abs().max() <= 1e-5 * g1[k].abs().max(), (b, k)
     # (iii) batch-summed parameter gradients: the same sum taken over eight B = 8 launches (fp32 reassociation only)
     acc = {k: torch.zeros_like(g[k]) for k in ("dA", "dA_b", "dD", "ddelta_bias")}
     for b0 in range(0, Bsz, 8):

@@ -1,0 +1,12 @@
+set -x
+export PYTHONPATH=$PWD/audio-mamba-aum_amd:$PYTHONPATH
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "scan" 2>&1 | tail -4
+for i in 1 2 3; do
+AUM_DEBUG=1 AUM_HIP_LIB=$PWD/audio-mamba-aum_amd/aum_hip/variants/libaum_hip_rowsfixed.so timeout 300 python tools/kbench.py --only scan_bwd 2>&1 | grep '"scan_bwd' | sed 's/^/fixed /'
+timeout 300 python tools/kbench.py --only scan_bwd 2>&1 | grep '"scan_bwd' | sed 's/^/sized /'
+done | tee gpurun_out/r2_ab_rows.txt
+for B in 8 16; do
+AUM_DEBUG=1 AUM_HIP_LIB=$PWD/audio-mamba-aum_amd/aum_hip/variants/libaum_hip_rowsfixed.so timeout 300 python tools/kbench.py --only scan_bwd --batch $B 2>&1 | grep '"scan_bwd' | sed "s/^/fixed B$B /"
+timeout 300 python tools/kbench.py --only scan_bwd --batch $B 2>&1 | grep '"scan_bwd' | sed "s/^/sized B$B /"
+done | tee -a gpurun_out/r2_ab_rows.txt
