@@ -39,6 +39,7 @@ class _Debug:
         self.no_ckpt = False       # long rows: no chunk-entry checkpoint
         self.no_accumulate = False  # long rows: second direction does not accumulate into the first one's tensors
         self.no_lane_ckpt = False  # L = 513 rows: scan_lane_ckpt() hands out no checkpoint
+        self.proj_splits = 0       # token splits of the projection weight-gradient kernel (0: aum_proj_bwd_weight_splits)
         if os.environ.get("AUM_DEBUG") == "1":
             self.ablate = int(os.environ.get("AUM_ABLATE", "0"))
             self.rowpair = os.environ.get("AUM_SCAN_ROWPAIR") == "1"
@@ -669,7 +670,7 @@ def proj_bwd_weight(x2d, y2d, transpose_out, lib=None):
     assert x2d.is_contiguous() and y2d.stride(1) == 1 and y2d.stride(0) == x2d.shape[1] and x2d.dtype == y2d.dtype
     dim, ntok = x2d.shape
     nrows = y2d.shape[0]
-    nsplit = int(lib.c.aum_proj_bwd_weight_splits(dim, ntok))
+    nsplit = debug.proj_splits or int(lib.c.aum_proj_bwd_weight_splits(dim, ntok))
     if nsplit <= 0:
         raise RuntimeError("aum_proj_bwd_weight: unsupported shape")
     part = torch.empty((nsplit, nrows, dim) if transpose_out else (nsplit, dim, nrows), dtype=torch.float32, device=x2d.device)
