@@ -14,7 +14,10 @@
 
 namespace aum {
 
-constexpr int CONVR_ROWS = 8;      // rows (batch entries of one channel) per wavefront
+#ifndef AUM_CONVR_ROWS
+#define AUM_CONVR_ROWS 8
+#endif
+constexpr int CONVR_ROWS = AUM_CONVR_ROWS;      // rows (batch entries of one channel) per wavefront
 constexpr int CONVR_MAIN = 512;    // steps owned by the lanes
 constexpr int CONVR_MAXTAIL = 8;
 
