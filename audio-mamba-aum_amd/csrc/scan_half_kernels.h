@@ -452,7 +452,11 @@ constexpr int SCANH_CH_NW = 16, SCANH_CH_ROWS = 64;
 template <int TAIL> constexpr int scanh_chunked_lds_floats() { return 4 * ScanGeo<8, TAIL>::TILE + 2 * SCANH_CH_ROWS * SCANWG_MAX_N; }
 // rows per workgroup (a multiple of the 16 waves, at most SCANH_CH_ROWS): long-form batches are small, so the grid is sized
 // to the 256 CUs -- B = 8, E = 1536: 64 rows would leave a quarter of the chip idle (192 workgroups), 48 rows give 256
+#ifndef AUM_SCANH_CH_ROWS_FORCE
+#define AUM_SCANH_CH_ROWS_FORCE 0      // > 0: forced row count (sweeps)
+#endif
 AUM_HOSTDEV int scanh_chunked_rows(int batch, int dim) {
+    if (AUM_SCANH_CH_ROWS_FORCE) return AUM_SCANH_CH_ROWS_FORCE;
     int best = SCANH_CH_ROWS;
     long best_cost = -1;
     for (int rows = SCANH_CH_ROWS; rows >= SCANH_CH_NW; rows -= SCANH_CH_NW) {
