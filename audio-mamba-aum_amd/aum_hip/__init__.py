@@ -25,7 +25,7 @@ _ERR = {-1: "AUM_E_NULL", -2: "AUM_E_SHAPE", -3: "AUM_E_DTYPE", -4: "AUM_E_UNSUP
         -6: "AUM_E_LAUNCH"}
 
 _i64, _i32, _u32, _vp, _fp = C.c_int64, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class _Debug:
@@ -110,7 +110,7 @@ class ProjWArgs(C.Structure):
 
 EXPORTS = ["aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
-           "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy"]
+           "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows"]
 
 
 class Lib:
@@ -137,6 +137,7 @@ class Lib:
         self.c.aum_proj_bwd_weight_splits.argtypes = [_i32, _i64]
         self.c.aum_selftest_wave_scan.argtypes = [_vp, _vp, C.c_int, _vp]
         self.c.aum_hbm_copy.argtypes = [_vp, _vp, _i64, _vp]
+        self.c.aum_sum_rows.argtypes = [_vp, _vp, _i64, _i64, _i32, _vp]
         self.c.aum_selective_scan_ckpt_bytes.restype = _i64
         self.c.aum_selective_scan_ckpt_bytes.argtypes = [_i32] * 4
         self.c.aum_selective_scan_lane_ckpt_bytes.restype = _i64
@@ -510,7 +511,7 @@ def rmsnorm_bwd(dy, x_saved, weight, rstd, dresidual=None, has_residual=False, x
     a.res_dtype = _DT[x_saved.dtype]
     a.flags = 2 if generic else 0
     _launch(lib.c.aum_rmsnorm_bwd, a, dy, lib, "rmsnorm_bwd", (rows, cols, dy.element_size()))
-    dw = dwp.sum(0)
+    dw = sum_rows(dwp, lib)
     if has_residual and dres_in is None:
         dres_in = dx
     return dx, dw, dres_in
@@ -678,7 +679,7 @@ def proj_bwd_weight(x2d, y2d, transpose_out, lib=None):
     a.x, a.y, a.out, a.ntok = _ptr(x2d), _ptr(y2d), _ptr(part), ntok
     a.dim, a.nrows, a.nsplit, a.transpose_out, a.dtype = dim, nrows, nsplit, int(transpose_out), _DT[x2d.dtype]
     _launch(lib.c.aum_proj_bwd_weight, a, x2d, lib, "proj_bwd_weight", (dim, ntok, nrows))
-    return part.sum(0) if nsplit > 1 else part[0]
+    return sum_rows(part, lib) if nsplit > 1 else part[0]
 
 
 def selftest_wave_scan(P, S, rev=False, lib=None):
@@ -687,6 +688,19 @@ def selftest_wave_scan(P, S, rev=False, lib=None):
     out = torch.empty_like(inp)
     _chk(lib.c.aum_selftest_wave_scan(_ptr(inp), _ptr(out), int(rev), lib.stream(inp)), "aum_selftest_wave_scan")
     return out[:64], out[64:]
+
+
+def sum_rows(t, lib=None):
+    """t: (outer, ...) contiguous fp32 / bf16 / fp16 -> fp32 sum over dim 0, in a fixed order (aum_sum_rows): the partial results of
+    rmsnorm_bwd / proj_bwd_weight and split-K GEMM partial products.  Shapes the kernel does not take go through torch."""
+    lib = lib or get()
+    inner = t[0].numel()
+    if t.dtype not in _DT or not t.is_contiguous() or inner % 8 or t.data_ptr() % 16:
+        return t.sum(0, dtype=torch.float32)
+    lib.check_tensor(t)
+    out = torch.empty(t.shape[1:], dtype=torch.float32, device=t.device)
+    _chk(lib.c.aum_sum_rows(_ptr(t), _ptr(out), t.shape[0], inner, _DT[t.dtype], lib.stream(t)), "aum_sum_rows")
+    return out
 
 
 def hbm_copy(src, dst, lib=None):

@@ -439,6 +439,55 @@ __global__ __launch_bounds__(256) void k_hbm_copy(const float4* __restrict__ src
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) dst[i] = src[i];
 }
+
+// dst[i] = sum_o src[o][i]: 256 threads = CW columns of 8 elements x RG row groups; a thread walks rows rg, rg + RG, ... with four loads in
+// flight, the row groups meet in LDS in a fixed order (no atomics: the result does not depend on the launch).
+template <class T, int RG> __global__ __launch_bounds__(256) void k_sum_rows(const T* __restrict__ src, float* __restrict__ dst, int64_t outer, int64_t inner) {
+    constexpr int CW = 256 / RG;
+    __shared__ float part[RG > 1 ? 256 * 8 : 8];
+    const int c = threadIdx.x % CW, rg = threadIdx.x / CW;
+    const int64_t col = ((int64_t)blockIdx.x * CW + c) * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (col < inner) {
+        int64_t o = rg;
+        for (; o + 3 * RG < outer; o += 4 * RG) {
+            float v[4][8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                T e[8];
+                __builtin_memcpy(e, src + (o + q * RG) * inner + col, 8 * sizeof(T));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[q][j] = elem_to_f32(e[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
+        }
+        for (; o < outer; o += RG) {
+            T e[8];
+            __builtin_memcpy(e, src + o * inner + col, 8 * sizeof(T));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += elem_to_f32(e[j]);
+        }
+    }
+    if constexpr (RG > 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[(rg * 8 + j) * CW + c] = acc[j];
+        __syncthreads();
+        if (rg == 0 && col < inner) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float s = acc[j];
+                for (int r = 1; r < RG; ++r) s += part[(r * 8 + j) * CW + c];
+                acc[j] = s;
+            }
+        }
+    }
+    if (rg == 0 && col < inner) {
+        float4* d4 = reinterpret_cast<float4*>(dst + col);
+        d4[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        d4[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
 #endif
 
 }  // namespace aum

@@ -35,7 +35,7 @@ AUM_HOSTDEV constexpr int scanh_rows(int mode) { return mode == 2 ? 96 : 64; }  
 #endif
 constexpr int SCANH_NUM_CU = 256;
 constexpr int SCANH_MAX_ROWS = 384;
-AUM_HOSTDEV inline int scanh_rows_for(int batch, int dim, int mode) {
+AUM_HOSTDEV int scanh_rows_for(int batch, int dim, int mode) {
     if (AUM_SCANH_ROWS_FIXED) return AUM_SCANH_ROWS_FIXED > 1 ? AUM_SCANH_ROWS_FIXED : scanh_rows(mode);
     const int nw = scanh_nw(mode);
     int64_t r = (int64_t)batch * dim / SCANH_NUM_CU / nw * nw;

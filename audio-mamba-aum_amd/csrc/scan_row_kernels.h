@@ -49,7 +49,7 @@ constexpr int scanr_fwd_lds_floats() { return 2 * ScanGeo<8, 1>::TILE; }
 #ifndef AUM_SCANR_FWD_ROWS
 #define AUM_SCANR_FWD_ROWS 0
 #endif
-AUM_HOSTDEV inline int scanr_fwd_rows_for(int batch, int dim) {
+AUM_HOSTDEV int scanr_fwd_rows_for(int batch, int dim) {
     if (AUM_SCANR_FWD_ROWS) return AUM_SCANR_FWD_ROWS;
     int rows = 32;
     while (rows > SCANR_FWD_NW && (int64_t)batch * ((dim + rows - 1) / rows) < 1024) rows /= 2;

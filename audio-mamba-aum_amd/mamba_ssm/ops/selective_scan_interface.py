@@ -215,7 +215,7 @@ def split_k_wgrad(a_mk, b_kn, splits, out_dtype=None):
     kc = K // splits
     a3 = a_mk.unflatten(1, (splits, kc)).permute(1, 0, 2)          # [S, M, kc], strided view
     b3 = b_kn.unflatten(0, (splits, kc))                            # [S, kc, N]
-    return torch.bmm(a3, b3).sum(0, dtype=torch.float32).to(out_dtype)
+    return aum_hip.sum_rows(torch.bmm(a3, b3)).to(out_dtype)
 
 
 class InProjFn(torch.autograd.Function):

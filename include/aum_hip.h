@@ -27,10 +27,11 @@
 extern "C" {
 #endif
 
-#define AUM_ABI_VERSION 5   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
+#define AUM_ABI_VERSION 6   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
                                3: x_lane (lane-entry state checkpoint of the L = 513 row kernels) appended after it;
                                4: aug / noise (per-clip augmentation in the log-mel kernel's epilogue) appended to AumFbankArgs;
-                               5: aum_frontend_tokens_fwd (waveform -> token sequence in one launch) */
+                               5: aum_frontend_tokens_fwd (waveform -> token sequence in one launch);
+                               6: aum_sum_rows (fixed-order sum of partial results) */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 
@@ -290,6 +291,14 @@ int aum_abi_version(void);
 int aum_selftest_wave_scan(const float* in, float* out, int rev, void* stream);
 /* float4 streaming copy, the measured-HBM-roofline denominator of SURVEY.md 8(d) */
 int aum_hbm_copy(const void* src, void* dst, int64_t bytes, void* stream);
+
+/*
+ * dst[i] = sum over o of src[o][i] in fp32 (ABI 6): the fixed-order sum of the per-workgroup partial results that
+ * aum_rmsnorm_bwd (dweight_partial) and aum_proj_bwd_weight (out) leave to the caller, and of split-K GEMM partial products
+ * (SSI:563, 586, 589; the reference leaves the same kind of sum to torch: LN:333-372).  src: (outer, inner) contiguous in
+ * src_dtype (AUM_F32 / AUM_BF16 / AUM_F16), dst: (inner) fp32.  inner % 8 == 0, 16-byte aligned pointers.
+ */
+int aum_sum_rows(const void* src, float* dst, int64_t outer, int64_t inner, int32_t src_dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -191,3 +191,13 @@ def test_proj_limits(emu):
     assert aum_hip.proj_supported(1536, 48, 16, 64 * 513, torch.bfloat16)
     with pytest.raises(RuntimeError, match="UNSUPPORTED|unsupported"):
         aum_hip.proj_fwd(x, torch.zeros(80, 64), torch.zeros(64, 48), 16, lib=emu)
+
+
+def test_sum_rows_emu(emu):
+    """aum_sum_rows on the lane-array build: fp32 / bf16 partials, shapes of the three callers (norm partials, projection splits, split-K)"""
+    torch.manual_seed(0)
+    for shape, dt in (((37, 768), torch.float32), ((42, 48, 64), torch.float32), ((4, 24, 16), torch.bfloat16), ((3, 7), torch.float32)):
+        t = torch.randn(shape).to(dt)
+        got = aum_hip.sum_rows(t, lib=emu)
+        assert got.dtype == torch.float32 and got.shape == t.shape[1:]
+        assert torch.allclose(got, t.float().sum(0), rtol=1e-5, atol=1e-5)

@@ -304,3 +304,18 @@ def test_scan_headline_grid_b64(lib):
             acc[k] += g8[k]
     for k in acc:
         assert (acc[k] - g[k]).abs().max() <= 1e-4 * g[k].abs().max(), k
+
+
+@pytest.mark.gpu
+def test_sum_rows(lib):
+    """aum_sum_rows at the callers' shapes: every launch geometry of the dispatcher, fp32 and 16-bit partials, fixed summation order"""
+    torch.manual_seed(0)
+    for shape, dt in (((2048, 768), torch.float32), ((42, 1536, 80), torch.float32), ((42, 48, 1536), torch.float32),
+                      ((4, 3072, 768), torch.bfloat16), ((8, 768, 1536), torch.bfloat16), ((2, 192, 8), torch.float16), ((5, 40), torch.float32),
+                      ((86, 16), torch.float32)):
+        t = torch.randn(shape, device="cuda").to(dt)
+        got = aum_hip.sum_rows(t, lib=lib)
+        ref = t.double().sum(0)
+        assert got.dtype == torch.float32 and got.shape == t.shape[1:]
+        assert (got.double() - ref).abs().max() <= 2e-6 * max(1.0, ref.abs().max().item()) * shape[0] ** 0.5, (shape, dt)
+        assert torch.equal(got, aum_hip.sum_rows(t, lib=lib))
