@@ -8,6 +8,8 @@ import sys
 from collections import defaultdict
 
 NAMES = [("k_scanh_bwd<aum::bf16_t, 1, 2>", "scan_bwd_bidir"), ("k_scanh_bwd<aum::bf16_t, 1, 0>", "scan_bwd"),
+         ("k_scanr_fwd<aum::bf16_t, 2>", "scan_fwd_bidir"), ("k_scanr_fwd<aum::bf16_t, 0>", "scan_fwd"),
+         ("k_frontend_tokens<", "frontend_tokens"), ("k_fbank_w", "fbank_fwd"), ("k_sum_rows<", "sum_rows"), ("k_scan_reduce", "scan_reduce"),
          ("k_conv4_rows_fwd<", "conv_fwd"), ("k_conv4_rows_bwd<", "conv_bwd"),
          ("k_scanwg_bwd<aum::bf16_t, 8, 1, 2>", "scan_bwd_bidir_rowpair"), ("k_scanwg_fwd<aum::bf16_t, 8, 1, 2>", "scan_fwd_bidir"),
          ("k_scanwg_bwd<aum::bf16_t, 8, 1, 0>", "scan_bwd_rowpair"), ("k_scanwg_fwd<aum::bf16_t, 8, 1, 0>", "scan_fwd"),
