@@ -40,12 +40,14 @@ class _Debug:
         self.no_accumulate = False  # long rows: second direction does not accumulate into the first one's tensors
         self.no_lane_ckpt = False  # L = 513 rows: scan_lane_ckpt() hands out no checkpoint
         self.proj_splits = 0       # token splits of the projection weight-gradient kernel (0: aum_proj_bwd_weight_splits)
+        self.torch_sums = False    # partial results summed by torch.sum instead of aum_sum_rows
         if os.environ.get("AUM_DEBUG") == "1":
             self.ablate = int(os.environ.get("AUM_ABLATE", "0"))
             self.rowpair = os.environ.get("AUM_SCAN_ROWPAIR") == "1"
             self.no_ckpt = os.environ.get("AUM_SCAN_NO_CKPT") == "1"
             self.no_accumulate = os.environ.get("AUM_SCAN_NO_ACCUMULATE") == "1"
             self.no_lane_ckpt = os.environ.get("AUM_SCAN_NO_LANE_CKPT") == "1"
+            self.torch_sums = os.environ.get("AUM_TORCH_SUMS") == "1"
 
 
 debug = _Debug()
@@ -695,7 +697,10 @@ def sum_rows(t, lib=None):
     rmsnorm_bwd / proj_bwd_weight and split-K GEMM partial products.  Shapes the kernel does not take go through torch."""
     lib = lib or get()
     inner = t[0].numel()
-    if t.dtype not in _DT or not t.is_contiguous() or inner % 8 or t.data_ptr() % 16:
+    # tall and narrow (the 4096 x 768 norm partials): too few columns for this kernel's column-per-thread walk (24 workgroups;
+    # 26.8 vs 21.7 us cold) -- torch's two-stage reduce stays
+    narrow = t.shape[0] >= 1024 and inner < 8192
+    if debug.torch_sums or narrow or t.dtype not in _DT or not t.is_contiguous() or inner % 8 or t.data_ptr() % 16:
         return t.sum(0, dtype=torch.float32)
     lib.check_tensor(t)
     out = torch.empty(t.shape[1:], dtype=torch.float32, device=t.device)

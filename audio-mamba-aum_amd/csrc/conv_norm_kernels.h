@@ -450,6 +450,19 @@ template <class T, int RG> __global__ __launch_bounds__(256) void k_sum_rows(con
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (col < inner) {
         int64_t o = rg;
+        for (; o + 7 * RG < outer; o += 8 * RG) {      // eight row loads in flight
+            float v[8][8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                T e[8];
+                __builtin_memcpy(e, src + (o + q * RG) * inner + col, 8 * sizeof(T));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[q][j] = elem_to_f32(e[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[j] += ((v[0][j] + v[1][j]) + (v[2][j] + v[3][j])) + ((v[4][j] + v[5][j]) + (v[6][j] + v[7][j]));
+        }
         for (; o + 3 * RG < outer; o += 4 * RG) {
             float v[4][8];
 #pragma unroll
