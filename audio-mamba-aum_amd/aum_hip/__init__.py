@@ -444,8 +444,10 @@ def conv1d_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, gener
     bias = _f32c(bias)
     dx = dx_out if dx_out is not None else torch.empty((batch, dim, length), dtype=x.dtype, device=x.device)
     _unit(dx, "dx")
-    dw = torch.zeros_like(weight)
-    db = torch.zeros((dim,), dtype=torch.float32, device=x.device) if bias is not None else None
+    # dweight / dbias accumulate (one fp32 atomic per wave and tap): one zero fill for both
+    zb = torch.zeros((weight.numel() + (dim if bias is not None else 0),), dtype=torch.float32, device=x.device)
+    dw = zb[:weight.numel()].view_as(weight)
+    db = zb[weight.numel():] if bias is not None else None
     a = ConvArgs()
     a.x, a.dy, a.weight, a.bias, a.dx, a.dweight, a.dbias = map(_ptr, (x, dy, weight, bias, dx, dw, db))
     a.x_bs, a.x_ds, a.dy_bs, a.dy_ds = x.stride(0), x.stride(1), dy.stride(0), dy.stride(1)
