@@ -200,6 +200,19 @@ def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
 # =================================================================================================
 # fused inner blocks  (SSI:155-633)
 # =================================================================================================
+# split-K counts of the in / out projection weight gradients, in order of preference: the first that divides K = batch * len is
+# used (B = 64, L = 513: 6 and 9; the long-form 8 x 4097 tokens: 4 and 8).  Same-box A/B of the step with the counts of round 1
+# (4, 8): 82.42 -> 81.63 ms; cold-cache sweep of the two GEMMs incl. their partial sums in profiles/r02_sweep_wgrad_splits.txt
+# (out_proj 8 / 9 splits: 123 / 98 us).  AUM_WGRAD_SPLITS="in,out" forces a pair for sweeps.
+_WGRAD_SPLITS = ((6, 4, 8, 2), (9, 8, 4, 2))
+if os.environ.get("AUM_WGRAD_SPLITS"):
+    _WGRAD_SPLITS = tuple((int(v),) for v in os.environ["AUM_WGRAD_SPLITS"].split(","))
+
+
+def _pick_splits(K, prefs):
+    return next((s for s in prefs if K % s == 0 and K // s >= 1024), 1)
+
+
 def split_k_wgrad(a_mk, b_kn, splits, out_dtype=None):
     """a_mk [M, K] @ b_kn [K, N] with a long K (= batch*len tokens) and a small [M, N] result: the weight-gradient GEMMs
     of the in/out projections.  hipBLASLt's best single-GEMM solutions keep the matrix pipe 20-31 % busy on these shapes
@@ -235,7 +248,7 @@ class InProjFn(torch.autograd.Function):
         w, h = ctx.saved_tensors
         dxz2d = dxz2d.to(w.dtype)
         dh = torch.matmul(dxz2d.t(), w) if ctx.needs_input_grad[1] else None
-        dw = split_k_wgrad(dxz2d, h, 4, ctx.wdtype) if ctx.needs_input_grad[0] else None
+        dw = split_k_wgrad(dxz2d, h, _pick_splits(h.shape[0], _WGRAD_SPLITS[0]), ctx.wdtype) if ctx.needs_input_grad[0] else None
         return dw, (None if dh is None else dh.to(ctx.hdtype))
 
 
@@ -340,7 +353,8 @@ def _inner_backward(ctx, dout):
     if ctx.has_out_proj:
         dout2 = dout.reshape(Bsz * L, -1).to(out_proj_weight.dtype)
         dout_z = torch.matmul(out_proj_weight.t(), dout2.t()).reshape(E, Bsz, L).permute(1, 0, 2)   # SSI:540
-        dout_proj_weight = split_k_wgrad(dout2.t(), _dm2d(out_z).t(), 8, ctx.out_proj_wdtype)        # SSI:563
+        dout_proj_weight = split_k_wgrad(dout2.t(), _dm2d(out_z).t(), _pick_splits(dout2.shape[0], _WGRAD_SPLITS[1]),
+                                         ctx.out_proj_wdtype)                                                  # SSI:563
         dout_proj_bias = dout2.sum(0) if not ctx.out_proj_bias_is_None else None
     else:
         dout_z = dout if dout.stride(-1) == 1 else dout.contiguous()
