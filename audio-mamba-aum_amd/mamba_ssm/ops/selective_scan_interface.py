@@ -200,6 +200,46 @@ def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
 # =================================================================================================
 # fused inner blocks  (SSI:155-633)
 # =================================================================================================
+# The token count of an AuM batch is batch * 513 -- never a multiple of a GEMM tile.  The library's kernels launch one workgroup per
+# output tile, so the 64 tokens past 32768 (B = 64) add a whole extra round of workgroups to a 3-7 round GEMM (cold-cache, one
+# box: in_proj forward 175 vs 144 us, out_proj data gradient 138 vs 90 us for 32832 vs 32768 tokens, profiles/
+# r02_sweep_gemm_tokens.txt).  The four big projection GEMMs are therefore issued as a tile-aligned GEMM over the first
+# n0 = 256 * floor(ntok / 256) tokens plus a small one over the remainder, both writing slices of one output.  AUM_GEMM_TOKEN_SPLIT is
+# a bit mask for A/B runs (1 in_proj forward, 2 out_proj forward, 4 out_proj data gradient, 8 in_proj data gradient).  Same-box A/B of the
+# step: mask 0 / 1 / 2 / 4 / 8 / 15 / 13 = 80.06 / 79.67 / 80.10 / 79.53 / 79.63 / 78.97 / 78.87 ms -> default 13 (the out_proj forward
+# loses what it gains to its 17 us remainder GEMM).
+_TOKEN_SPLIT = int(os.environ.get("AUM_GEMM_TOKEN_SPLIT", "13"))
+
+
+def _tok_n0(ntok, bit, t):
+    n0 = ntok // 256 * 256
+    return n0 if (_TOKEN_SPLIT & bit) and t.is_cuda and ntok >= 8192 and 0 < n0 < ntok else 0
+
+
+def _mm_tokens_cols(a, bt, bit):
+    """a [M, K] @ bt[ntok, K]^T -> [M, ntok] (tokens = output columns)"""
+    ntok = bt.shape[0]
+    n0 = _tok_n0(ntok, bit, bt)
+    if not n0:
+        return torch.matmul(a, bt.t())
+    out = torch.empty((a.shape[0], ntok), dtype=a.dtype, device=a.device)
+    torch.matmul(a, bt[:n0].t(), out=out[:, :n0])
+    torch.matmul(a, bt[n0:].t(), out=out[:, n0:])
+    return out
+
+
+def _mm_tokens_rows(at, b, bit):
+    """at[K, ntok]^T @ b [K, N] -> [ntok, N] (tokens = output rows); `at` is the channel-major activation"""
+    ntok = at.shape[1]
+    n0 = _tok_n0(ntok, bit, at)
+    if not n0:
+        return torch.matmul(at.t(), b)
+    out = torch.empty((ntok, b.shape[1]), dtype=at.dtype, device=at.device)
+    torch.matmul(at[:, :n0].t(), b, out=out[:n0])
+    torch.matmul(at[:, n0:].t(), b, out=out[n0:])
+    return out
+
+
 # split-K counts of the in / out projection weight gradients, in order of preference: the first that divides K = batch * len is
 # used (B = 64, L = 513: 6 and 9; the long-form 8 x 4097 tokens: 4 and 8).  Same-box A/B of the step with the counts of round 1
 # (4, 8): 82.42 -> 81.63 ms; cold-cache sweep of the two GEMMs incl. their partial sums in profiles/r02_sweep_wgrad_splits.txt
@@ -241,13 +281,13 @@ class InProjFn(torch.autograd.Function):
         h = hidden2d.to(w.dtype)
         ctx.save_for_backward(w, h)
         ctx.wdtype, ctx.hdtype = weight.dtype, hidden2d.dtype
-        return torch.matmul(w, h.t())
+        return _mm_tokens_cols(w, h, 1)
 
     @staticmethod
     def backward(ctx, dxz2d):
         w, h = ctx.saved_tensors
         dxz2d = dxz2d.to(w.dtype)
-        dh = torch.matmul(dxz2d.t(), w) if ctx.needs_input_grad[1] else None
+        dh = _mm_tokens_rows(dxz2d, w, 8) if ctx.needs_input_grad[1] else None
         dw = split_k_wgrad(dxz2d, h, _pick_splits(h.shape[0], _WGRAD_SPLITS[0]), ctx.wdtype) if ctx.needs_input_grad[0] else None
         return dw, (None if dh is None else dh.to(ctx.hdtype))
 
@@ -333,7 +373,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
                           x_proj_wt, delta_proj_wt)
     if out_proj_weight is None:
         return out_z                                                                          # SSI:224
-    out = torch.matmul(_dm2d(out_z).t(), out_proj_weight.t())                                 # SSI:517
+    out = _mm_tokens_rows(_dm2d(out_z), out_proj_weight.t(), 2)                               # SSI:517
     if out_proj_bias is not None:
         out = out + out_proj_bias
     return out.reshape(Bsz, L, -1)
@@ -352,7 +392,7 @@ def _inner_backward(ctx, dout):
     dout_proj_weight = dout_proj_bias = None
     if ctx.has_out_proj:
         dout2 = dout.reshape(Bsz * L, -1).to(out_proj_weight.dtype)
-        dout_z = torch.matmul(out_proj_weight.t(), dout2.t()).reshape(E, Bsz, L).permute(1, 0, 2)   # SSI:540
+        dout_z = _mm_tokens_cols(out_proj_weight.t(), dout2, 4).reshape(E, Bsz, L).permute(1, 0, 2)   # SSI:540
         dout_proj_weight = split_k_wgrad(dout2.t(), _dm2d(out_z).t(), _pick_splits(dout2.shape[0], _WGRAD_SPLITS[1]),
                                          ctx.out_proj_wdtype)                                                  # SSI:563
         dout_proj_bias = dout2.sum(0) if not ctx.out_proj_bias_is_None else None
