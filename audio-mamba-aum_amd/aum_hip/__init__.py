@@ -139,7 +139,7 @@ class Lib:
         self.c.aum_proj_bwd_weight_splits.argtypes = [_i32, _i64]
         self.c.aum_selftest_wave_scan.argtypes = [_vp, _vp, C.c_int, _vp]
         self.c.aum_hbm_copy.argtypes = [_vp, _vp, _i64, _vp]
-        self.c.aum_sum_rows.argtypes = [_vp, _vp, _i64, _i64, _i32, _vp]
+        self.c.aum_sum_rows.argtypes = [_vp, _vp, _i64, _i64, _i64, _i32, _vp]
         self.c.aum_selective_scan_ckpt_bytes.restype = _i64
         self.c.aum_selective_scan_ckpt_bytes.argtypes = [_i32] * 4
         self.c.aum_selective_scan_lane_ckpt_bytes.restype = _i64
@@ -696,17 +696,21 @@ def selftest_wave_scan(P, S, rev=False, lib=None):
 
 def sum_rows(t, lib=None):
     """t: (outer, ...) contiguous fp32 / bf16 / fp16 -> fp32 sum over dim 0, in a fixed order (aum_sum_rows): the partial results of
-    rmsnorm_bwd / proj_bwd_weight and split-K GEMM partial products.  Shapes the kernel does not take go through torch."""
+    rmsnorm_bwd / proj_bwd_weight and split-K GEMM partial products.  Tall and narrow inputs (the 4096 x 768 norm partials: too few
+    columns for one pass to fill the chip) are summed in two stages, 32 slices first.  Shapes the kernel does not take go through torch."""
     lib = lib or get()
     inner = t[0].numel()
-    # tall and narrow (the 4096 x 768 norm partials): too few columns for this kernel's column-per-thread walk (24 workgroups;
-    # 26.8 vs 21.7 us cold) -- torch's two-stage reduce stays
-    narrow = t.shape[0] >= 1024 and inner < 8192
-    if debug.torch_sums or narrow or t.dtype not in _DT or not t.is_contiguous() or inner % 8 or t.data_ptr() % 16:
+    if debug.torch_sums or t.dtype not in _DT or not t.is_contiguous() or inner % 8 or t.data_ptr() % 16:
         return t.sum(0, dtype=torch.float32)
     lib.check_tensor(t)
-    out = torch.empty(t.shape[1:], dtype=torch.float32, device=t.device)
-    _chk(lib.c.aum_sum_rows(_ptr(t), _ptr(out), t.shape[0], inner, _DT[t.dtype], lib.stream(t)), "aum_sum_rows")
+    outer, shape = t.shape[0], t.shape[1:]
+    stream = lib.stream(t)
+    if outer >= 1024 and inner < 8192 and outer % 32 == 0:
+        mid = torch.empty((32, inner), dtype=torch.float32, device=t.device)
+        _chk(lib.c.aum_sum_rows(_ptr(t), _ptr(mid), 32, outer // 32, inner, _DT[t.dtype], stream), "aum_sum_rows")
+        t, outer = mid, 32
+    out = torch.empty(shape, dtype=torch.float32, device=t.device)
+    _chk(lib.c.aum_sum_rows(_ptr(t), _ptr(out), 1, outer, inner, _DT[t.dtype], stream), "aum_sum_rows")
     return out
 
 

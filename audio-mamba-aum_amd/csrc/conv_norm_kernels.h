@@ -447,6 +447,8 @@ template <class T, int RG> __global__ __launch_bounds__(256) void k_sum_rows(con
     __shared__ float part[RG > 1 ? 256 * 8 : 8];
     const int c = threadIdx.x % CW, rg = threadIdx.x / CW;
     const int64_t col = ((int64_t)blockIdx.x * CW + c) * 8;
+    src += (int64_t)blockIdx.y * outer * inner;        // batch entry
+    dst += (int64_t)blockIdx.y * inner;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (col < inner) {
         int64_t o = rg;

@@ -293,12 +293,12 @@ int aum_selftest_wave_scan(const float* in, float* out, int rev, void* stream);
 int aum_hbm_copy(const void* src, void* dst, int64_t bytes, void* stream);
 
 /*
- * dst[i] = sum over o of src[o][i] in fp32 (ABI 6): the fixed-order sum of the per-workgroup partial results that
+ * dst[b][i] = sum over o of src[b][o][i] in fp32 (ABI 6; batch = 1 for a plain sum, > 1 for the first stage of a two-stage sum): the fixed-order sum of the per-workgroup partial results that
  * aum_rmsnorm_bwd (dweight_partial) and aum_proj_bwd_weight (out) leave to the caller, and of split-K GEMM partial products
- * (SSI:563, 586, 589; the reference leaves the same kind of sum to torch: LN:333-372).  src: (outer, inner) contiguous in
- * src_dtype (AUM_F32 / AUM_BF16 / AUM_F16), dst: (inner) fp32.  inner % 8 == 0, 16-byte aligned pointers.
+ * (SSI:563, 586, 589; the reference leaves the same kind of sum to torch: LN:333-372).  src: (batch, outer, inner) contiguous in
+ * src_dtype (AUM_F32 / AUM_BF16 / AUM_F16), dst: (batch, inner) fp32.  inner % 8 == 0, 16-byte aligned pointers.
  */
-int aum_sum_rows(const void* src, float* dst, int64_t outer, int64_t inner, int32_t src_dtype, void* stream);
+int aum_sum_rows(const void* src, float* dst, int64_t batch, int64_t outer, int64_t inner, int32_t src_dtype, void* stream);
 
 #ifdef __cplusplus
 }

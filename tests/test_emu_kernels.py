@@ -196,7 +196,7 @@ def test_proj_limits(emu):
 def test_sum_rows_emu(emu):
     """aum_sum_rows on the lane-array build: fp32 / bf16 partials, shapes of the three callers (norm partials, projection splits, split-K)"""
     torch.manual_seed(0)
-    for shape, dt in (((37, 768), torch.float32), ((42, 48, 64), torch.float32), ((4, 24, 16), torch.bfloat16), ((3, 7), torch.float32)):
+    for shape, dt in (((1024, 16), torch.float32), ((37, 768), torch.float32), ((42, 48, 64), torch.float32), ((4, 24, 16), torch.bfloat16), ((3, 7), torch.float32)):
         t = torch.randn(shape).to(dt)
         got = aum_hip.sum_rows(t, lib=emu)
         assert got.dtype == torch.float32 and got.shape == t.shape[1:]

@@ -310,7 +310,7 @@ def test_scan_headline_grid_b64(lib):
 def test_sum_rows(lib):
     """aum_sum_rows at the callers' shapes: every launch geometry of the dispatcher, fp32 and 16-bit partials, fixed summation order"""
     torch.manual_seed(0)
-    for shape, dt in (((2048, 768), torch.float32), ((42, 1536, 80), torch.float32), ((42, 48, 1536), torch.float32),
+    for shape, dt in (((4096, 768), torch.float32), ((2048, 768), torch.float32), ((1024, 4, 48), torch.float32), ((42, 1536, 80), torch.float32), ((42, 48, 1536), torch.float32),
                       ((4, 3072, 768), torch.bfloat16), ((8, 768, 1536), torch.bfloat16), ((2, 192, 8), torch.float16), ((5, 40), torch.float32),
                       ((86, 16), torch.float32)):
         t = torch.randn(shape, device="cuda").to(dt)
