@@ -1,3 +1,5 @@
+# The end-of-round measurement run (through gpurun): full GPU suite, smoke(), the default bench under rocprofv3 --kernel-trace --stats
+# (-> profiles/rNN_final_bench_n1.json + rNN_final_bench_kernel_stats.txt via tools/rocpd_stats.py), the micro-benchmark, a plain bench.
 set -x
 export PYTHONPATH=$PWD/audio-mamba-aum_amd:$PYTHONPATH
 mkdir -p gpurun_out/final
