@@ -28,7 +28,7 @@ big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
 base = timeit(lambda: big.zero_())
 w_in = torch.randn(3072, 768, device="cuda").to(bf)
 w_out = torch.randn(768, 1536, device="cuda").to(bf)
-for ntok in (64 * 513, 64 * 512, 64 * 513 - 64, 64):
+for ntok in [int(v) for v in (sys.argv[1:] or ['32832', '32768', '64'])]:
     h = torch.randn(ntok, 768, device="cuda").to(bf)
     y2d = torch.randn(1536, ntok, device="cuda").to(bf)
     dout2 = torch.randn(ntok, 768, device="cuda").to(bf)
