@@ -260,3 +260,24 @@ def test_split_k_weight_gradients_match_single_gemm(dtype, monkeypatch):
     tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
     assert rel_err(gw.double().cpu().numpy(), w.grad.double().cpu().numpy()) < tol
     assert rel_err(gx.double().cpu().numpy(), x.grad.double().cpu().numpy()) < tol
+
+
+@pytest.mark.gpu
+def test_token_aligned_gemm_split_matches_single_gemm():
+    """The big projection GEMMs issued as a tile-aligned GEMM + a remainder GEMM into one output (selective_scan_interface.
+    _mm_tokens_cols / _mm_tokens_rows) against the single GEMM, at the AuM-Base shapes, bf16."""
+    from mamba_ssm.ops import selective_scan_interface as S
+    torch.manual_seed(0)
+    ntok = 64 * 513
+    w = torch.randn(3072, 768, device="cuda").to(torch.bfloat16)
+    h = torch.randn(ntok, 768, device="cuda").to(torch.bfloat16)
+    assert S._tok_n0(ntok, 1, h) == 32768
+    got, ref = S._mm_tokens_cols(w, h, 1), torch.matmul(w, h.t())
+    assert got.shape == ref.shape and got.is_contiguous()
+    assert (got.float() - ref.float()).abs().max() <= 2 ** -7 * ref.float().abs().max()
+    x = torch.randn(3072, ntok, device="cuda").to(torch.bfloat16)
+    got, ref = S._mm_tokens_rows(x, w, 8), torch.matmul(x.t(), w)
+    assert got.shape == ref.shape and got.is_contiguous()
+    assert (got.float() - ref.float()).abs().max() <= 2 ** -7 * ref.float().abs().max()
+    # rows past the split hold the remainder GEMM's result, not stale memory
+    assert torch.isfinite(got[32768:].float()).all() and (got[32768:].float() - ref[32768:].float()).abs().max() <= 2 ** -7 * ref.float().abs().max()

@@ -303,3 +303,18 @@ def test_step_cache_is_the_per_call_arithmetic(monkeypatch):
     assert torch.equal(outs[0][0], outs[1][0])
     for k in outs[0][1]:
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def test_split_counts_and_token_split_rules():
+    """Host-side launch rules of the library GEMMs: split-K counts are the first preference that divides the token count; the token
+    split keeps a tile-aligned first GEMM and only applies to device tensors of a few thousand tokens or more."""
+    from mamba_ssm.ops import selective_scan_interface as S
+    assert S._pick_splits(64 * 513, (6, 4, 8, 2)) == 6 and S._pick_splits(64 * 513, (9, 8, 4, 2)) == 9
+    assert S._pick_splits(8 * 4097, (6, 4, 8, 2)) == 4 and S._pick_splits(8 * 4097, (9, 8, 4, 2)) == 8      # long-form: 2^3 * 17 * 241
+    assert S._pick_splits(2 * 513, (6, 4, 8, 2)) == 1                                                          # too short to split
+    cpu = torch.zeros(1)
+    assert S._tok_n0(64 * 513, 1, cpu) == 0                                                                   # host tensors: one GEMM
+    a, bt = torch.randn(5, 7), torch.randn(9000, 7)
+    assert torch.equal(S._mm_tokens_cols(a, bt, 1), a @ bt.t())
+    at, b = torch.randn(7, 9000), torch.randn(7, 3)
+    assert torch.equal(S._mm_tokens_rows(at, b, 8), at.t() @ b)
