@@ -262,9 +262,9 @@ def main():
         if isinstance(roof.get("valu"), dict) and "valu_busy_frac" in roof["valu"]:
             roof["valu_frac"] = roof["valu"]["valu_busy_frac"]
         if dom.startswith("scan"):
-            roof["note"] = ("VALU-bound kernel (16 states x 2 directions x v_exp_f32 per element, ~6100 vector instructions per "
-                            "513-step row): SQ_ACTIVE_INST_VALU shows the vector ALU 74% (backward) / 77% (forward) busy "
-                            "(profiles/r01_valu_busy.txt), so the HBM fraction is bounded near 0.1 by arithmetic; see DESIGN.md 4.1")
+            roof["note"] = ("VALU-bound kernel (16 states x 2 directions x v_exp_f32 per element, ~6000 vector instructions per "
+                            "513-step row): SQ_ACTIVE_INST_VALU shows the vector ALU 75% (backward) / 81% (forward) busy "
+                            "(profiles/r02_valu_busy.txt), so the HBM fraction is bounded near 0.1 by arithmetic; see DESIGN.md 4.1")
         out = {
             "metric": "clips/sec/node AuM-Base 128x1024 fwd+bwd", "value": round(clips / elapsed, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -3,7 +3,7 @@ set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export PYTHONPATH=$PWD/audio-mamba-aum_amd:$PYTHONPATH
 mkdir -p gpurun_out/pmc_valu
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_valu/run -o pmc -- python tools/kbench.py --only scan > gpurun_out/pmc_valu/run.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_valu/run -o pmc -- python tools/kbench.py --only scan_fwd,scan_bwd > gpurun_out/pmc_valu/run.log 2>&1
 find gpurun_out/pmc_valu/run -name "*counter_collection.csv" -exec cp {} gpurun_out/pmc_valu/valu.csv \;
 python - <<'PY'
 import csv, collections
