@@ -25,6 +25,11 @@ import torch.nn.functional as F
 
 import aum_hip
 
+# Host-side switches (README.md "Switches"), read ONCE at import: a variable set later in a running job changes nothing.
+_STEP_CACHE_ON = os.environ.get("AUM_STEP_CACHE", "1") != "0"
+_WGRAD_SPLIT_ON = os.environ.get("AUM_WGRAD_SPLIT", "1") != "0"
+_REF_DZ_DROP = os.environ.get("AUM_REF_DZ_DROP", "0") == "1"
+
 _custom_fwd = torch.amp.custom_fwd(device_type="cuda")
 _custom_bwd = torch.amp.custom_bwd(device_type="cuda")
 
@@ -47,7 +52,7 @@ _STEP_CACHE = {}
 @contextlib.contextmanager
 def step_cache(mixers, dtype):
     groups, a_logs = {}, []
-    if os.environ.get("AUM_STEP_CACHE", "1") == "0":           # A/B switch: per-call casts, as a block used on its own does
+    if not _STEP_CACHE_ON:                                      # A/B switch: per-call casts, as a block used on its own does
         mixers = []
     for m in mixers:
         for name in ("in_proj", "x_proj", "dt_proj", "out_proj", "x_proj_b", "dt_proj_b"):
@@ -263,7 +268,7 @@ def split_k_wgrad(a_mk, b_kn, splits, out_dtype=None):
     autograd (two cast launches per weight; the reference's autocast GEMM rounds its weight gradient to 16 bits, this one does not)."""
     K = a_mk.shape[1]
     out_dtype = out_dtype or a_mk.dtype
-    if splits <= 1 or K % splits or K // splits < 1024 or os.environ.get("AUM_WGRAD_SPLIT", "1") == "0" or not a_mk.is_cuda:
+    if splits <= 1 or K % splits or K // splits < 1024 or not _WGRAD_SPLIT_ON or not a_mk.is_cuda:
         return torch.matmul(a_mk, b_kn).to(out_dtype)
     kc = K // splits
     a3 = a_mk.unflatten(1, (splits, kc)).permute(1, 0, 2)          # [S, M, kc], strided view
@@ -399,7 +404,7 @@ def _inner_backward(ctx, dout):
     else:
         dout_z = dout if dout.stride(-1) == 1 else dout.contiguous()
         dout_z = dout_z.to(xz.dtype)
-    drop = os.environ.get("AUM_REF_DZ_DROP", "0") == "1" and A_b is not None
+    drop = _REF_DZ_DROP and A_b is not None
     if A_b is None or ctx.bidir_fused:
         g = aum_hip.scan_bwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_z, out_pre, ctx.delta_softplus,
                              ctx.reverse, A_b=A_b, dz_out=dz, dmajor=True, x_ck=ck_f)        # SSI:541-561, one launch
