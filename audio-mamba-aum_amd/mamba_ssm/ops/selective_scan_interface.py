@@ -61,6 +61,7 @@ def step_cache(mixers, dtype):
                 groups.setdefault((name in ("x_proj", "dt_proj", "x_proj_b", "dt_proj_b"), tuple(lin.weight.shape), lin.weight.device),
                                   []).append(lin.weight)
         a_logs += [p for p in (getattr(m, "A_log", None), getattr(m, "A_b_log", None)) if p is not None]
+    mine = []
     with torch.no_grad():
         for (want_t, shape, dev), ps in groups.items():
             bank = torch.empty((len(ps),) + shape, dtype=dtype, device=dev)
@@ -68,6 +69,7 @@ def step_cache(mixers, dtype):
             bank_t = bank.transpose(1, 2).contiguous() if want_t else None
             for i, p in enumerate(ps):
                 _STEP_CACHE[id(p)] = (dtype, bank[i], None if bank_t is None else bank_t[i])
+                mine.append(id(p))
         by_shape = {}
         for p in a_logs:
             by_shape.setdefault((tuple(p.shape), p.device), []).append(p)
@@ -75,10 +77,12 @@ def step_cache(mixers, dtype):
             A = -torch.exp(torch.stack([p.detach().float() for p in ps]))
             for i, p in enumerate(ps):
                 _STEP_CACHE[id(p)] = ("A", A[i], None)
+                mine.append(id(p))
     try:
         yield
     finally:
-        _STEP_CACHE.clear()
+        for k in mine:                      # only this context's entries: another model's forward may be open around this one
+            _STEP_CACHE.pop(k, None)
 
 
 def _cast(w, dtype):
