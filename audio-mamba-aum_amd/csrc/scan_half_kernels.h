@@ -43,11 +43,13 @@ AUM_HOSTDEV int scanh_rows_for(int batch, int dim, int mode) {
     if (r > SCANH_MAX_ROWS) r = SCANH_MAX_ROWS;
     return (int)r;
 }
-// Opt-in tile layout (-DAUM_SCANH_PAIRED=1, off until measured on the GPU): a lane's steps i and 4+i adjacent in the LDS tiles, so
-// the B/C reads and the dB/dC read-add-write move whole vf2 values (ds_read2_b32 / v_pk_add_f32 / ds_write2_b32) and the 12
-// v_mov_b32 per state that re-pair the default layout's (i, i+1) reads disappear ("next (0)").
+// Tile layout: a lane's steps i and 4+i adjacent in the LDS tiles, so the B/C reads and the dB/dC read-add-write move whole vf2
+// values (ds_read2_b32 / ds_write2_b32) and the 12 v_mov_b32 per state that re-pair the (i, i+1) reads of the plain layout
+// disappear.  Round 1 measured it 1.5 % slower (before the batched tile update); on top of the batched update it is 0.5 % (fused
+// bidirectional) / 1.2 % (one direction) faster in three alternating same-box runs, gradients bitwise equal
+// (profiles/r02_ab_paired_batched.txt) -> on.  -DAUM_SCANH_PAIRED=0 restores the plain layout.
 #ifndef AUM_SCANH_PAIRED
-#define AUM_SCANH_PAIRED 0
+#define AUM_SCANH_PAIRED 1
 #endif
 constexpr bool SCANH_PAIRED = AUM_SCANH_PAIRED != 0;
 // Opt-in (-DAUM_SCANH_RMW_BATCH=1): the dB/dC tile update of the fused bidirectional kernel issues all 18 LDS reads, then adds,
