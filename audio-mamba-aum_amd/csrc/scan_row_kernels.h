@@ -41,6 +41,13 @@ AUM_HOSTDEV constexpr int scanr_bwd_nw(int mode) { return mode == 2 ? AUM_SCANR_
 AUM_HOSTDEV constexpr int scanr_bwd_rows(int mode) { return 8 * scanr_bwd_nw(mode); }
 constexpr int SCANR_TACC = 128;                        // floats per wave of the tail dB/dC hand-off area
 constexpr int scanr_fwd_lds_floats() { return 2 * ScanGeo<8, 1>::TILE; }
+// B/C tile layout of the forward: steps i and 4 + i adjacent (scan_tile_slot<true>), so the two halves of a vf2 are one
+// ds_read2_b32 -- the layout the one-row backward uses (AUM_SCANH_PAIRED).  Same-box A/B, three alternating runs: fused
+// bidirectional (training) 0.539 -> 0.522 ms, one direction 0.388 -> 0.373 ms (profiles/r02_ab_fwd_paired.txt).
+#ifndef AUM_SCANR_FWD_PAIRED
+#define AUM_SCANR_FWD_PAIRED 1
+#endif
+constexpr bool SCANR_FWD_PAIRED = AUM_SCANR_FWD_PAIRED != 0;
 // Rows per forward workgroup.  Unlike the one-row backward (scanh_rows_for: one workgroup per CU, so fewer and longer is better) the
 // forward has two workgroups per CU and gains from MORE, shorter ones: one workgroup's tile load and row prologues overlap the
 // other's state loops.  Sweep at B = 64, E = 1536 (fused bidirectional, training): 16 / 32 / 64 / 96 / 192 rows = 0.540 / 0.540 /
@@ -153,15 +160,18 @@ AUM_DEV void scanr_fwd(const AumScanFwdArgs& p, int wg, float* lds, int rows_per
     const T* Csrc = row_ptr<T>(p.C, (int64_t)b * p.C_bs);
 
     AUM_FOR_EACH_WAVE(w, NW) {
-        scanwg_load_tile<T, 8, 1, NW, false>(Bsrc, p.B_ns, N, 0, p.len, Bt, w);
-        scanwg_load_tile<T, 8, 1, NW, false>(Csrc, p.C_ns, N, 0, p.len, Ct, w);
+        scanwg_load_tile<T, 8, 1, NW, SCANR_FWD_PAIRED>(Bsrc, p.B_ns, N, 0, p.len, Bt, w);
+        scanwg_load_tile<T, 8, 1, NW, SCANR_FWD_PAIRED>(Csrc, p.C_ns, N, 0, p.len, Ct, w);
     }
     AUM_WG_BARRIER();
     AUM_FOR_EACH_WAVE(w, NW) {
         const vi lane = lane_id();
         vi pos[4], pos4[4];
         AUM_UNROLL
-        for (int i = 0; i < 4; ++i) { pos[i] = lane * GE::LK + i; pos4[i] = lane * GE::LK + 4 + i; }
+        for (int i = 0; i < 4; ++i) {         // steps i and 4 + i of the lane: adjacent tile words in the paired layout
+            pos[i] = lane * GE::LK + scan_tile_slot<SCANR_FWD_PAIRED>(i);
+            pos4[i] = lane * GE::LK + scan_tile_slot<SCANR_FWD_PAIRED>(4 + i);
+        }
         // tail lanes: lane 16*d + n <-> (direction slot d, state n)
         const vi tn = vmin_i(lane & 15, N - 1);
         const vm tvalid = (lane < 16 * ND) && ((lane & 15) < N);
