@@ -252,3 +252,4 @@ def test_fbank_real_audio_emu():
 @pytest.mark.gpu
 def test_fbank_real_audio_gpu():
     _check_real_audio(aum_hip.get(), "cuda", 320)
+

@@ -281,3 +281,27 @@ def test_token_aligned_gemm_split_matches_single_gemm():
     assert (got.float() - ref.float()).abs().max() <= 2 ** -7 * ref.float().abs().max()
     # rows past the split hold the remainder GEMM's result, not stale memory
     assert torch.isfinite(got[32768:].float()).all() and (got[32768:].float() - ref[32768:].float()).abs().max() <= 2 ** -7 * ref.float().abs().max()
+
+
+@pytest.mark.gpu
+def test_model_forward_from_waveform_matches_spectrogram_input():
+    """AudioMamba.forward(wave, frontend=WaveInput) -- the call the launcher and bench.py make -- against forward(spectrogram) of the
+    same clips under bf16 autocast: same logits up to the 16-bit rounding of the patch GEMM, gradients reach every parameter."""
+    from aum.model import AudioMamba
+    from aum.frontend import FbankTables, WaveInput, prepare_wave
+    torch.manual_seed(0)
+    model = AudioMamba(spectrogram_size=(128, 128), depth=2, embed_dim=192, num_classes=7).to(DEV)
+    tabs = FbankTables(DEV)
+    n = 400 + 127 * 160
+    g = torch.Generator(device="cpu").manual_seed(3)
+    waves = (torch.randn(3, n, generator=g) * 0.1).to(DEV)
+    wave, aug = prepare_wave(waves, torch.tensor([n, n - 3000, n - 123], device=DEV), tabs)
+    fe = WaveInput(tabs, 128, aug=aug)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y_wave = model(wave, frontend=fe)
+        y_spec = model(fe.spectrogram(wave))
+    assert y_wave.shape == y_spec.shape == (3, 7)
+    assert (y_wave.float() - y_spec.float()).abs().max() <= 2e-2 * max(1.0, y_spec.float().abs().max().item())
+    y_wave.float().square().sum().backward()
+    missing = [k for k, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not missing, missing
