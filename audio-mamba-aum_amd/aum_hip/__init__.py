@@ -25,7 +25,7 @@ _ERR = {-1: "AUM_E_NULL", -2: "AUM_E_SHAPE", -3: "AUM_E_DTYPE", -4: "AUM_E_UNSUP
         -6: "AUM_E_LAUNCH"}
 
 _i64, _i32, _u32, _vp, _fp = C.c_int64, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class _Debug:
@@ -70,6 +70,22 @@ class ScanBwdArgs(C.Structure):
                 + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32), ("x_ck", _vp), ("x_lane", _vp)])
 
 
+class ScanTmFwdArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("u", "delta", "z", "B", "C", "A", "A_b", "D", "delta_bias", "out", "out_pre", "ckpt")]
+                + [(n, _i64) for n in ("u_bs", "u_ts", "delta_bs", "delta_ts", "z_bs", "z_ts", "B_bs", "B_ts", "C_bs", "C_ts",
+                                       "out_bs", "out_ts", "pre_bs", "pre_ts")]
+                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32)])
+
+
+class ScanTmBwdArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("u", "delta", "z", "B", "C", "dout", "out_pre", "A", "A_b", "D", "delta_bias", "ckpt", "du",
+                                    "ddelta", "dz", "dA", "dA_b", "dBC", "dD", "ddelta_bias", "workspace")]
+                + [(n, _i64) for n in ("workspace_bytes", "u_bs", "u_ts", "delta_bs", "delta_ts", "z_bs", "z_ts", "B_bs", "B_ts",
+                                       "C_bs", "C_ts", "dout_bs", "dout_ts", "pre_bs", "pre_ts", "du_bs", "du_ts", "ddelta_bs",
+                                       "ddelta_ts", "dz_bs", "dz_ts")]
+                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32)])
+
+
 class ConvArgs(C.Structure):
     _fields_ = ([(n, _vp) for n in ("x", "dy", "weight", "bias", "y", "dx", "dweight", "dbias")]
                 + [(n, _i64) for n in ("x_bs", "x_ds", "y_bs", "y_ds", "dy_bs", "dy_ds", "dx_bs", "dx_ds")]
@@ -112,7 +128,8 @@ class ProjWArgs(C.Structure):
 
 EXPORTS = ["aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
-           "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows"]
+           "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows",
+           "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes"]
 
 
 class Lib:
@@ -132,6 +149,11 @@ class Lib:
         for n in ("aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd",
                   "aum_rmsnorm_fwd", "aum_rmsnorm_bwd"):
             getattr(self.c, n).argtypes = [_vp, _vp]
+        self.c.aum_scan_tm_fwd.argtypes = [_vp, _vp]
+        self.c.aum_scan_tm_bwd.argtypes = [_vp, _vp]
+        self.c.aum_scan_tm_nck.argtypes = [_i32]
+        self.c.aum_scan_tm_workspace_bytes.restype = _i64
+        self.c.aum_scan_tm_workspace_bytes.argtypes = [_i32] * 5
         self.c.aum_fbank_fwd.argtypes = [_vp, _vp]
         self.c.aum_frontend_tokens_fwd.argtypes = [_vp, _vp]
         for n in ("aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight"):
@@ -411,6 +433,72 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, delta_softplus=
     _launch(lib.c.aum_selective_scan_bwd, a, u, lib, "scan_bwd_bidir" if A_b is not None else "scan_bwd",
             (batch, dim, length, dstate, u.element_size(), True))
     return dict(du=du, ddelta=ddelta, dA=dA, dA_b=dA_b, dB=dB, dC=dC, dD=dD, dz=dz, ddelta_bias=dbias)
+
+
+# ---- time-serial scan on token-major activations (aum_scan_tm_*, ABI 7) -------------------------------------------------
+SCAN_TM_CK = 8
+
+
+def scan_tm_supported(dim, dstate):
+    """the limits of aum_scan_tm_fwd / _bwd (include/aum_hip.h); outside them callers use scan_fwd / scan_bwd"""
+    return dstate == 16 and dim % 64 == 0
+
+
+def _tm3(t, name, last):
+    """(batch, len, X) tensor with unit stride along X -> (batch stride, token stride) in elements"""
+    if t.dim() != 3 or t.shape[2] != last or (t.stride(2) != 1 and last != 1):
+        raise RuntimeError(f"{name}: expected (batch, len, {last}) with the last axis contiguous (token-major)")
+    return t.stride(0), t.stride(1)
+
+
+def scan_tm_ckpt(batch, length, dim, dstate, bidir, device, lib=None):
+    """empty state checkpoint (directions, batch, nck, dstate, dim) fp32 for scan_tm_fwd to fill and scan_tm_bwd to read"""
+    lib = lib or get()
+    nck = int(lib.c.aum_scan_tm_nck(length))
+    return torch.empty((2 if bidir else 1, batch, max(nck, 1), dstate, dim), dtype=torch.float32, device=device)
+
+
+def scan_tm_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, reverse=False, A_b=None,
+                want_out_pre=False, ckpt=None, out=None, lib=None):
+    """Selective scan forward on token-major tensors: u, delta, z (batch, len, dim) with channels contiguous (row strides free: z
+    may be a slice of an xz tensor); B, C (batch, len, dstate) in u's dtype.  A_b != None: both directions (Fo-Bi).
+    Returns (out, out_pre|None), both (batch, len, dim) contiguous."""
+    lib = lib or get()
+    batch, length, dim = u.shape
+    dstate = A.shape[1]
+    for t in (u, delta, z, B, C):
+        lib.check_tensor(t)
+    if u.dtype not in _DT or delta.dtype != u.dtype or (z is not None and z.dtype != u.dtype):
+        raise RuntimeError("u, delta, z must share one dtype in {fp32, bf16, fp16}")
+    if B.dtype != u.dtype or C.dtype != u.dtype:
+        raise RuntimeError("B, C must have u's dtype")
+    A, A_b, D, delta_bias = _f32c(A), _f32c(A_b), _f32c(D), _f32c(delta_bias)
+    a = ScanTmFwdArgs()
+    a.u_bs, a.u_ts = _tm3(u, "u", dim)
+    a.delta_bs, a.delta_ts = _tm3(delta, "delta", dim)
+    if z is not None:
+        a.z_bs, a.z_ts = _tm3(z, "z", dim)
+    a.B_bs, a.B_ts = _tm3(B, "B", dstate)
+    a.C_bs, a.C_ts = _tm3(C, "C", dstate)
+    if out is None:
+        out = torch.empty((batch, length, dim), dtype=u.dtype, device=u.device)
+    out_pre = torch.empty((batch, length, dim), dtype=u.dtype, device=u.device) if want_out_pre else None
+    a.out_bs, a.out_ts = _tm3(out, "out", dim)
+    if out_pre is not None:
+        a.pre_bs, a.pre_ts = _tm3(out_pre, "out_pre", dim)
+    a.u, a.delta, a.z, a.B, a.C = _ptr(u), _ptr(delta), _ptr(z), _ptr(B), _ptr(C)
+    a.A, a.A_b, a.D, a.delta_bias = _ptr(A), _ptr(A_b), _ptr(D), _ptr(delta_bias)
+    a.out, a.out_pre = _ptr(out), _ptr(out_pre)
+    if ckpt is not None:
+        assert ckpt.dtype == torch.float32 and ckpt.is_contiguous()
+        assert ckpt.shape == (2 if A_b is not None else 1, batch, max(int(lib.c.aum_scan_tm_nck(length)), 1), dstate, dim)
+        lib.check_tensor(ckpt)
+        a.ckpt = _ptr(ckpt)
+    a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
+    a.flags = (SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0)
+    _launch(lib.c.aum_scan_tm_fwd, a, u, lib, "scan_tm_fwd_bidir" if A_b is not None else "scan_tm_fwd",
+            (batch, dim, length, dstate, u.element_size(), want_out_pre))
+    return out, out_pre
 
 
 def conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, dmajor=False, generic=False, lib=None):

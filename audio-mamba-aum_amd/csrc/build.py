@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT_DIR = os.path.join(os.path.dirname(HERE), "aum_hip")
 OBJ_DIR = os.path.join(HERE, "_obj")
 SRC = os.path.join(HERE, "aum_hip.hip")
-DEPS = ["aum_hip.hip", "aum_api.inc", "wave.h", "scan_kernels.h", "scan_wg_kernels.h", "scan_half_kernels.h", "scan_row_kernels.h", "scan_state_kernels.h", "fbank_kernels.h", "frontend_kernels.h", "proj_kernels.h", "conv_rows_kernels.h", "conv_norm_kernels.h",
+DEPS = ["aum_hip.hip", "aum_api.inc", "wave.h", "scan_kernels.h", "scan_wg_kernels.h", "scan_half_kernels.h", "scan_row_kernels.h", "scan_state_kernels.h", "fbank_kernels.h", "frontend_kernels.h", "proj_kernels.h", "conv_rows_kernels.h", "conv_norm_kernels.h", "scan_tm_kernels.h", "aum_api_tm.inc",
         os.path.join("..", "..", "include", "aum_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
@@ -32,6 +32,9 @@ def parts():
     for part in (1, 2):
         for dt in (0, 1, 2):
             out.append((f"scan_p{part}_d{dt}.o", [f"-DAUM_API_PART={part}", f"-DAUM_DTYPE_ONLY={dt}"]))
+    for part in (5, 6):
+        for dt in (0, 1, 2):
+            out.append((f"scantm_p{part}_d{dt}.o", [f"-DAUM_API_PART={part}", f"-DAUM_DTYPE_ONLY={dt}"]))
     for dt in (1, 2):
         out.append((f"proj_d{dt}.o", ["-DAUM_API_PART=4", f"-DAUM_DTYPE_ONLY={dt}"]))
     out.append(("api.o", ["-DAUM_API_PART=3"]))
@@ -55,7 +58,7 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         return name, r.returncode, r.stdout + r.stderr
 
-    with cf.ThreadPoolExecutor(max_workers=min(10, os.cpu_count() or 4)) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:
         res = list(ex.map(cc, parts()))
     for name, rc, log in res:
         if rc != 0:

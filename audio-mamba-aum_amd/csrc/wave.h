@@ -88,6 +88,10 @@ AUM_DEV int wave_in_wg() { return __builtin_amdgcn_readfirstlane((int)(threadIdx
 #define AUM_WG_BARRIER_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 // compiler scheduling fence (no instruction): keeps what was issued before it ahead of what follows
 #define AUM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// wait for every outstanding scalar-cache (and LDS) request of this wave.  Scalar loads return out of order, so the only count
+// the hardware can wait for is zero: a wave that prefetches row s+1 while it still has to wait for row s waits for both.  Placing
+// this BEFORE the next prefetch is issued makes the wait cover only requests that have had a whole step to arrive.
+#define AUM_WAIT_SCALAR_LOADS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // Per-wave state that must survive from one phase to the next (registers on the device): declare `T name[AUM_PER_WAVE(NW)]...`
 // and index it with AUM_W(w).  One slot on the device; the lane-array build keeps a slot per wave it steps through.
 #define AUM_PER_WAVE(NW) 1
@@ -240,6 +244,144 @@ template <class T> AUM_DEV float gload_s(const T* p, int idx) { return elem_to_f
 // a value the optimiser must treat as unknown at this point: address arithmetic that depends on it is not hoisted out of
 // the enclosing loop (where it would occupy registers for the whole loop)
 AUM_DEV vi opaque_i(vi x) { asm volatile("" : "+v"(x)); return x; }
+// a wave-uniform pointer pinned to an SGPR pair: what is added to it afterwards (a 32-bit per-lane offset) stays the `voffset` of a
+// `global_* v, voffset, s[base]` access -- without the pin the optimiser folds the uniform part into a 64-bit per-lane address
+// (v_lshl_add_u64 per access)
+template <class P> AUM_DEV P* uniform_ptr(P* p) { asm volatile("" : "+s"(p)); return p; }
+// accesses through a pinned pointer: the pin hides where the pointer came from, so the global address space is stated here
+// (a generic pointer would make these flat_load / flat_store with 64-bit per-lane addresses)
+template <class T> AUM_DEV vf gload_g(const T* p, vi idx) {
+    if constexpr (sizeof(T) == 4) {
+        return ((const __attribute__((address_space(1))) float*)p)[(uint32_t)idx];
+    } else {
+        T e;
+        e.bits = ((const __attribute__((address_space(1))) uint16_t*)p)[(uint32_t)idx];
+        return elem_to_f32(e);
+    }
+}
+template <class T> AUM_DEV void gstore_g(T* p, vi idx, vf v) {
+    if constexpr (sizeof(T) == 4) {
+        ((__attribute__((address_space(1))) float*)p)[(uint32_t)idx] = v;
+    } else {
+        auto* q = (__attribute__((address_space(1))) uint16_t*)p;
+        if constexpr (__is_same(T, bf16_t)) q[(uint32_t)idx] = (uint16_t)f32x2_to_elem2<T>(v, v);
+        else { T e; f32_to_elem(v, e); q[(uint32_t)idx] = e.bits; }
+    }
+}
+// Buffer-resource accesses (buffer_load/store ... offen): address = descriptor base + per-lane byte offset (VGPR, constant over a
+// kernel's row walk) + wave-uniform byte offset (SGPR, one s_add per step).  No 64-bit address arithmetic on either ALU.
+template <class T> struct gbuf { __amdgpu_buffer_rsrc_t r; };
+template <class T> AUM_DEV gbuf<T> make_gbuf(const T* p) {
+    gbuf<T> b;
+    b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p), 0, 0x7fffffff, 0x00020000);
+    return b;
+}
+template <class T> AUM_DEV vf gbuf_load(const gbuf<T>& b, vi voff_bytes, int soff_bytes) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff_bytes, soff_bytes, 0));
+    } else {
+        T e;
+        e.bits = __builtin_amdgcn_raw_buffer_load_b16(b.r, voff_bytes, soff_bytes, 0);
+        return elem_to_f32(e);
+    }
+}
+// the same access with the element left as it was loaded (its bits in the low end of a register): a prefetch whose widening --
+// and with it the s_waitcnt -- is written where the value is used, not where the load is issued
+template <class T> AUM_DEV vi gbuf_load_raw(const gbuf<T>& b, vi voff_bytes, int soff_bytes) {
+    if constexpr (sizeof(T) == 4) return (int)__builtin_amdgcn_raw_buffer_load_b32(b.r, voff_bytes, soff_bytes, 0);
+    else return (int)__builtin_amdgcn_raw_buffer_load_b16(b.r, voff_bytes, soff_bytes, 0);
+}
+template <class T> AUM_DEV vf raw_to_f32(vi raw) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(float, raw);
+    } else {
+        T e;
+        e.bits = (uint16_t)raw;
+        return elem_to_f32(e);
+    }
+}
+template <class T> AUM_DEV void gbuf_store(const gbuf<T>& b, vi voff_bytes, int soff_bytes, vf v) {
+    if constexpr (sizeof(T) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), b.r, voff_bytes, soff_bytes, 0);
+    } else if constexpr (__is_same(T, bf16_t)) {
+        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)f32x2_to_elem2<T>(v, v), b.r, voff_bytes, soff_bytes, 0);
+    } else {
+        T e;
+        f32_to_elem(v, e);
+        __builtin_amdgcn_raw_buffer_store_b16(e.bits, b.r, voff_bytes, soff_bytes, 0);
+    }
+}
+typedef float aum_f2 __attribute__((ext_vector_type(2)));
+typedef float aum_f4 __attribute__((ext_vector_type(4)));
+// two consecutive elements of a row as fp32 (one dword for the 16-bit types, one dwordx2 for float)
+template <class T> AUM_DEV void gbuf_load_pair(const gbuf<T>& b, vi voff_bytes, int soff_bytes, vf& lo, vf& hi) {
+    if constexpr (sizeof(T) == 4) {
+        const auto w = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff_bytes, soff_bytes, 0);
+        static_assert(sizeof(w) == 8, "dwordx2");
+        const aum_f2 f = __builtin_bit_cast(aum_f2, w);
+        lo = f.x;
+        hi = f.y;
+    } else {
+        const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(b.r, voff_bytes, soff_bytes, 0);
+        if constexpr (__is_same(T, bf16_t)) {
+            lo = bits_to_f32(w << 16);
+            hi = bits_to_f32(w & 0xffff0000u);
+        } else {
+            lo = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
+            hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+        }
+    }
+}
+// LDS: a pair per lane (ds_write_b64; idx even) and four consecutive words read by every lane from ONE wave-uniform index
+// (ds_read_b128, all lanes the same address: a broadcast)
+AUM_DEV void lds_write2(float* lds, vi idx, vf a, vf b) { *reinterpret_cast<aum_f2*>(lds + idx) = aum_f2{a, b}; }
+AUM_DEV void lds_read4_u(const float* lds, int idx, vf (&o)[4]) {
+    const aum_f4 v = *reinterpret_cast<const aum_f4*>(lds + idx);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+// 16 bytes per lane: global <-> registers (buffer_load/store_dwordx4 ... offen) and registers <-> LDS (ds_write/read_b128), and one
+// element of T per lane out of / into an LDS tile (ds_read_u16 / ds_read_b32, ds_write_b16 / ds_write_b32).  Byte offsets.
+struct vq { vi w[4]; };
+template <class T> AUM_DEV vq gbuf_load16(const gbuf<T>& b, vi voff_bytes, int soff_bytes) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const auto r = __builtin_amdgcn_raw_buffer_load_b128(b.r, voff_bytes, soff_bytes, 0);
+    static_assert(sizeof(r) == 16, "dwordx4");
+    const u4 u = __builtin_bit_cast(u4, r);
+    vq q;
+    q.w[0] = (int)u.x; q.w[1] = (int)u.y; q.w[2] = (int)u.z; q.w[3] = (int)u.w;
+    return q;
+}
+template <class T> AUM_DEV void gbuf_store16(const gbuf<T>& b, vi voff_bytes, int soff_bytes, const vq& q) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 u = {(uint32_t)q.w[0], (uint32_t)q.w[1], (uint32_t)q.w[2], (uint32_t)q.w[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(b.r, 0, 0, 0)), u), b.r, voff_bytes,
+                                           soff_bytes, 0);
+}
+AUM_DEV void lds_write16(float* lds, vi byte_off, const vq& q) {
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<i4*>(reinterpret_cast<char*>(lds) + byte_off) = i4{q.w[0], q.w[1], q.w[2], q.w[3]};
+}
+AUM_DEV vq lds_read16(const float* lds, vi byte_off) {
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    const i4 v = *reinterpret_cast<const i4*>(reinterpret_cast<const char*>(lds) + byte_off);
+    vq q;
+    q.w[0] = v.x; q.w[1] = v.y; q.w[2] = v.z; q.w[3] = v.w;
+    return q;
+}
+template <class T> AUM_DEV vi lds_read_raw(const float* lds, vi byte_off) {
+    if constexpr (sizeof(T) == 4) return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(lds) + byte_off);
+    else return (int)*reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(lds) + byte_off);
+}
+template <class T> AUM_DEV void lds_write_elem(float* lds, vi byte_off, vf v) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + byte_off) = v;
+    } else {
+        uint16_t bits;
+        if constexpr (__is_same(T, bf16_t)) bits = (uint16_t)f32x2_to_elem2<T>(v, v);
+        else { T e; f32_to_elem(v, e); bits = e.bits; }
+        *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(lds) + byte_off) = bits;
+    }
+}
 #define AUM_LDS(type, name, count) __shared__ type name[count]
 
 #else
@@ -345,6 +487,7 @@ inline void lds_atomic_add(float* lds, const vi& idx, const vf& v) { AUM_LANES l
 #define AUM_WG_BARRIER_IN_PHASE() do { } while (0)
 #define AUM_WG_BARRIER_LDS() do { } while (0)
 #define AUM_SCHED_FENCE() do { } while (0)
+#define AUM_WAIT_SCALAR_LOADS() do { } while (0)
 #define AUM_PER_WAVE(NW) (NW)
 #define AUM_W(w) (w)
 inline void wave_sync() {}
@@ -368,8 +511,150 @@ inline float readlane(const vf& x, int lane) { return x.v[lane]; }
 inline vf writelane(const vf& v, float s, int lane) { vf r = v; r.v[lane] = s; return r; }
 template <class T> inline float gload_s(const T* p, int idx) { return elem_to_f32(p[idx]); }
 inline vi opaque_i(const vi& x) { return x; }
+template <class P> inline P* uniform_ptr(P* p) { return p; }
+template <class T> inline vf gload_g(const T* p, const vi& idx) { return gload_u(p, idx); }
+template <class T> inline void gstore_g(T* p, const vi& idx, const vf& v) { AUM_LANES f32_to_elem(v.v[l], p[idx.v[l]]); }
+template <class T> struct gbuf { T* p; };
+template <class T> inline gbuf<T> make_gbuf(const T* p) { return gbuf<T>{const_cast<T*>(p)}; }
+template <class T> inline vf gbuf_load(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes) {
+    vf r; AUM_LANES r.v[l] = elem_to_f32(*(const T*)((const char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes)); return r;
+}
+template <class T> inline vi gbuf_load_raw(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes) {
+    vi r;
+    AUM_LANES {
+        const T* q = (const T*)((const char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes);
+        if constexpr (sizeof(T) == 4) std::memcpy(&r.v[l], q, 4);
+        else r.v[l] = (int)q->bits;
+    }
+    return r;
+}
+template <class T> inline vf raw_to_f32(const vi& raw) {
+    vf r;
+    AUM_LANES {
+        if constexpr (sizeof(T) == 4) std::memcpy(&r.v[l], &raw.v[l], 4);
+        else { T e; e.bits = (uint16_t)raw.v[l]; r.v[l] = elem_to_f32(e); }
+    }
+    return r;
+}
+template <class T> inline void gbuf_store(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes, const vf& v) {
+    AUM_LANES f32_to_elem(v.v[l], *(T*)((char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes));
+}
+template <class T> inline void gbuf_load_pair(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes, vf& lo, vf& hi) {
+    AUM_LANES {
+        const T* q = (const T*)((const char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes);
+        lo.v[l] = elem_to_f32(q[0]);
+        hi.v[l] = elem_to_f32(q[1]);
+    }
+}
+inline void lds_write2(float* lds, const vi& idx, const vf& a, const vf& b) { AUM_LANES { lds[idx.v[l]] = a.v[l]; lds[idx.v[l] + 1] = b.v[l]; } }
+inline void lds_read4_u(const float* lds, int idx, vf (&o)[4]) { for (int k = 0; k < 4; ++k) o[k] = splat(lds[idx + k]); }
+struct vq { vi w[4]; };
+template <class T> inline vq gbuf_load16(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes) {
+    vq q;
+    AUM_LANES {
+        int t[4];
+        std::memcpy(t, (const char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes, 16);
+        for (int k = 0; k < 4; ++k) q.w[k].v[l] = t[k];
+    }
+    return q;
+}
+template <class T> inline void gbuf_store16(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes, const vq& q) {
+    AUM_LANES {
+        int t[4];
+        for (int k = 0; k < 4; ++k) t[k] = q.w[k].v[l];
+        std::memcpy((char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes, t, 16);
+    }
+}
+inline void lds_write16(float* lds, const vi& byte_off, const vq& q) {
+    AUM_LANES {
+        int t[4];
+        for (int k = 0; k < 4; ++k) t[k] = q.w[k].v[l];
+        std::memcpy((char*)lds + byte_off.v[l], t, 16);
+    }
+}
+inline vq lds_read16(const float* lds, const vi& byte_off) {
+    vq q;
+    AUM_LANES {
+        int t[4];
+        std::memcpy(t, (const char*)lds + byte_off.v[l], 16);
+        for (int k = 0; k < 4; ++k) q.w[k].v[l] = t[k];
+    }
+    return q;
+}
+template <class T> inline vi lds_read_raw(const float* lds, const vi& byte_off) {
+    vi r;
+    AUM_LANES {
+        const char* q = (const char*)lds + byte_off.v[l];
+        if constexpr (sizeof(T) == 4) std::memcpy(&r.v[l], q, 4);
+        else { uint16_t h; std::memcpy(&h, q, 2); r.v[l] = (int)h; }
+    }
+    return r;
+}
+template <class T> inline void lds_write_elem(float* lds, const vi& byte_off, const vf& v) {
+    AUM_LANES {
+        T e;
+        f32_to_elem(v.v[l], e);
+        std::memcpy((char*)lds + byte_off.v[l], &e, sizeof(T));
+    }
+}
 #define AUM_LDS(type, name, count) type name[count]
 #endif  // AUM_EMU
+
+// ------------------------------------------------------------------------------------------------
+// Wave-uniform loads through the scalar cache (s_load_dword*): the row is the same for all 64 lanes, so its values live in
+// SGPRs and enter VALU instructions as scalar operands -- no vector registers, no LDS.  On the device the pointer is re-typed to
+// the constant address space, which is what lets the compiler select SMEM for memory the kernel does not write (a plain global
+// load of a uniform address stays a vector load: the kernel's own stores might alias it).  Rows must be 4-byte aligned.
+// ------------------------------------------------------------------------------------------------
+#ifndef AUM_EMU
+typedef const __attribute__((address_space(4))) uint32_t* aum_cptr32;
+AUM_DEV uint32_t sload_u32(const void* row, int dword) { return ((aum_cptr32)(uintptr_t)row)[dword]; }
+#else
+inline uint32_t sload_u32(const void* row, int dword) {
+    uint32_t v;
+    std::memcpy(&v, (const char*)row + 4 * (size_t)dword, 4);
+    return v;
+}
+#endif
+// dword `dword` of the wave-uniform row at byte offset `row_bytes` (a multiple of 4) from `base`: s_load_dword* sdst, s[base], soffset
+#ifndef AUM_EMU
+AUM_DEV uint32_t sload_u32_at(const void* base, int row_bytes, int dword) {
+    return *(aum_cptr32)((uintptr_t)base + (uint32_t)row_bytes + 4u * (uint32_t)dword);
+}
+#else
+inline uint32_t sload_u32_at(const void* base, int row_bytes, int dword) {
+    uint32_t v;
+    std::memcpy(&v, (const char*)base + row_bytes + 4 * (size_t)dword, 4);
+    return v;
+}
+#endif
+// elements 2j and 2j+1 of a wave-uniform row of T
+AUM_DEV void sload_pair(const float* row, int j, float& a, float& b) {
+    a = bits_to_f32(sload_u32(row, 2 * j));
+    b = bits_to_f32(sload_u32(row, 2 * j + 1));
+}
+AUM_DEV void sload_pair(const bf16_t* row, int j, float& a, float& b) {
+    const uint32_t w = sload_u32(row, j);
+    a = bits_to_f32(w << 16);
+    b = bits_to_f32(w & 0xffff0000u);
+}
+AUM_DEV void sload_pair(const f16_t* row, int j, float& a, float& b) {
+    const uint32_t w = sload_u32(row, j);
+    a = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
+    b = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+}
+
+// one element per lane, converted with the packed hardware conversion where there is one (bf16: v_cvt_pk_bf16_f32, same
+// rounding as f32_to_elem)
+template <class T> AUM_DEV void gstore1(T* p, vi idx, vf v, vm m) {
+#ifndef AUM_EMU
+    if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t)) {
+        if (m) p[(uint32_t)idx].bits = (uint16_t)f32x2_to_elem2<T>(v, v);
+        return;
+    }
+#endif
+    gstore(p, idx, v, m);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Backend-independent helpers built from the primitives above.

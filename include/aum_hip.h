@@ -27,11 +27,12 @@
 extern "C" {
 #endif
 
-#define AUM_ABI_VERSION 6   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
+#define AUM_ABI_VERSION 7   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
                                3: x_lane (lane-entry state checkpoint of the L = 513 row kernels) appended after it;
                                4: aug / noise (per-clip augmentation in the log-mel kernel's epilogue) appended to AumFbankArgs;
                                5: aum_frontend_tokens_fwd (waveform -> token sequence in one launch);
-                               6: aum_sum_rows (fixed-order sum of partial results) */
+                               6: aum_sum_rows (fixed-order sum of partial results);
+                               7: aum_scan_tm_fwd / _bwd (time-serial selective scan on token-major activations) */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 
@@ -284,6 +285,60 @@ typedef struct AumProjWArgs {
 } AumProjWArgs;
 int aum_proj_bwd_weight(const AumProjWArgs* args, void* stream);
 int aum_proj_bwd_weight_splits(int32_t dim, int64_t ntok);
+
+/*
+ * Selective scan on TOKEN-MAJOR activations, time-serial (ABI 7).  Same arithmetic as aum_selective_scan_fwd/_bwd
+ * (selective_scan_cuda.fwd / .bwd, SSI:37, 62-65, 499-507, 541-561; oracle selective_scan_ref SSI:86-152), different division of the
+ * work: a wavefront owns 64 CHANNELS of one batch entry and walks the sequence step by step with the 16 states of every channel in
+ * registers; B_t / C_t are wave-uniform and come through the scalar cache.  No associative scan, no LDS tiles, any length.
+ *   u, delta, z, out, out_pre, dout, du, ddelta, dz : element (b, t, e) at  b * X_bs + t * X_ts + e   (channels contiguous -- the
+ *       natural output of F.linear; z / dz may be the second half of an xz row: pass the offset pointer and X_ts = 2 * dim)
+ *   B, C : element (b, t, n) at  b * X_bs + t * X_ts + n, same dtype; rows 4-byte aligned (even strides / offsets for 16-bit dtypes)
+ *   A, A_b : (dim, dstate) fp32;  D, delta_bias : (dim) fp32 or NULL
+ * A_b != NULL: both directions in one launch (BiMambaInnerFn, SSI:499-507): out = gate * (y_fwd + y_rev + 2 D u); the two
+ * direction waves of a channel group meet in the middle of the sequence and exchange their halves through `out`.
+ * AUM_SCAN_REVERSE (A_b == NULL): the recurrence runs from t = len-1 down to 0.
+ * ckpt (optional, forward output / backward input): the state entering every AUM_SCAN_TM_CK-step block in scan order,
+ *   (directions, batch, nck, dstate, dim) fp32 with nck = aum_scan_tm_nck(len) -- the `x` tensor of selective_scan_cuda.fwd at this
+ *   kernel's granularity.  The backward requires it.
+ * Limits: dstate == 16, dim % 64 == 0, len * X_ts * sizeof(element) < 2^31 for every tensor; otherwise AUM_E_UNSUPPORTED (callers
+ * use aum_selective_scan_*).
+ */
+#define AUM_SCAN_TM_CK 8
+typedef struct AumScanTmFwdArgs {
+    const void *u, *delta, *z, *B, *C;
+    const float *A, *A_b, *D, *delta_bias;
+    void *out, *out_pre;
+    float *ckpt;
+    int64_t u_bs, u_ts, delta_bs, delta_ts, z_bs, z_ts, B_bs, B_ts, C_bs, C_ts, out_bs, out_ts, pre_bs, pre_ts;
+    int32_t batch, dim, len, dstate;
+    int32_t dtype;
+    uint32_t flags;
+} AumScanTmFwdArgs;
+int aum_scan_tm_fwd(const AumScanTmFwdArgs* args, void* stream);
+int32_t aum_scan_tm_nck(int32_t len);
+
+/*
+ * Backward of the above.  du, ddelta, dz in `dtype` (written).  dBC: (batch, len, 2 * dstate) fp32 = dB | dC per token, written
+ * (the sum over the channel-group partials the kernel leaves in `workspace`).  dA, dA_b (dim, dstate), dD, ddelta_bias (dim): fp32,
+ * written.  out_pre: the pre-gate sum saved by the forward (required with z).  workspace: aum_scan_tm_workspace_bytes(...) bytes.
+ */
+typedef struct AumScanTmBwdArgs {
+    const void *u, *delta, *z, *B, *C, *dout, *out_pre;
+    const float *A, *A_b, *D, *delta_bias;
+    const float *ckpt;
+    void *du, *ddelta, *dz;
+    float *dA, *dA_b, *dBC, *dD, *ddelta_bias;
+    void *workspace;
+    int64_t workspace_bytes;
+    int64_t u_bs, u_ts, delta_bs, delta_ts, z_bs, z_ts, B_bs, B_ts, C_bs, C_ts, dout_bs, dout_ts, pre_bs, pre_ts;
+    int64_t du_bs, du_ts, ddelta_bs, ddelta_ts, dz_bs, dz_ts;
+    int32_t batch, dim, len, dstate;
+    int32_t dtype;
+    uint32_t flags;
+} AumScanTmBwdArgs;
+int aum_scan_tm_bwd(const AumScanTmBwdArgs* args, void* stream);
+int64_t aum_scan_tm_workspace_bytes(int32_t batch, int32_t dim, int32_t len, int32_t dstate, int32_t bidirectional);
 
 /* Self-tests and calibration (used by tests/ and bench.py; not part of the reference's surface). */
 int aum_abi_version(void);

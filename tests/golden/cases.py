@@ -43,6 +43,22 @@ SCAN_LONG_CASES = [
     ("l1537_d3", 1, 3, 1537, 16, True, True, True, True),
 ]
 
+# time-serial token-major scan (scan_tm_kernels.h: lanes = channels, dim % 64 == 0, dstate 16): lengths around the 8-step block /
+# 4-step prefetch group boundaries, an even and an odd meeting point of the direction pair, two channel groups; live oracle only
+SCAN_TM_CASES = [
+    ("tm_l1", 2, 64, 1, 16, True, True, True, True),
+    ("tm_l2", 1, 64, 2, 16, True, True, True, True),
+    ("tm_l7", 1, 64, 7, 16, True, True, True, True),
+    ("tm_l8", 2, 64, 8, 16, True, True, True, True),
+    ("tm_l9", 1, 64, 9, 16, True, True, True, True),
+    ("tm_l25", 1, 128, 25, 16, True, True, True, True),
+    ("tm_l40_plain", 2, 64, 40, 16, False, False, False, False),
+    ("tm_l65_noz", 1, 64, 65, 16, False, True, True, True),
+    ("tm_l66_nod", 1, 64, 66, 16, True, False, False, True),
+    ("tm_l130", 2, 128, 130, 16, True, True, True, True),
+    ("tm_l513", 1, 64, 513, 16, True, True, True, True),
+]
+
 # (name, batch, dim, len, width, has_bias)
 CONV_CASES = [
     ("l1", 2, 8, 1, 4, True),

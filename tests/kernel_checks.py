@@ -216,3 +216,59 @@ def check_scan_accumulate(lib, dev, case, dtype=torch.float32, tol=None):
     assert not bad, (name, str(dtype), bad)
     return errs
 
+
+
+def check_scan_tm(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, tol=None, xz_layout=False, backward=True):
+    """aum_scan_tm_fwd / _bwd (time-serial scan on token-major activations) against the fp64 oracle on the same seeded inputs as the
+    channel-major kernels.  xz_layout: u and z are the two
+    halves of one (batch, len, 2 dim) tensor (row stride 2 dim), as in_proj leaves them."""
+    name, batch, dim, length, dstate, has_z, has_D, has_bias, softplus = case
+    d = cases.scan_inputs(*case)
+    tol = tol or (TOL_F32 if dtype == torch.float32 else TOL_BF16)
+    q = {k: rq(d[k], dtype) for k in ("u", "delta", "z", "B", "C", "dout")}
+    rng = np.random.default_rng(7)
+    A_b = (d["A"] * np.exp(rng.normal(0, 0.1, d["A"].shape))).astype(np.float32) if bidir else None
+    tm = lambda a: None if a is None else T(a, dev, dtype).transpose(1, 2).contiguous()      # (batch, len, X)
+    u, delta, z, dout = tm(d["u"]), tm(d["delta"]), tm(d["z"]), tm(d["dout"])
+    if xz_layout and z is not None:
+        xz = torch.cat([u, z], dim=2).contiguous()
+        u, z = xz[:, :, :dim], xz[:, :, dim:]
+    Bm, Cm = tm(d["B"]), tm(d["C"])
+    bcm = torch.cat([Bm, Cm], dim=2).contiguous()       # one (batch, len, 2N) row like x_dbl's B | C columns
+    Bm, Cm = bcm[:, :, :dstate], bcm[:, :, dstate:]
+    A, D, bias = T(d["A"], dev), T(d["D"], dev), T(d["delta_bias"], dev)
+    ck = aum_hip.scan_tm_ckpt(batch, length, dim, dstate, bidir, dev, lib=lib) if backward else None
+    if ck is not None:
+        ck.fill_(float("nan"))
+    out, out_pre = aum_hip.scan_tm_fwd(u, delta, A, Bm, Cm, D, z, bias, softplus, reverse, T(A_b, dev), want_out_pre=True, ckpt=ck,
+                                       lib=lib)
+    ref = O.scan_fwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], softplus, reverse, "f64")
+    ref_out, ref_pre = ref["out"], ref["y_pre"]
+    if bidir:
+        rb = O.scan_fwd(q["u"], q["delta"], A_b, q["B"], q["C"], d["D"], q["z"], d["delta_bias"], softplus, True, "f64")
+        ref_out, ref_pre = ref_out + rb["out"], ref_pre + rb["y_pre"]
+    cm = lambda t: N(t).transpose(0, 2, 1)
+    errs = {"out": rel_err(cm(out), ref_out), "out_pre": rel_err(cm(out_pre), ref_pre)}
+    out2, none = aum_hip.scan_tm_fwd(u, delta, A, Bm, Cm, D, z, bias, softplus, reverse, T(A_b, dev), lib=lib)    # inference form
+    assert none is None
+    errs["out_nopre"] = rel_err(cm(out2), ref_out)
+    if backward:
+        g = aum_hip.scan_tm_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, out_pre if has_z else None, ck, softplus, reverse, T(A_b, dev), lib=lib)
+        gr = O.scan_bwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus, reverse, "f64")
+        if bidir:
+            gb = O.scan_bwd(q["u"], q["delta"], A_b, q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus, True, "f64")
+            for k in ("du", "ddelta", "dB", "dC", "dD", "dz", "ddelta_bias"):
+                if gr[k] is not None:
+                    gr[k] = gr[k] + gb[k]
+            gr["dA_b"] = gb["dA"]
+        got = dict(du=cm(g["du"]), ddelta=cm(g["ddelta"]), dz=None if g["dz"] is None else cm(g["dz"]), dA=N(g["dA"]),
+                   dA_b=N(g["dA_b"]), dB=N(g["dBC"])[:, :, :dstate].transpose(0, 2, 1), dC=N(g["dBC"])[:, :, dstate:].transpose(0, 2, 1),
+                   dD=N(g["dD"]), ddelta_bias=N(g["ddelta_bias"]))
+        for k in ("du", "ddelta", "dA", "dA_b", "dB", "dC", "dD", "dz", "ddelta_bias"):
+            if gr.get(k) is None:
+                assert got.get(k) is None, k
+                continue
+            errs[k] = rel_err(got[k], gr[k])
+    bad = {k: v for k, v in errs.items() if not (v < tol * (4 if k.startswith("d") else 1))}
+    assert not bad, (name, str(dtype), "rev" if reverse else "fwd", "bidir" if bidir else "uni", bad, errs)
+    return errs

@@ -138,6 +138,27 @@ def main():
         aum_hip.debug.ablate = 0
     if want("scan_bwd") and fused:
         rec("scan_bwd_bidir", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre, True, A_b=A_b), iters=10), bw_bytes)
+    if want("scan_tm"):       # time-serial scan on token-major activations (scan_tm_kernels.h), the layout in_proj / x_proj leave
+        xz = torch.randn(Bsz, L, 2 * E, device=dev).to(dt)
+        ut = torch.randn(Bsz, L, E, device=dev).to(dt)
+        zt = xz[:, :, E:]
+        dlt = (0.5 * torch.randn(Bsz, L, E, device=dev)).to(dt)
+        R = a.dmodel // 16
+        xdbl = torch.randn(Bsz, L, R + 2 * N, device=dev).to(dt)
+        Bt, Ct = xdbl[:, :, R:R + N], xdbl[:, :, R + N:]
+        ck1 = aum_hip.scan_tm_ckpt(Bsz, L, E, N, False, dev)
+        ck2 = aum_hip.scan_tm_ckpt(Bsz, L, E, N, True, dev)
+        Bx, Cx = Bt, Ct
+        dsp = torch.nn.functional.softplus(dlt.float() + bias).to(dt)       # delta as a producer with a fused softplus would leave it
+        for tag, dl_, bias_, sp_ in (("", dlt, bias, True), ("_nosp", dsp, None, False)):
+            rec("scan_tm_fwd_uni" + tag, timeit(lambda: aum_hip.scan_tm_fwd(ut, dl_, A, Bx, Cx, D, zt, bias_, sp_)), 4 * T * s + bc)
+            rec("scan_tm_fwd_bidir" + tag, timeit(lambda: aum_hip.scan_tm_fwd(ut, dl_, A, Bx, Cx, D, zt, bias_, sp_, A_b=A_b)), 4 * T * s + bc)
+            rec("scan_tm_fwd_bidir_train" + tag, timeit(lambda: aum_hip.scan_tm_fwd(ut, dl_, A, Bx, Cx, D, zt, bias_, sp_, A_b=A_b, want_out_pre=True, ckpt=ck2)),
+                5 * T * s + bc + ck2.numel() * 4)
+            rec("scan_tm_fwd_bidir_pre_nockpt" + tag, timeit(lambda: aum_hip.scan_tm_fwd(ut, dl_, A, Bx, Cx, D, zt, bias_, sp_, A_b=A_b, want_out_pre=True)),
+                5 * T * s + bc)
+            rec("scan_tm_fwd_uni_train" + tag, timeit(lambda: aum_hip.scan_tm_fwd(ut, dl_, A, Bx, Cx, D, zt, bias_, sp_, want_out_pre=True, ckpt=ck1)),
+                5 * T * s + bc + ck1.numel() * 4)
     if want("conv"):
         w = torch.randn(E, 4, device=dev)
         b = torch.randn(E, device=dev)

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Where and when the waves of the time-serial scan ran (a -DAUM_SCANT_TRACE=1 build: every wave leaves HW_ID, XCC_ID and its
+begin / end s_memrealtime stamps in the buffer passed as `ckpt`).  usage: tm_trace.py <variant> [uni|bidir]"""
+import collections
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "audio-mamba-aum_amd"))
+import aum_hip  # noqa: E402
+
+
+def main():
+    variant, mode = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "bidir")
+    lib = aum_hip.Lib(os.path.join(ROOT, "audio-mamba-aum_amd", "aum_hip", "variants", f"libaum_hip_{variant}.so"))
+    torch.manual_seed(0)
+    Bsz, E, L, N, dt, dev = 64, 1536, 513, 16, torch.bfloat16, "cuda"
+    xz = torch.randn(Bsz, L, 2 * E, device=dev).to(dt)
+    u = torch.randn(Bsz, L, E, device=dev).to(dt)
+    z = xz[:, :, E:]
+    dl = torch.nn.functional.softplus(0.5 * torch.randn(Bsz, L, E, device=dev) - 4.0).to(dt)
+    xdbl = torch.randn(Bsz, L, 48 + 2 * N, device=dev).to(dt)
+    Bm, Cm = xdbl[:, :, 48:48 + N], xdbl[:, :, 48 + N:]
+    A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(E, 1)
+    bidir = mode == "bidir"
+    ck = aum_hip.scan_tm_ckpt(Bsz, L, E, N, bidir, dev)          # used as the trace buffer by this build
+    for rep in range(3):
+        ck.zero_()
+        aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, torch.ones(E, device=dev), z, None, False, A_b=A * 1.05 if bidir else None, want_out_pre=True, ckpt=ck, lib=lib)
+        torch.cuda.synchronize()
+    nwg = Bsz * (E // 64) // (2 if bidir else 4)
+    tr = ck.view(torch.int64).flatten()[: nwg * 4 * 4].view(nwg, 4, 4).cpu().numpy()
+    hw, xcc, t0, t1 = tr[..., 0], tr[..., 1] & 0xF, tr[..., 2], tr[..., 3]
+    tmin = t0.min()
+    print(f"{mode}: {nwg} workgroups x 4 waves; kernel span {(t1.max() - tmin) / 100:.1f} us (s_memrealtime, 100 MHz)")
+    cu = (hw >> 8) & 0xF
+    sh = (hw >> 12) & 0x1
+    se = (hw >> 13) & 0x7
+    simd = (hw >> 4) & 0x3
+    cuid = xcc * 1000 + se * 100 + sh * 10 + cu
+    per_cu = collections.Counter(cuid[:, 0].tolist())
+    print("distinct CUs used:", len(per_cu), " workgroups per CU histogram:", sorted(collections.Counter(per_cu.values()).items()))
+    per_simd = collections.Counter((cuid * 4 + simd).flatten().tolist())
+    print("waves per SIMD histogram:", sorted(collections.Counter(per_simd.values()).items()))
+    dur = (t1 - t0) / 100.0
+    start = (t0 - tmin) / 100.0
+    print(f"wave duration us: min {dur.min():.1f} median {float(sorted(dur.flatten())[dur.size // 2]):.1f} max {dur.max():.1f};  start offset us: median "
+          f"{float(sorted(start.flatten())[start.size // 2]):.1f} max {start.max():.1f}")
+    late = (start[:, 0] > 5.0).sum()
+    print(f"workgroups starting more than 5 us after the first: {late}")
+    by = collections.defaultdict(list)
+    for w in range(nwg):
+        for k in range(4):
+            by[per_simd[int(cuid[w, k] * 4 + simd[w, k])]].append(dur[w, k])
+    for n, v in sorted(by.items()):
+        print(f"  SIMDs holding {n} waves: {len(v)} waves, mean duration {sum(v) / len(v):.1f} us")
+
+
+if __name__ == "__main__":
+    main()
