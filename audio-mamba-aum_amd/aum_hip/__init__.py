@@ -448,7 +448,9 @@ def _tm3(t, name, last):
     """(batch, len, X) tensor with unit stride along X -> (batch stride, token stride) in elements"""
     if t.dim() != 3 or t.shape[2] != last or (t.stride(2) != 1 and last != 1):
         raise RuntimeError(f"{name}: expected (batch, len, {last}) with the last axis contiguous (token-major)")
-    return t.stride(0), t.stride(1)
+    ts = t.stride(1) if t.shape[1] > 1 else last                # the stride of a size-1 axis is arbitrary: normalise
+    bs = t.stride(0) if t.shape[0] > 1 else ts * t.shape[1]
+    return bs, ts
 
 
 def scan_tm_ckpt(batch, length, dim, dstate, bidir, device, lib=None):

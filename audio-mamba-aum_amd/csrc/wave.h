@@ -88,6 +88,10 @@ AUM_DEV int wave_in_wg() { return __builtin_amdgcn_readfirstlane((int)(threadIdx
 #define AUM_WG_BARRIER_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 // compiler scheduling fence (no instruction): keeps what was issued before it ahead of what follows
 #define AUM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// issue priority of this wave among the waves of its SIMD (0..3; the arbiter picks by priority, then by age), and the slot number
+// the hardware gave the wave on its SIMD (HW_ID.wave_id: distinct for the waves that share a SIMD)
+#define AUM_SET_PRIO(p) __builtin_amdgcn_s_setprio(p)
+AUM_DEV int wave_slot_on_simd() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u); }
 // wait for every outstanding scalar-cache (and LDS) request of this wave.  Scalar loads return out of order, so the only count
 // the hardware can wait for is zero: a wave that prefetches row s+1 while it still has to wait for row s waits for both.  Placing
 // this BEFORE the next prefetch is issued makes the wait cover only requests that have had a whole step to arrive.
@@ -313,6 +317,34 @@ template <class T> AUM_DEV void gbuf_store(const gbuf<T>& b, vi voff_bytes, int 
 }
 typedef float aum_f2 __attribute__((ext_vector_type(2)));
 typedef float aum_f4 __attribute__((ext_vector_type(4)));
+// two consecutive elements of a row, raw (one dword for the 16-bit types, a dwordx2 for float), and their widening -- separate so that
+// a prefetch is not waited for where it is issued
+struct vpair_raw { vi w[2]; };
+template <class T> AUM_DEV vpair_raw gbuf_load_pair_raw(const gbuf<T>& b, vi voff_bytes, int soff_bytes) {
+    vpair_raw r;
+    if constexpr (sizeof(T) == 4) {
+        typedef int i2 __attribute__((ext_vector_type(2)));
+        const i2 v = __builtin_bit_cast(i2, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff_bytes, soff_bytes, 0));
+        r.w[0] = v.x;
+        r.w[1] = v.y;
+    } else {
+        r.w[0] = (int)__builtin_amdgcn_raw_buffer_load_b32(b.r, voff_bytes, soff_bytes, 0);
+        r.w[1] = 0;
+    }
+    return r;
+}
+template <class T> AUM_DEV void pair_raw_to_f32(const vpair_raw& r, vf& lo, vf& hi) {
+    if constexpr (sizeof(T) == 4) {
+        lo = __builtin_bit_cast(float, r.w[0]);
+        hi = __builtin_bit_cast(float, r.w[1]);
+    } else if constexpr (__is_same(T, bf16_t)) {
+        lo = bits_to_f32((uint32_t)r.w[0] << 16);
+        hi = bits_to_f32((uint32_t)r.w[0] & 0xffff0000u);
+    } else {
+        lo = (float)__builtin_bit_cast(_Float16, (uint16_t)((uint32_t)r.w[0] & 0xffffu));
+        hi = (float)__builtin_bit_cast(_Float16, (uint16_t)((uint32_t)r.w[0] >> 16));
+    }
+}
 // two consecutive elements of a row as fp32 (one dword for the 16-bit types, one dwordx2 for float)
 template <class T> AUM_DEV void gbuf_load_pair(const gbuf<T>& b, vi voff_bytes, int soff_bytes, vf& lo, vf& hi) {
     if constexpr (sizeof(T) == 4) {
@@ -356,6 +388,9 @@ template <class T> AUM_DEV void gbuf_store16(const gbuf<T>& b, vi voff_bytes, in
     const u4 u = {(uint32_t)q.w[0], (uint32_t)q.w[1], (uint32_t)q.w[2], (uint32_t)q.w[3]};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(b.r, 0, 0, 0)), u), b.r, voff_bytes,
                                            soff_bytes, 0);
+}
+template <class T> AUM_DEV void gbuf_store16_m(const gbuf<T>& b, vi voff_bytes, int soff_bytes, const vq& q, vm m) {
+    if (m) gbuf_store16(b, voff_bytes, soff_bytes, q);
 }
 AUM_DEV void lds_write16(float* lds, vi byte_off, const vq& q) {
     typedef int i4 __attribute__((ext_vector_type(4)));
@@ -487,6 +522,8 @@ inline void lds_atomic_add(float* lds, const vi& idx, const vf& v) { AUM_LANES l
 #define AUM_WG_BARRIER_IN_PHASE() do { } while (0)
 #define AUM_WG_BARRIER_LDS() do { } while (0)
 #define AUM_SCHED_FENCE() do { } while (0)
+#define AUM_SET_PRIO(p) do { } while (0)
+inline int wave_slot_on_simd() { return 0; }
 #define AUM_WAIT_SCALAR_LOADS() do { } while (0)
 #define AUM_PER_WAVE(NW) (NW)
 #define AUM_W(w) (w)
@@ -539,6 +576,17 @@ template <class T> inline vf raw_to_f32(const vi& raw) {
 template <class T> inline void gbuf_store(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes, const vf& v) {
     AUM_LANES f32_to_elem(v.v[l], *(T*)((char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes));
 }
+struct vpair_raw { vf lo, hi; };
+template <class T> inline vpair_raw gbuf_load_pair_raw(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes) {
+    vpair_raw r;
+    AUM_LANES {
+        const T* q = (const T*)((const char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes);
+        r.lo.v[l] = elem_to_f32(q[0]);
+        r.hi.v[l] = elem_to_f32(q[1]);
+    }
+    return r;
+}
+template <class T> inline void pair_raw_to_f32(const vpair_raw& r, vf& lo, vf& hi) { lo = r.lo; hi = r.hi; }
 template <class T> inline void gbuf_load_pair(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes, vf& lo, vf& hi) {
     AUM_LANES {
         const T* q = (const T*)((const char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes);
@@ -560,6 +608,13 @@ template <class T> inline vq gbuf_load16(const gbuf<T>& b, const vi& voff_bytes,
 }
 template <class T> inline void gbuf_store16(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes, const vq& q) {
     AUM_LANES {
+        int t[4];
+        for (int k = 0; k < 4; ++k) t[k] = q.w[k].v[l];
+        std::memcpy((char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes, t, 16);
+    }
+}
+template <class T> inline void gbuf_store16_m(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes, const vq& q, const vm& m) {
+    AUM_LANES if (m.v[l]) {
         int t[4];
         for (int k = 0; k < 4; ++k) t[k] = q.w[k].v[l];
         std::memcpy((char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes, t, 16);

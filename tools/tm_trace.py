@@ -31,7 +31,7 @@ def main():
         aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, torch.ones(E, device=dev), z, None, False, A_b=A * 1.05 if bidir else None, want_out_pre=True, ckpt=ck, lib=lib)
         torch.cuda.synchronize()
     nwg = Bsz * (E // 64) // (2 if bidir else 4)
-    tr = ck.view(torch.int64).flatten()[: nwg * 4 * 4].view(nwg, 4, 4).cpu().numpy()
+    tr = ck.view(torch.int64).flatten()[: nwg * 4 * 12].view(nwg, 4, 12).cpu().numpy()
     hw, xcc, t0, t1 = tr[..., 0], tr[..., 1] & 0xF, tr[..., 2], tr[..., 3]
     tmin = t0.min()
     print(f"{mode}: {nwg} workgroups x 4 waves; kernel span {(t1.max() - tmin) / 100:.1f} us (s_memrealtime, 100 MHz)")
@@ -56,6 +56,22 @@ def main():
             by[per_simd[int(cuid[w, k] * 4 + simd[w, k])]].append(dur[w, k])
     for n, v in sorted(by.items()):
         print(f"  SIMDs holding {n} waves: {len(v)} waves, mean duration {sum(v) / len(v):.1f} us")
+    import numpy as np
+    print("  duration percentiles us (5/25/50/75/95/100):", " ".join(f"{np.percentile(dur, q):.0f}" for q in (5, 25, 50, 75, 95, 100)))
+    print("  mean duration by XCD:", " ".join(f"{dur[xcc == k].mean():.0f}" for k in range(8)))
+    print("  mean duration by wave slot in the workgroup:", " ".join(f"{dur[:, k].mean():.0f}" for k in range(4)))
+    print("  mean end time by XCD:", " ".join(f"{((t1 - tmin) / 100.0)[xcc == k].mean():.0f}" for k in range(8)))
+    wg_end = ((t1 - tmin) / 100.0).max(1)
+    order = np.argsort(wg_end)[-5:]
+    print("  last workgroups to finish:", [(int(w), int(xcc[w, 0]), int(se[w, 0]), int(cu[w, 0]), round(float(wg_end[w]), 1)) for w in order])
+    cu_end = collections.defaultdict(float)
+    for w in range(nwg):
+        cu_end[int(cuid[w, 0])] = max(cu_end[int(cuid[w, 0])], float(wg_end[w]))
+    v = np.array(list(cu_end.values()))
+    print("  per-CU finish time us percentiles (5/50/95/100):", " ".join(f"{np.percentile(v, q):.0f}" for q in (5, 50, 95, 100)))
+    acc = tr[..., 4:9].astype(float).reshape(-1, 5).mean(0)
+    names = ["prologue", "request", "steps", "flush", "park"]
+    print("  shader-clock cycles per wave (mean): " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, acc)) + f"  total {acc.sum():.0f}")
 
 
 if __name__ == "__main__":
