@@ -129,7 +129,7 @@ class ProjWArgs(C.Structure):
 EXPORTS = ["aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows",
-           "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes"]
+           "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_selftest_wave_sum32"]
 
 
 class Lib:
@@ -161,6 +161,7 @@ class Lib:
         self.c.aum_proj_bwd_weight_splits.argtypes = [_i32, _i64]
         self.c.aum_selftest_wave_scan.argtypes = [_vp, _vp, C.c_int, _vp]
         self.c.aum_hbm_copy.argtypes = [_vp, _vp, _i64, _vp]
+        self.c.aum_selftest_wave_sum32.argtypes = [_vp, _vp, _vp]
         self.c.aum_sum_rows.argtypes = [_vp, _vp, _i64, _i64, _i64, _i32, _vp]
         self.c.aum_selective_scan_ckpt_bytes.restype = _i64
         self.c.aum_selective_scan_ckpt_bytes.argtypes = [_i32] * 4
@@ -503,6 +504,55 @@ def scan_tm_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softpl
     return out, out_pre
 
 
+def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_softplus=False, reverse=False, A_b=None, dz_out=None,
+                lib=None):
+    """Backward of scan_tm_fwd (same tensor conventions; ckpt: the tensor scan_tm_fwd filled).  Returns dict(du, ddelta, dz (batch, len,
+    dim) in u's dtype, dBC (batch, len, 2 * dstate) fp32 = dB | dC, dA, dA_b (dim, dstate), dD, ddelta_bias (dim) fp32)."""
+    lib = lib or get()
+    batch, length, dim = u.shape
+    dstate = A.shape[1]
+    dev = u.device
+    for t in (u, delta, z, B, C, dout, out_pre, ckpt):
+        lib.check_tensor(t)
+    A, A_b, D, delta_bias = _f32c(A), _f32c(A_b), _f32c(D), _f32c(delta_bias)
+    bidir = A_b is not None
+    du = torch.empty((batch, length, dim), dtype=u.dtype, device=dev)
+    ddelta = torch.empty((batch, length, dim), dtype=u.dtype, device=dev)
+    dz = None
+    if z is not None:
+        dz = dz_out if dz_out is not None else torch.empty((batch, length, dim), dtype=u.dtype, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    dBC = torch.empty((batch, length, 2 * dstate), **f32)
+    dA = torch.empty((dim, dstate), **f32)
+    dA_b = torch.empty((dim, dstate), **f32) if bidir else None
+    dD = torch.empty((dim,), **f32) if D is not None else None
+    dbias = torch.empty((dim,), **f32) if delta_bias is not None else None
+    ws_bytes = int(lib.c.aum_scan_tm_workspace_bytes(batch, dim, length, dstate, int(bidir)))
+    ws = torch.empty((max(ws_bytes, 4) // 4,), **f32)
+    a = ScanTmBwdArgs()
+    a.u, a.delta, a.z, a.B, a.C, a.dout, a.out_pre = map(_ptr, (u, delta, z, B, C, dout, out_pre))
+    a.A, a.A_b, a.D, a.delta_bias, a.ckpt = _ptr(A), _ptr(A_b), _ptr(D), _ptr(delta_bias), _ptr(ckpt)
+    a.du, a.ddelta, a.dz = _ptr(du), _ptr(ddelta), _ptr(dz)
+    a.dA, a.dA_b, a.dBC, a.dD, a.ddelta_bias = map(_ptr, (dA, dA_b, dBC, dD, dbias))
+    a.workspace, a.workspace_bytes = _ptr(ws), ws_bytes
+    a.u_bs, a.u_ts = _tm3(u, "u", dim)
+    a.delta_bs, a.delta_ts = _tm3(delta, "delta", dim)
+    a.B_bs, a.B_ts = _tm3(B, "B", dstate)
+    a.C_bs, a.C_ts = _tm3(C, "C", dstate)
+    a.dout_bs, a.dout_ts = _tm3(dout, "dout", dim)
+    a.du_bs, a.du_ts = _tm3(du, "du", dim)
+    a.ddelta_bs, a.ddelta_ts = _tm3(ddelta, "ddelta", dim)
+    if z is not None:
+        a.z_bs, a.z_ts = _tm3(z, "z", dim)
+        a.pre_bs, a.pre_ts = _tm3(out_pre, "out_pre", dim)
+        a.dz_bs, a.dz_ts = _tm3(dz, "dz", dim)
+    assert ckpt.dtype == torch.float32 and ckpt.is_contiguous()
+    a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
+    a.flags = (SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0)
+    _launch(lib.c.aum_scan_tm_bwd, a, u, lib, "scan_tm_bwd_bidir" if bidir else "scan_tm_bwd", (batch, dim, length, dstate, u.element_size(), True))
+    return dict(du=du, ddelta=ddelta, dz=dz, dBC=dBC, dA=dA, dA_b=dA_b, dD=dD, ddelta_bias=dbias)
+
+
 def conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, dmajor=False, generic=False, lib=None):
     """causal_conv1d_cuda.causal_conv1d_fwd(x, weight(dim,width), bias, None, silu) -> y (batch, dim, len) contiguous."""
     lib = lib or get()
@@ -782,6 +832,16 @@ def selftest_wave_scan(P, S, rev=False, lib=None):
     out = torch.empty_like(inp)
     _chk(lib.c.aum_selftest_wave_scan(_ptr(inp), _ptr(out), int(rev), lib.stream(inp)), "aum_selftest_wave_scan")
     return out[:64], out[64:]
+
+
+def selftest_wave_sum32(values, lib=None):
+    """values: (32, 64) fp32 -> (2, 64): row 0 the totals in the lane order of wave_sum32 (lane l: value 2 * (l & 15) + ((l >> 4) & 1)),
+    row 1 wave_sum16 of the first 16 values (lane l: value l & 15)"""
+    lib = lib or get()
+    inp = values.float().contiguous()
+    out = torch.empty((2, 64), dtype=torch.float32, device=inp.device)
+    _chk(lib.c.aum_selftest_wave_sum32(_ptr(inp), _ptr(out), lib.stream(inp)), "aum_selftest_wave_sum32")
+    return out
 
 
 def sum_rows(t, lib=None):

@@ -43,6 +43,7 @@ AUM_HOSTDEV bool scant_supported(int dim, int dstate) { return dstate == SCANT_N
 // with a 2- or 4-byte LDS access.  Row i of a tile is iteration base + i of the block: memory row r is i = r (forward time) or
 // 7 - r (reverse time), so per-lane global offsets are never negative.
 // ------------------------------------------------------------------------------------------------
+template <bool V> struct ScanTTag { static constexpr bool value = V; };
 template <class T> struct ScanTTile {
     static constexpr int ES = (int)sizeof(T);
     static constexpr int ROWB = WAVE * ES;                 // bytes per tile row
@@ -417,6 +418,399 @@ AUM_DEV void scant_fwd(const AumScanTmFwdArgs& p, int wg, float* lds, unsigned l
         if (unit < units)
             scant_fwd_run<T, N, 2, SP, HAS_Z, HAS_PRE>(p, unit / gpb, (unit % gpb) * WAVE, d, d ? L - 1 : 0, d ? -1 : 1, scant_first_half(L, d), L,
                                                        d ? p.A_b : p.A, 2.f, x[AUM_W(w)], lds + w * scant_lds_wave_floats<T>(), tacc);
+    }
+}
+
+
+// ================================================================================================
+// Backward.  The same division of the work: lane = channel, a wave owns one direction of a channel group and walks its blocks of
+// 8 steps in REVERSE scan order.  A block is processed in passes over state pairs (two states at a time):
+//   forward sweep over the block from the checkpointed entry state:  a = exp2(delta A2), w = a x, x = w + (delta u) B -- keeps w_i
+//     (= a_i x_{i-1}) in registers and forms the dC products dy_i x_i;
+//   reverse sweep with the adjoint  g_i = dy_i C_i + a_{i+1} g_{i+1}  carried from block to block:  dB products g (delta u),
+//     S1_i += g . B_i,  S2_i += A2 . (g w_i),  dA += delta_i g w_i;
+//   the 16 + 16 products of the pass are summed over the 64 channels by two transposing butterflies (wave_sum16) and collected in
+//     an LDS tile [step][dB_0..15 | dC_0..15] that leaves as ONE partial row block per wave and block (no atomics; a second
+//     kernel sums the channel-group partials).
+// After the passes: du_i = delta_i S1_i + D dy_i, ddelta_i = u_i S1_i + ln2 S2_i, dz_i = dout_i ytot_i d(gate)/dz.
+// Fo-Bi: the two direction waves of a channel group walk time in opposite order; as in the forward each first writes its half of
+// du / ddelta as partials, they meet at one barrier, and each then finishes the other's half (adding the partial, applying the
+// softplus derivative, dz, dD, ddelta_bias).
+// Memory: tiles as in the forward.  The next block's tensors are requested ONE PER PASS (four registers in flight) and parked a
+// pass later -- the input tiles are free by then, because a block turns them into per-step registers (delta, u, dy) before its
+// first pass.
+// ================================================================================================
+template <class T> AUM_HOSTDEV constexpr int scant_bwd_lds_wave_floats() {
+    return 8 * ScanTTile<T>::FLOATS + 2 * SCANT_BC_BLOCK;      // u, delta, z, dout, ypre | du, ddelta, dz | B/C block | dB/dC block
+}
+// partials of one (batch entry, direction, channel group) wave
+struct ScanTBwdOut {
+    float* dbc;        // [batch][len][nparts][2N] fp32 partial rows
+    float* dA;         // [ndir][batch][N][dim]
+    float* dD;         // [ndir][batch][dim]
+    float* dbias;      // [ndir][batch][dim]
+    int nparts;
+};
+
+template <class T, int N, int PHASE, bool SP, bool HAS_Z>
+AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int b, int e0, int dir, int part, int t0, int tstep, int it0,
+                           int it1, const float* Aptr, float dmul, vf2 (&hh)[N / 2], vf2 (&dAacc)[N / 2], vf& dDacc, vf& dbacc, float* lds) {
+    using TL = ScanTTile<T>;
+    constexpr int ES = TL::ES, ROWB = TL::ROWB, NLD = TL::NLD;
+    constexpr bool FINAL = PHASE != 1, LD_PART = PHASE == 2;
+    static_assert(N == 16 && SCANT_CK == 8, "8 steps x 8 state pairs");
+    const int L = p.len;
+    const vi lane = lane_id();
+    const vi ec = lane + e0;
+    vf2 A2[N / 2];
+    AUM_UNROLL
+    for (int j = 0; j < N / 2; ++j) A2[j] = mk2(gload_u(Aptr, ec * N + 2 * j) * LOG2E, gload_u(Aptr, ec * N + 2 * j + 1) * LOG2E);
+    const vf biasv = p.delta_bias ? gload_u(p.delta_bias, ec) : splat(0.f);
+    const vf Dv = p.D ? gload_u(p.D, ec) * dmul : splat(0.f);
+    const gbuf<T> ubuf = make_gbuf(row_ptr<T>(p.u, (int64_t)b * p.u_bs));
+    const gbuf<T> dbuf = make_gbuf(row_ptr<T>(p.delta, (int64_t)b * p.delta_bs));
+    const gbuf<T> zbuf = make_gbuf(HAS_Z ? row_ptr<T>(p.z, (int64_t)b * p.z_bs) : row_ptr<T>(p.u, 0));
+    const gbuf<T> gbuf_ = make_gbuf(row_ptr<T>(p.dout, (int64_t)b * p.dout_bs));
+    const gbuf<T> ybuf = make_gbuf(HAS_Z ? row_ptr<T>(p.out_pre, (int64_t)b * p.pre_bs) : row_ptr<T>(p.u, 0));
+    const gbuf<T> dubuf = make_gbuf(row_ptr<T>(p.du, (int64_t)b * p.du_bs));
+    const gbuf<T> ddbuf = make_gbuf(row_ptr<T>(p.ddelta, (int64_t)b * p.ddelta_bs));
+    const gbuf<T> dzbuf = make_gbuf(HAS_Z ? row_ptr<T>(p.dz, (int64_t)b * p.dz_bs) : row_ptr<T>(p.du, 0));
+    const gbuf<T> Bbuf = make_gbuf(row_ptr<T>(p.B, (int64_t)b * p.B_bs));
+    const gbuf<T> Cbuf = make_gbuf(row_ptr<T>(p.C, (int64_t)b * p.C_bs));
+    const int nck = scant_nck(L);
+    const gbuf<float> ckbuf = make_gbuf(p.ckpt + ((int64_t)dir * p.batch + b) * (nck > 0 ? nck : 1) * N * p.dim);
+    const gbuf<float> dbcbuf = make_gbuf(wo.dbc + (int64_t)b * L * wo.nparts * (2 * N));
+    const int u_tb = (int)p.u_ts * ES, d_tb = (int)p.delta_ts * ES, z_tb = HAS_Z ? (int)p.z_ts * ES : 0, g_tb = (int)p.dout_ts * ES,
+              y_tb = HAS_Z ? (int)p.pre_ts * ES : 0, du_tb = (int)p.du_ts * ES, dd_tb = (int)p.ddelta_ts * ES,
+              dz_tb = HAS_Z ? (int)p.dz_ts * ES : 0, B_tb = (int)p.B_ts * ES, C_tb = (int)p.C_ts * ES;
+    const int dbc_tb = wo.nparts * (2 * N) * 4, dbc_col = part * (2 * N) * 4;
+    auto tok = [&](int it) { return t0 + it * tstep; };
+    float* t_u = lds;
+    float* t_d = lds + TL::FLOATS;
+    float* t_z = lds + 2 * TL::FLOATS;
+    float* t_g = lds + 3 * TL::FLOATS;
+    float* t_y = lds + 4 * TL::FLOATS;
+    float* t_du = lds + 5 * TL::FLOATS;
+    float* t_dd = lds + 6 * TL::FLOATS;
+    float* t_dz = lds + 7 * TL::FLOATS;
+    float* t_bc = lds + 8 * TL::FLOATS;
+    float* t_dbc = t_bc + SCANT_BC_BLOCK;
+    const vi st_r = lane >> 3, st_c = lane & 7;
+    const vi st_i = tstep > 0 ? st_r : (SCANT_CK - 1) - st_r;
+    const vi st_gcol = st_c * 16 + e0 * ES;
+    const vi st_lds = st_i * ROWB + st_c * 16;
+    const vi el_off = lane * ES;
+    const vi bc_slot = st_i * SCANT_BC_ROW + st_c * 2;
+    const vi vo4 = ec * 4;
+
+    // per-lane row of block `blk` in a global tensor: memory row st_r for blocks inside the phase (plus the scalar offset of the
+    // block's lowest time step), the clamped row's time step for ragged ones
+    struct Rows { vi rowt; int t_lo; vm valid; bool inside; };
+    auto rows_of = [&](int blk) {
+        Rows r;
+        const int base = blk * SCANT_CK;
+        r.inside = base >= it0 && base + SCANT_CK <= it1;
+        r.t_lo = 0;
+        r.valid = lane >= 0;
+        if (r.inside) {
+            r.t_lo = tstep > 0 ? tok(base) : tok(base + SCANT_CK - 1);
+            r.rowt = st_r;
+        } else {
+            // loads: any real step of the direction (the forward sweep of a block re-runs its steps before the phase's first one);
+            // stores: the phase's own steps only
+            const vi it = st_i + base;
+            r.valid = (it >= it0) && (it < it1);
+            r.rowt = vmax_i(vmin_i(it, L - 1), 0) * tstep + t0;
+        }
+        return r;
+    };
+    auto load_tile = [&](const gbuf<T>& buf, int tb, const Rows& r, ScanTStage<T>& st) {
+        AUM_UNROLL
+        for (int i = 0; i < NLD; ++i) st.q[i] = gbuf_load16(buf, r.rowt * tb + st_gcol + 128 * i, r.t_lo * tb);
+    };
+    auto park_tile = [&](float* tile, const ScanTStage<T>& st) {
+        AUM_UNROLL
+        for (int i = 0; i < NLD; ++i) lds_write16(tile, st_lds + 128 * i, st.q[i]);
+    };
+    auto store_tile = [&](const gbuf<T>& buf, int tb, const float* tile, const Rows& r) {
+        AUM_UNROLL
+        for (int i = 0; i < NLD; ++i) {
+            const vq q = lds_read16(tile, st_lds + 128 * i);
+            if (r.inside) gbuf_store16(buf, r.rowt * tb + st_gcol + 128 * i, r.t_lo * tb, q);
+            else gbuf_store16_m(buf, r.rowt * tb + st_gcol + 128 * i, 0, q, r.valid);
+        }
+    };
+    // everything block `blk` needs, fetched in one go (the prologue of a phase)
+    auto fetch_block = [&](int blk) {
+        const Rows r = rows_of(blk);
+        ScanTStage<T> st;
+        load_tile(ubuf, u_tb, r, st); park_tile(t_u, st);
+        load_tile(dbuf, d_tb, r, st); park_tile(t_d, st);
+        load_tile(gbuf_, g_tb, r, st); park_tile(t_g, st);
+        if (HAS_Z) {
+            load_tile(zbuf, z_tb, r, st); park_tile(t_z, st);
+            load_tile(ybuf, y_tb, r, st); park_tile(t_y, st);
+        }
+        if (LD_PART) {
+            load_tile(dubuf, du_tb, r, st); park_tile(t_du, st);
+            load_tile(ddbuf, dd_tb, r, st); park_tile(t_dd, st);
+        }
+        vf b0, b1, c0, c1;
+        pair_raw_to_f32<T>(gbuf_load_pair_raw(Bbuf, r.rowt * B_tb + st_c * (2 * ES), r.t_lo * B_tb), b0, b1);
+        pair_raw_to_f32<T>(gbuf_load_pair_raw(Cbuf, r.rowt * C_tb + st_c * (2 * ES), r.t_lo * C_tb), c0, c1);
+        lds_write2(t_bc, bc_slot, b0, b1);
+        lds_write2(t_bc, bc_slot + N, c0, c1);
+        wave_lds_fence();
+    };
+
+    if (it0 >= it1) return;
+    const int blk_lo = it0 / SCANT_CK, blk_hi = (it1 + SCANT_CK - 1) / SCANT_CK;       // blocks blk_hi-1 down to blk_lo
+    fetch_block(blk_hi - 1);
+    vf2 xfirst = spl2(splat(0.f));       // entry state of the next block to process, first pair (requested a block ahead)
+    if (blk_hi - 1 > 0) {
+        const int off = (blk_hi - 2) * N * p.dim * 4;
+        xfirst = mk2(gbuf_load(ckbuf, vo4, off), gbuf_load(ckbuf, vo4, off + p.dim * 4));
+    }
+    // one block; FULL: all eight steps belong to the phase (no per-step conditions)
+    auto do_block = [&](auto full_tag, int blk) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int base = blk * SCANT_CK;
+        const int s_lo = FULL ? 0 : (it0 > base ? it0 - base : 0);                       // steps [s_lo, s_hi) of the block are this phase's
+        const int s_hi = FULL ? SCANT_CK : (it1 < base + SCANT_CK ? it1 - base : SCANT_CK);
+        const bool more = blk > blk_lo;
+        // ---- per-step registers of the block; dz of its steps --------------------------------------------------
+        vf dl[SCANT_CK], uu[SCANT_CK], dy[SCANT_CK];
+        AUM_UNROLL
+        for (int s = 0; s < SCANT_CK; ++s) {
+            const vi off = el_off + s * ROWB;
+            uu[s] = raw_to_f32<T>(lds_read_raw<T>(t_u, off));
+            vf d = raw_to_f32<T>(lds_read_raw<T>(t_d, off)) + biasv;
+            if (SP) d = vsoftplus(d);
+            dl[s] = d;
+            const vf go = raw_to_f32<T>(lds_read_raw<T>(t_g, off));
+            if (HAS_Z) {
+                const vf zz = raw_to_f32<T>(lds_read_raw<T>(t_z, off));
+                const vf sg = vsigmoid(zz);
+                dy[s] = go * (zz * sg);
+                if (FINAL) {        // dz = dout ytot d(z sigmoid(z))/dz  (direction-independent: written by whoever finishes the step)
+                    const vf yt = raw_to_f32<T>(lds_read_raw<T>(t_y, off));
+                    lds_write_elem<T>(t_dz, off, go * yt * (sg * vfma(zz, splat(1.f) - sg, splat(1.f))));
+                }
+            } else {
+                dy[s] = go;
+            }
+        }
+        vf S1[SCANT_CK], S2[SCANT_CK];
+        AUM_UNROLL
+        for (int s = 0; s < SCANT_CK; ++s) S1[s] = S2[s] = splat(0.f);
+        wave_lds_fence();
+        const Rows rn = rows_of(more ? blk - 1 : blk);
+        ScanTStage<T> st, st_pu, st_pd;   // the tensor of the next block in flight during a pass; its du / ddelta partials
+        vpair_raw bpn, cpn;
+        // entry state of the block for the first pair; the later pairs' a pass ahead
+        auto load_entry = [&](int blk_, int j_) {
+            if (blk_ <= 0) return spl2(splat(0.f));
+            const int off = ((blk_ - 1) * N + 2 * j_) * p.dim * 4;
+            return mk2(gbuf_load(ckbuf, vo4, off), gbuf_load(ckbuf, vo4, off + p.dim * 4));
+        };
+        vf2 xnext = xfirst;
+        // ---- passes over the state pairs (unrolled: the pair's registers are named, the staging schedule is static) ----------
+        AUM_UNROLL
+        for (int j = 0; j < N / 2; ++j) {
+            // next block: one tensor requested per pass, parked at the top of the next pass (its tile is free since the registers
+            // above were filled)
+            if (more) {
+                if (j == 1) park_tile(t_u, st);
+                if (j == 2) park_tile(t_d, st);
+                if (j == 3) park_tile(t_g, st);
+                if (HAS_Z && j == 4) park_tile(t_z, st);
+                if (HAS_Z && j == 5) park_tile(t_y, st);
+                if (j == 0) load_tile(ubuf, u_tb, rn, st);
+                if (j == 1) load_tile(dbuf, d_tb, rn, st);
+                if (j == 2) load_tile(gbuf_, g_tb, rn, st);
+                if (HAS_Z && j == 3) load_tile(zbuf, z_tb, rn, st);
+                if (HAS_Z && j == 4) load_tile(ybuf, y_tb, rn, st);
+                if (LD_PART && j == 5) load_tile(dubuf, du_tb, rn, st_pu);
+                if (LD_PART && j == 6) load_tile(ddbuf, dd_tb, rn, st_pd);
+                if (j == 6) {
+                    bpn = gbuf_load_pair_raw(Bbuf, rn.rowt * B_tb + st_c * (2 * ES), rn.t_lo * B_tb);
+                    cpn = gbuf_load_pair_raw(Cbuf, rn.rowt * C_tb + st_c * (2 * ES), rn.t_lo * C_tb);
+                }
+            }
+            AUM_SCHED_FENCE();        // passes are scheduled one by one: across them the scheduler's reordering costs registers (2.5 KB of scratch)
+            vf2 x = xnext;
+            if (j + 1 < N / 2) xnext = load_entry(blk, j + 1);
+            else if (more) xfirst = load_entry(blk - 1, 0);
+            const vf2 A2j = A2[j];
+            vf2 hj = hh[j], dAj = dAacc[j];
+            vf2 w[SCANT_CK];
+            vf pc[16], pb[16];
+            // forward sweep: steps 0 .. s_hi-1
+            AUM_UNROLL
+            for (int s = 0; s < SCANT_CK; ++s) {
+                pc[2 * s] = pc[2 * s + 1] = splat(0.f);
+                pb[2 * s] = pb[2 * s + 1] = splat(0.f);
+                if (FULL || s < s_hi) {
+                    vf q[2];
+                    lds_read2_u(t_bc, s * SCANT_BC_ROW + 2 * j, q);
+                    const vf2 a = vexp2_2(spl2(dl[s]) * A2j);
+                    w[s] = a * x;
+                    x = vfma2(spl2(dl[s] * uu[s]), mk2(q[0], q[1]), w[s]);
+                    if (FULL || s >= s_lo) {
+                        const vf2 pcs = spl2(dy[s]) * x;
+                        pc[2 * s] = lo2(pcs);
+                        pc[2 * s + 1] = hi2(pcs);
+                    }
+                }
+            }
+            AUM_SCHED_FENCE();
+            const vf dCsum = wave_sum16(pc);
+            AUM_SCHED_FENCE();
+            // reverse sweep: steps s_hi-1 .. s_lo
+            AUM_UNROLL
+            for (int s = SCANT_CK - 1; s >= 0; --s) {
+                if (FULL || (s >= s_lo && s < s_hi)) {
+                    vf qb[2], qc[2];
+                    lds_read2_u(t_bc, s * SCANT_BC_ROW + 2 * j, qb);
+                    lds_read2_u(t_bc, s * SCANT_BC_ROW + N + 2 * j, qc);
+                    const vf2 a = vexp2_2(spl2(dl[s]) * A2j);
+                    const vf2 g = vfma2(spl2(dy[s]), mk2(qc[0], qc[1]), hj);
+                    const vf2 pbs = g * spl2(dl[s] * uu[s]);
+                    pb[2 * s] = lo2(pbs);
+                    pb[2 * s + 1] = hi2(pbs);
+                    const vf2 gb = g * mk2(qb[0], qb[1]);
+                    S1[s] = S1[s] + (lo2(gb) + hi2(gb));
+                    pin_value(S1[s]);
+                    const vf2 r = g * w[s];
+                    const vf2 ar = A2j * r;
+                    S2[s] = S2[s] + (lo2(ar) + hi2(ar));
+                    pin_value(S2[s]);
+                    dAj = vfma2(spl2(dl[s]), r, dAj);
+                    hj = a * g;
+                }
+            }
+            AUM_SCHED_FENCE();
+            const vf dBsum = wave_sum16(pb);
+            // lane l < 16 holds the totals of (step l >> 1, state 2j + (l & 1))
+            {
+                const vi slot = (lane >> 1) * SCANT_BC_ROW + (lane & 1) + 2 * j;
+                lds_write_m(t_dbc, slot, dBsum, lane < 16);
+                lds_write_m(t_dbc, slot + N, dCsum, lane < 16);
+            }
+            hh[j] = hj;
+            dAacc[j] = dAj;
+        }
+        // ---- the block's du, ddelta; partials / finish ----------------------------------------------------------
+        wave_lds_fence();
+        AUM_UNROLL
+        for (int s = 0; s < SCANT_CK; ++s) {
+            if (FULL || (s >= s_lo && s < s_hi)) {
+                const vi off = el_off + s * ROWB;
+                vf du = dl[s] * S1[s];
+                vf dd = vfma(uu[s], S1[s], S2[s] * LN2);
+                if (FINAL) {
+                    du = vfma(Dv, dy[s], du);
+                    dDacc = vfma(dy[s], uu[s], dDacc);
+                    if (LD_PART) {
+                        du = du + raw_to_f32<T>(lds_read_raw<T>(t_du, off));
+                        dd = dd + raw_to_f32<T>(lds_read_raw<T>(t_dd, off));
+                    }
+                    if (SP) dd = dd * (splat(1.f) - vexp2(dl[s] * (-LOG2E)));      // sigmoid(raw) = 1 - exp(-softplus(raw))
+                    dbacc = dbacc + dd;
+                }
+                lds_write_elem<T>(t_du, off, du);
+                lds_write_elem<T>(t_dd, off, dd);
+            }
+        }
+        wave_lds_fence();
+        const Rows rc = rows_of(blk);
+        store_tile(dubuf, du_tb, t_du, rc);
+        store_tile(ddbuf, dd_tb, t_dd, rc);
+        if (HAS_Z && FINAL) store_tile(dzbuf, dz_tb, t_dz, rc);
+        {       // dB / dC partial rows of the block: [step][2N] fp32 = 16 bytes per lane
+            const vq q = lds_read16(t_dbc, st_i * (SCANT_BC_ROW * 4) + st_c * 16);
+            if (rc.inside) gbuf_store16(dbcbuf, rc.rowt * dbc_tb + st_c * 16 + dbc_col, rc.t_lo * dbc_tb, q);
+            else gbuf_store16_m(dbcbuf, rc.rowt * dbc_tb + st_c * 16 + dbc_col, 0, q, rc.valid);
+        }
+        wave_lds_fence();
+        if (more) {
+            // the last tensors of the next block: z / ytot parked above when present; the partials and B/C now
+            if (LD_PART) {
+                park_tile(t_du, st_pu);
+                park_tile(t_dd, st_pd);
+            }
+            vf b0, b1, c0, c1;
+            pair_raw_to_f32<T>(bpn, b0, b1);
+            pair_raw_to_f32<T>(cpn, c0, c1);
+            lds_write2(t_bc, bc_slot, b0, b1);
+            lds_write2(t_bc, bc_slot + N, c0, c1);
+            wave_lds_fence();
+        }
+    };
+    for (int blk = blk_hi - 1; blk >= blk_lo; --blk) {
+        if (blk * SCANT_CK >= it0 && blk * SCANT_CK + SCANT_CK <= it1) do_block(ScanTTag<true>{}, blk);
+        else do_block(ScanTTag<false>{}, blk);
+    }
+}
+
+// workgroup = four waves as in the forward.  Workspace partials are summed by scant_bwd_reduce.
+template <class T, bool SP, bool HAS_Z, bool BIDIR>
+AUM_DEV void scant_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int wg, float* lds) {
+    constexpr int N = SCANT_N;
+    constexpr int NW = SCANT_NW;
+    constexpr int UPW = scant_units_per_wg<BIDIR>();
+    const int gpb = p.dim / WAVE;
+    const int units = p.batch * gpb;
+    const int L = p.len;
+    vf2 hh[AUM_PER_WAVE(NW)][N / 2], dA[AUM_PER_WAVE(NW)][N / 2];
+    vf dD[AUM_PER_WAVE(NW)], dbias[AUM_PER_WAVE(NW)];
+    auto finish = [&](int w, int unit, int d) {      // per-wave partial sums of dA, dD, ddelta_bias
+        const int b = unit / gpb, e0 = (unit % gpb) * WAVE;
+        const vi ec = lane_id() + e0;
+        float* pa = wo.dA + ((int64_t)d * p.batch + b) * N * p.dim;
+        AUM_UNROLL
+        for (int n = 0; n < N; ++n) gstore(pa + (int64_t)n * p.dim, ec, (n & 1) ? hi2(dA[AUM_W(w)][n >> 1]) : lo2(dA[AUM_W(w)][n >> 1]), ec >= 0);
+        gstore(wo.dD + ((int64_t)d * p.batch + b) * p.dim, ec, dD[AUM_W(w)] * (BIDIR ? 2.f : 1.f), ec >= 0);
+        gstore(wo.dbias + ((int64_t)d * p.batch + b) * p.dim, ec, dbias[AUM_W(w)], ec >= 0);
+    };
+    auto init = [&](int w) {
+        AUM_UNROLL
+        for (int j = 0; j < N / 2; ++j) hh[AUM_W(w)][j] = dA[AUM_W(w)][j] = spl2(splat(0.f));
+        dD[AUM_W(w)] = dbias[AUM_W(w)] = splat(0.f);
+    };
+    if (!BIDIR) {
+        const bool rev = (p.flags & AUM_SCAN_REVERSE) != 0;
+        AUM_FOR_EACH_WAVE(w, NW) {
+            const int unit = wg * UPW + w;
+            if (unit < units) {
+                init(w);
+                scant_bwd_run<T, N, 0, SP, HAS_Z>(p, wo, unit / gpb, (unit % gpb) * WAVE, 0, unit % gpb, rev ? L - 1 : 0, rev ? -1 : 1, 0, L, p.A, 1.f,
+                                                  hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)], dbias[AUM_W(w)], lds + w * scant_bwd_lds_wave_floats<T>());
+                finish(w, unit, 0);
+            }
+        }
+        return;
+    }
+    // the backward walks a direction's iterations from the last to the first: its first phase is the iterations the forward's second
+    // phase ran, [first_half, L), its second phase [0, first_half)
+    AUM_FOR_EACH_WAVE(w, NW) {
+        const int unit = wg * UPW + (w >> 1), d = w & 1;
+        if (unit < units) {
+            init(w);
+            scant_bwd_run<T, N, 1, SP, HAS_Z>(p, wo, unit / gpb, (unit % gpb) * WAVE, d, (unit % gpb) * 2 + d, d ? L - 1 : 0, d ? -1 : 1,
+                                              scant_first_half(L, d), L, d ? p.A_b : p.A, 2.f, hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)],
+                                              dbias[AUM_W(w)], lds + w * scant_bwd_lds_wave_floats<T>());
+        }
+    }
+    AUM_WG_BARRIER();
+    AUM_FOR_EACH_WAVE(w, NW) {
+        const int unit = wg * UPW + (w >> 1), d = w & 1;
+        if (unit < units) {
+            scant_bwd_run<T, N, 2, SP, HAS_Z>(p, wo, unit / gpb, (unit % gpb) * WAVE, d, (unit % gpb) * 2 + d, d ? L - 1 : 0, d ? -1 : 1, 0,
+                                              scant_first_half(L, d), d ? p.A_b : p.A, 2.f, hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)],
+                                              dbias[AUM_W(w)], lds + w * scant_bwd_lds_wave_floats<T>());
+            finish(w, unit, d);
+        }
     }
 }
 

@@ -248,6 +248,9 @@ template <class T> AUM_DEV float gload_s(const T* p, int idx) { return elem_to_f
 // a value the optimiser must treat as unknown at this point: address arithmetic that depends on it is not hoisted out of
 // the enclosing loop (where it would occupy registers for the whole loop)
 AUM_DEV vi opaque_i(vi x) { asm volatile("" : "+v"(x)); return x; }
+// the value exists in a register HERE: keeps the optimiser from sinking a chain of accumulator updates to their distant use (and
+// carrying the operands of all of them in between)
+AUM_DEV void pin_value(vf& x) { asm volatile("" : "+v"(x)); }
 // a wave-uniform pointer pinned to an SGPR pair: what is added to it afterwards (a 32-bit per-lane offset) stays the `voffset` of a
 // `global_* v, voffset, s[base]` access -- without the pin the optimiser folds the uniform part into a 64-bit per-lane address
 // (v_lshl_add_u64 per access)
@@ -367,6 +370,10 @@ template <class T> AUM_DEV void gbuf_load_pair(const gbuf<T>& b, vi voff_bytes, 
 // LDS: a pair per lane (ds_write_b64; idx even) and four consecutive words read by every lane from ONE wave-uniform index
 // (ds_read_b128, all lanes the same address: a broadcast)
 AUM_DEV void lds_write2(float* lds, vi idx, vf a, vf b) { *reinterpret_cast<aum_f2*>(lds + idx) = aum_f2{a, b}; }
+AUM_DEV void lds_read2_u(const float* lds, int idx, vf (&o)[2]) {
+    const aum_f2 v = *reinterpret_cast<const aum_f2*>(lds + idx);
+    o[0] = v.x; o[1] = v.y;
+}
 AUM_DEV void lds_read4_u(const float* lds, int idx, vf (&o)[4]) {
     const aum_f4 v = *reinterpret_cast<const aum_f4*>(lds + idx);
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
@@ -548,6 +555,7 @@ inline float readlane(const vf& x, int lane) { return x.v[lane]; }
 inline vf writelane(const vf& v, float s, int lane) { vf r = v; r.v[lane] = s; return r; }
 template <class T> inline float gload_s(const T* p, int idx) { return elem_to_f32(p[idx]); }
 inline vi opaque_i(const vi& x) { return x; }
+inline void pin_value(vf&) {}
 template <class P> inline P* uniform_ptr(P* p) { return p; }
 template <class T> inline vf gload_g(const T* p, const vi& idx) { return gload_u(p, idx); }
 template <class T> inline void gstore_g(T* p, const vi& idx, const vf& v) { AUM_LANES f32_to_elem(v.v[l], p[idx.v[l]]); }
@@ -596,6 +604,7 @@ template <class T> inline void gbuf_load_pair(const gbuf<T>& b, const vi& voff_b
 }
 inline void lds_write2(float* lds, const vi& idx, const vf& a, const vf& b) { AUM_LANES { lds[idx.v[l]] = a.v[l]; lds[idx.v[l] + 1] = b.v[l]; } }
 inline void lds_read4_u(const float* lds, int idx, vf (&o)[4]) { for (int k = 0; k < 4; ++k) o[k] = splat(lds[idx + k]); }
+inline void lds_read2_u(const float* lds, int idx, vf (&o)[2]) { for (int k = 0; k < 2; ++k) o[k] = splat(lds[idx + k]); }
 struct vq { vi w[4]; };
 template <class T> inline vq gbuf_load16(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes) {
     vq q;
@@ -804,6 +813,144 @@ AUM_DEV float wave_sum(vf x) {
     x = x + dpp_row_shr<8>(x, splat(0.f));
     return (readlane(x, 15) + readlane(x, 31)) + (readlane(x, 47) + readlane(x, 63));
 }
+
+// ------------------------------------------------------------------------------------------------
+// Sum of 32 per-lane values over the 64 lanes with the results spread over the lanes (a transposing butterfly): on return lane l
+// holds the total of value k(l) = 2 * (l & 15) + ((l >> 4) & 1); lanes l and l ^ 32 hold the same total.
+// Each level pairs a lane with the partner that differs in one bit of the lane number; a lane keeps the half of the values its own
+// bit selects and adds the partner's partial sums of that half (and hands the partner the other half), so 32 values cost
+// 16 + 8 + 4 + 2 + 1 exchanges instead of 32 x 6.  Bits 3, 2, 1, 0 stay inside a 16-lane row (DPP), bit 4 goes through
+// v_permlane16_swap, and the last level adds the two halves of the wave (v_permlane32_swap).
+// ------------------------------------------------------------------------------------------------
+constexpr int wave_sum32_value_of_lane(int l) { return 2 * (l & 15) + ((l >> 4) & 1); }
+// the same for 16 values: lane l holds the total of value l & 15 (every 16-lane row holds all sixteen)
+#ifdef AUM_EMU
+inline vf wave_sum16(vf (&v)[16]) {
+    vf r;
+    AUM_LANES {
+        float acc = 0.f;
+        for (int m = 0; m < WAVE; ++m) acc += v[l & 15].v[m];
+        r.v[l] = acc;
+    }
+    return r;
+}
+inline vf wave_sum32(vf (&v)[32]) {
+    vf r;
+    AUM_LANES {
+        const int k = wave_sum32_value_of_lane(l);
+        float acc = 0.f;
+        for (int m = 0; m < WAVE; ++m) acc += v[k].v[m];
+        r.v[l] = acc;
+    }
+    return r;
+}
+#else
+template <int CTRL> AUM_DEV vf dpp_fetch(vf x) { return dpp_mov<CTRL>(x, x); }
+// levels over lane bits 2, 1, 0 of the butterfly: 8 values in v[0..7] -> v[0] (lane l: the value (l & 7) of the eight)
+AUM_DEV void wave_sum_low3(vf (&v)[32], int lane) {
+    {   // bit 2 (xor 4: lanes with the bit clear take lane + 4, the others lane - 4), 4 results
+        const bool up = (lane & 4) != 0;
+        AUM_UNROLL
+        for (int i = 0; i < 4; ++i) {
+            const vf keep = up ? v[4 + i] : v[i], send = up ? v[i] : v[4 + i];
+            const vf fromhi = dpp_mov<0x104>(send, send);      // row_shl:4  lane i <- i + 4
+            const vf fromlo = dpp_mov<0x114>(send, send);      // row_shr:4  lane i <- i - 4
+            v[i] = keep + (up ? fromlo : fromhi);
+        }
+    }
+    {   // bit 1 (xor 2: quad_perm [2,3,0,1]), 2 results
+        const bool up = (lane & 2) != 0;
+        AUM_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            const vf keep = up ? v[2 + i] : v[i], send = up ? v[i] : v[2 + i];
+            v[i] = keep + dpp_fetch<0x4E>(send);
+        }
+    }
+    {   // bit 0 (xor 1: quad_perm [1,0,3,2])
+        const bool up = (lane & 1) != 0;
+        const vf keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+        v[0] = keep + dpp_fetch<0xB1>(send);
+    }
+}
+AUM_DEV vf wave_sum16(vf (&v16)[16]) {
+    const int lane = (int)(threadIdx.x & 63u);
+    vf v[32];
+    {   // bit 3 (xor 8: row_ror:8), 8 results
+        const bool up = (lane & 8) != 0;
+        AUM_UNROLL
+        for (int i = 0; i < 8; ++i) {
+            const vf keep = up ? v16[8 + i] : v16[i], send = up ? v16[i] : v16[8 + i];
+            v[i] = keep + dpp_fetch<0x128>(send);
+        }
+    }
+    wave_sum_low3(v, lane);
+    vf r = v[0];
+    {   // rows: xor 16, then xor 32 (plain sums: every row ends with all sixteen totals)
+        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, r), __builtin_bit_cast(unsigned, r), false, false);
+        r = r + __builtin_bit_cast(float, (lane & 16) ? sw[0] : sw[1]);
+        const auto sx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, r), __builtin_bit_cast(unsigned, r), false, false);
+        r = r + __builtin_bit_cast(float, (lane & 32) ? sx[0] : sx[1]);
+    }
+    return r;
+}
+AUM_DEV vf wave_sum32(vf (&v)[32]) {
+    const int lane = (int)(threadIdx.x & 63u);
+    // bit 3 (xor 8: row_ror:8), 16 results
+    {
+        const bool up = (lane & 8) != 0;
+        AUM_UNROLL
+        for (int i = 0; i < 16; ++i) {
+            const vf keep = up ? v[16 + i] : v[i], send = up ? v[i] : v[16 + i];
+            v[i] = keep + dpp_fetch<0x128>(send);
+        }
+    }
+    // bit 2 (xor 4: lanes with the bit clear take lane + 4, the others lane - 4), 8 results
+    {
+        const bool up = (lane & 4) != 0;
+        AUM_UNROLL
+        for (int i = 0; i < 8; ++i) {
+            const vf keep = up ? v[8 + i] : v[i], send = up ? v[i] : v[8 + i];
+            const vf fromhi = dpp_mov<0x104>(send, send);      // row_shl:4  lane i <- i + 4
+            const vf fromlo = dpp_mov<0x114>(send, send);      // row_shr:4  lane i <- i - 4
+            v[i] = keep + (up ? fromlo : fromhi);
+        }
+    }
+    // bit 1 (xor 2: quad_perm [2,3,0,1]), 4 results
+    {
+        const bool up = (lane & 2) != 0;
+        AUM_UNROLL
+        for (int i = 0; i < 4; ++i) {
+            const vf keep = up ? v[4 + i] : v[i], send = up ? v[i] : v[4 + i];
+            v[i] = keep + dpp_fetch<0x4E>(send);
+        }
+    }
+    // bit 0 (xor 1: quad_perm [1,0,3,2]), 2 results
+    {
+        const bool up = (lane & 1) != 0;
+        AUM_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            const vf keep = up ? v[2 + i] : v[i], send = up ? v[i] : v[2 + i];
+            v[i] = keep + dpp_fetch<0xB1>(send);
+        }
+    }
+    // bit 4 (xor 16): v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second
+    vf r;
+    {
+        const bool up = (lane & 16) != 0;
+        const vf keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, send), __builtin_bit_cast(unsigned, send), false, false);
+        // first result: rows (r0, r0, r2, r2) of `send`; second: rows (r1, r1, r3, r3): an even row wants its odd neighbour and vice versa
+        r = keep + __builtin_bit_cast(float, up ? sw[0] : sw[1]);
+    }
+    // the two halves of the wave
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, r), __builtin_bit_cast(unsigned, r), false, false);
+        // first result: halves (lo, lo) of r; second: (hi, hi)
+        r = r + __builtin_bit_cast(float, (lane & 32) ? sw[0] : sw[1]);
+    }
+    return r;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // The associative scan of the selective-scan recurrence x' = a*x + b over the 64 lanes.

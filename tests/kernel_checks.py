@@ -145,6 +145,16 @@ def check_wave_scan(lib, dev):
         assert rel_err(N(So), ref) < 1e-5, ("wave scan", rev)
 
 
+def check_wave_sum32(lib, dev):
+    rng = np.random.default_rng(5)
+    v = rng.normal(0, 1, (32, 64)).astype(np.float32)
+    got = N(aum_hip.selftest_wave_sum32(T(v, dev), lib=lib))
+    ref = np.array([v[2 * (l & 15) + ((l >> 4) & 1)].astype(np.float64).sum() for l in range(64)])
+    assert rel_err(got[0], ref) < 1e-5, ("wave_sum32", got[0], ref)
+    ref16 = np.array([v[l & 15].astype(np.float64).sum() for l in range(64)])
+    assert rel_err(got[1], ref16) < 1e-5, ("wave_sum16", got[1], ref16)
+
+
 def check_proj(lib, dev, case, dtype=torch.bfloat16):
     """aum_proj_fwd / _bwd_data / _bwd_weight against fp64 matmuls of the same (rounded) operands: SSI:467-468 and
     SSI:570-590 restated on channel-major operands.  Second-stage references take the kernel's own 16-bit x_dbl /

@@ -15,6 +15,8 @@ import kernel_checks as KC  # noqa: E402
 lib = aum_hip.get()
 bwd = "--bwd" in sys.argv
 bad = 0
+KC.check_wave_sum32(lib, "cuda")
+print("ok  wave_sum32 / wave_sum16")
 for case in cases.SCAN_TM_CASES:
     for mode in ("fwd", "rev", "bidir"):
         for dt, xz in ((torch.float32, False), (torch.bfloat16, True), (torch.bfloat16, False), (torch.float16, False)):
