@@ -454,7 +454,7 @@ struct ScanTBwdOut {
 
 template <class T, int N, int PHASE, bool SP, bool HAS_Z>
 AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int b, int e0, int dir, int part, int t0, int tstep, int it0,
-                           int it1, const float* Aptr, float dmul, vf2 (&hh)[N / 2], vf2 (&dAacc)[N / 2], vf& dDacc, vf& dbacc, float* lds) {
+                           int it1, const float* Aptr, float dmul, vf16& hh, vf16& dAacc, vf& dDacc, vf& dbacc, float* lds) {
     using TL = ScanTTile<T>;
     constexpr int ES = TL::ES, ROWB = TL::ROWB, NLD = TL::NLD;
     constexpr bool FINAL = PHASE != 1, LD_PART = PHASE == 2;
@@ -462,9 +462,9 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     const int L = p.len;
     const vi lane = lane_id();
     const vi ec = lane + e0;
-    vf2 A2[N / 2];
-    AUM_UNROLL
-    for (int j = 0; j < N / 2; ++j) A2[j] = mk2(gload_u(Aptr, ec * N + 2 * j) * LOG2E, gload_u(Aptr, ec * N + 2 * j + 1) * LOG2E);
+    // A of a state pair is fetched a pass ahead (two loads that hit L1/L2) rather than held for all sixteen states: the registers go to
+    // the block's per-step values
+    auto load_A = [&](int j_) { return mk2(gload_u(Aptr, ec * N + 2 * j_), gload_u(Aptr, ec * N + 2 * j_ + 1)); };
     const vf biasv = p.delta_bias ? gload_u(p.delta_bias, ec) : splat(0.f);
     const vf Dv = p.D ? gload_u(p.D, ec) * dmul : splat(0.f);
     const gbuf<T> ubuf = make_gbuf(row_ptr<T>(p.u, (int64_t)b * p.u_bs));
@@ -551,10 +551,6 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             load_tile(zbuf, z_tb, r, st); park_tile(t_z, st);
             load_tile(ybuf, y_tb, r, st); park_tile(t_y, st);
         }
-        if (LD_PART) {
-            load_tile(dubuf, du_tb, r, st); park_tile(t_du, st);
-            load_tile(ddbuf, dd_tb, r, st); park_tile(t_dd, st);
-        }
         vf b0, b1, c0, c1;
         pair_raw_to_f32<T>(gbuf_load_pair_raw(Bbuf, r.rowt * B_tb + st_c * (2 * ES), r.t_lo * B_tb), b0, b1);
         pair_raw_to_f32<T>(gbuf_load_pair_raw(Cbuf, r.rowt * C_tb + st_c * (2 * ES), r.t_lo * C_tb), c0, c1);
@@ -566,6 +562,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     if (it0 >= it1) return;
     const int blk_lo = it0 / SCANT_CK, blk_hi = (it1 + SCANT_CK - 1) / SCANT_CK;       // blocks blk_hi-1 down to blk_lo
     fetch_block(blk_hi - 1);
+    vf2 Afirst = load_A(0);
     vf2 xfirst = spl2(splat(0.f));       // entry state of the next block to process, first pair (requested a block ahead)
     if (blk_hi - 1 > 0) {
         const int off = (blk_hi - 2) * N * p.dim * 4;
@@ -605,7 +602,8 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
         for (int s = 0; s < SCANT_CK; ++s) S1[s] = S2[s] = splat(0.f);
         wave_lds_fence();
         const Rows rn = rows_of(more ? blk - 1 : blk);
-        ScanTStage<T> st, st_pu, st_pd;   // the tensor of the next block in flight during a pass; its du / ddelta partials
+        const Rows rc = rows_of(blk);
+        ScanTStage<T> st;                 // the tensor in flight during a pass
         vpair_raw bpn, cpn;
         // entry state of the block for the first pair; the later pairs' a pass ahead
         auto load_entry = [&](int blk_, int j_) {
@@ -613,9 +611,10 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             const int off = ((blk_ - 1) * N + 2 * j_) * p.dim * 4;
             return mk2(gbuf_load(ckbuf, vo4, off), gbuf_load(ckbuf, vo4, off + p.dim * 4));
         };
-        vf2 xnext = xfirst;
-        // ---- passes over the state pairs (unrolled: the pair's registers are named, the staging schedule is static) ----------
-        AUM_UNROLL
+        vf2 xnext = xfirst, Anext = Afirst;
+        // ---- passes over the state pairs: a real loop (unrolled, the optimiser spread its work over all eight passes and needed more
+        // than 340 registers); the pairs' carries sit in register vectors indexed by the loop counter
+        _Pragma("nounroll")
         for (int j = 0; j < N / 2; ++j) {
             // next block: one tensor requested per pass, parked at the top of the next pass (its tile is free since the registers
             // above were filled)
@@ -630,26 +629,38 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                 if (j == 2) load_tile(gbuf_, g_tb, rn, st);
                 if (HAS_Z && j == 3) load_tile(zbuf, z_tb, rn, st);
                 if (HAS_Z && j == 4) load_tile(ybuf, y_tb, rn, st);
-                if (LD_PART && j == 5) load_tile(dubuf, du_tb, rn, st_pu);
-                if (LD_PART && j == 6) load_tile(ddbuf, dd_tb, rn, st_pd);
                 if (j == 6) {
                     bpn = gbuf_load_pair_raw(Bbuf, rn.rowt * B_tb + st_c * (2 * ES), rn.t_lo * B_tb);
                     cpn = gbuf_load_pair_raw(Cbuf, rn.rowt * C_tb + st_c * (2 * ES), rn.t_lo * C_tb);
                 }
             }
+            // the other direction's partial du / ddelta of THIS block (second phase): their tiles are idle until the block's last lines
+            if (LD_PART) {
+                if (j == 6) park_tile(t_du, st);
+                if (j == 7) park_tile(t_dd, st);
+                if (j == 5) load_tile(dubuf, du_tb, rc, st);
+                if (j == 6) load_tile(ddbuf, dd_tb, rc, st);
+            }
             AUM_SCHED_FENCE();        // passes are scheduled one by one: across them the scheduler's reordering costs registers (2.5 KB of scratch)
             vf2 x = xnext;
-            if (j + 1 < N / 2) xnext = load_entry(blk, j + 1);
-            else if (more) xfirst = load_entry(blk - 1, 0);
-            const vf2 A2j = A2[j];
-            vf2 hj = hh[j], dAj = dAacc[j];
+            const vf2 A2j = Anext * spl2(splat(LOG2E));
+            if (j + 1 < N / 2) {
+                xnext = load_entry(blk, j + 1);
+                Anext = load_A(j + 1);
+            } else {
+                if (more) xfirst = load_entry(blk - 1, 0);
+                Afirst = load_A(0);
+            }
+            vf2 hj = mk2(vf16_get(hh, 2 * j), vf16_get(hh, 2 * j + 1)), dAj = mk2(vf16_get(dAacc, 2 * j), vf16_get(dAacc, 2 * j + 1));
             vf2 w[SCANT_CK];
             vf pc[16], pb[16];
             // forward sweep: steps 0 .. s_hi-1
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) {
-                pc[2 * s] = pc[2 * s + 1] = splat(0.f);
-                pb[2 * s] = pb[2 * s + 1] = splat(0.f);
+                if (!FULL) {
+                    pc[2 * s] = pc[2 * s + 1] = splat(0.f);
+                    pb[2 * s] = pb[2 * s + 1] = splat(0.f);
+                }
                 if (FULL || s < s_hi) {
                     vf q[2];
                     lds_read2_u(t_bc, s * SCANT_BC_ROW + 2 * j, q);
@@ -666,6 +677,12 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             AUM_SCHED_FENCE();
             const vf dCsum = wave_sum16(pc);
             AUM_SCHED_FENCE();
+            // the reverse sweep recomputes a = exp2(delta A2) (an opaque copy of A2 keeps the compiler from carrying the forward sweep's
+            // sixteen values across: those registers do not exist at three waves per SIMD)
+            vf A2r_lo = lo2(A2j), A2r_hi = hi2(A2j);
+            pin_value(A2r_lo);
+            pin_value(A2r_hi);
+            const vf2 A2r = mk2(A2r_lo, A2r_hi);
             // reverse sweep: steps s_hi-1 .. s_lo
             AUM_UNROLL
             for (int s = SCANT_CK - 1; s >= 0; --s) {
@@ -673,7 +690,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                     vf qb[2], qc[2];
                     lds_read2_u(t_bc, s * SCANT_BC_ROW + 2 * j, qb);
                     lds_read2_u(t_bc, s * SCANT_BC_ROW + N + 2 * j, qc);
-                    const vf2 a = vexp2_2(spl2(dl[s]) * A2j);
+                    const vf2 a = vexp2_2(spl2(dl[s]) * A2r);
                     const vf2 g = vfma2(spl2(dy[s]), mk2(qc[0], qc[1]), hj);
                     const vf2 pbs = g * spl2(dl[s] * uu[s]);
                     pb[2 * s] = lo2(pbs);
@@ -697,8 +714,10 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                 lds_write_m(t_dbc, slot, dBsum, lane < 16);
                 lds_write_m(t_dbc, slot + N, dCsum, lane < 16);
             }
-            hh[j] = hj;
-            dAacc[j] = dAj;
+            vf16_set(hh, 2 * j, lo2(hj));
+            vf16_set(hh, 2 * j + 1, hi2(hj));
+            vf16_set(dAacc, 2 * j, lo2(dAj));
+            vf16_set(dAacc, 2 * j + 1, hi2(dAj));
         }
         // ---- the block's du, ddelta; partials / finish ----------------------------------------------------------
         wave_lds_fence();
@@ -723,7 +742,6 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             }
         }
         wave_lds_fence();
-        const Rows rc = rows_of(blk);
         store_tile(dubuf, du_tb, t_du, rc);
         store_tile(ddbuf, dd_tb, t_dd, rc);
         if (HAS_Z && FINAL) store_tile(dzbuf, dz_tb, t_dz, rc);
@@ -735,10 +753,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
         wave_lds_fence();
         if (more) {
             // the last tensors of the next block: z / ytot parked above when present; the partials and B/C now
-            if (LD_PART) {
-                park_tile(t_du, st_pu);
-                park_tile(t_dd, st_pd);
-            }
+
             vf b0, b1, c0, c1;
             pair_raw_to_f32<T>(bpn, b0, b1);
             pair_raw_to_f32<T>(cpn, c0, c1);
@@ -762,20 +777,23 @@ AUM_DEV void scant_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int wg,
     const int gpb = p.dim / WAVE;
     const int units = p.batch * gpb;
     const int L = p.len;
-    vf2 hh[AUM_PER_WAVE(NW)][N / 2], dA[AUM_PER_WAVE(NW)][N / 2];
+    vf16 hh[AUM_PER_WAVE(NW)], dA[AUM_PER_WAVE(NW)];
     vf dD[AUM_PER_WAVE(NW)], dbias[AUM_PER_WAVE(NW)];
     auto finish = [&](int w, int unit, int d) {      // per-wave partial sums of dA, dD, ddelta_bias
         const int b = unit / gpb, e0 = (unit % gpb) * WAVE;
         const vi ec = lane_id() + e0;
         float* pa = wo.dA + ((int64_t)d * p.batch + b) * N * p.dim;
         AUM_UNROLL
-        for (int n = 0; n < N; ++n) gstore(pa + (int64_t)n * p.dim, ec, (n & 1) ? hi2(dA[AUM_W(w)][n >> 1]) : lo2(dA[AUM_W(w)][n >> 1]), ec >= 0);
+        for (int n = 0; n < N; ++n) gstore(pa + (int64_t)n * p.dim, ec, vf16_get(dA[AUM_W(w)], n), ec >= 0);
         gstore(wo.dD + ((int64_t)d * p.batch + b) * p.dim, ec, dD[AUM_W(w)] * (BIDIR ? 2.f : 1.f), ec >= 0);
         gstore(wo.dbias + ((int64_t)d * p.batch + b) * p.dim, ec, dbias[AUM_W(w)], ec >= 0);
     };
     auto init = [&](int w) {
         AUM_UNROLL
-        for (int j = 0; j < N / 2; ++j) hh[AUM_W(w)][j] = dA[AUM_W(w)][j] = spl2(splat(0.f));
+        for (int n = 0; n < N; ++n) {
+            vf16_set(hh[AUM_W(w)], n, splat(0.f));
+            vf16_set(dA[AUM_W(w)], n, splat(0.f));
+        }
         dD[AUM_W(w)] = dbias[AUM_W(w)] = splat(0.f);
     };
     if (!BIDIR) {

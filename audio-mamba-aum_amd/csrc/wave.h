@@ -251,6 +251,11 @@ AUM_DEV vi opaque_i(vi x) { asm volatile("" : "+v"(x)); return x; }
 // the value exists in a register HERE: keeps the optimiser from sinking a chain of accumulator updates to their distant use (and
 // carrying the operands of all of them in between)
 AUM_DEV void pin_value(vf& x) { asm volatile("" : "+v"(x)); }
+// sixteen per-lane values addressed by a wave-uniform RUN-TIME index: a register vector the compiler indexes through M0
+// (s_set_gpr_idx / v_movrel), so a loop over state pairs need not be unrolled to keep its per-pair carries in registers
+struct vf16 { float __attribute__((ext_vector_type(16))) r; };
+AUM_DEV vf vf16_get(const vf16& a, int i) { return a.r[i]; }
+AUM_DEV void vf16_set(vf16& a, int i, vf v) { a.r[i] = v; }
 // a wave-uniform pointer pinned to an SGPR pair: what is added to it afterwards (a 32-bit per-lane offset) stays the `voffset` of a
 // `global_* v, voffset, s[base]` access -- without the pin the optimiser folds the uniform part into a 64-bit per-lane address
 // (v_lshl_add_u64 per access)
@@ -556,6 +561,9 @@ inline vf writelane(const vf& v, float s, int lane) { vf r = v; r.v[lane] = s; r
 template <class T> inline float gload_s(const T* p, int idx) { return elem_to_f32(p[idx]); }
 inline vi opaque_i(const vi& x) { return x; }
 inline void pin_value(vf&) {}
+struct vf16 { vf v[16]; };
+inline vf vf16_get(const vf16& a, int i) { return a.v[i]; }
+inline void vf16_set(vf16& a, int i, const vf& v) { a.v[i] = v; }
 template <class P> inline P* uniform_ptr(P* p) { return p; }
 template <class T> inline vf gload_g(const T* p, const vi& idx) { return gload_u(p, idx); }
 template <class T> inline void gstore_g(T* p, const vi& idx, const vf& v) { AUM_LANES f32_to_elem(v.v[l], p[idx.v[l]]); }

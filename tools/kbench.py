@@ -159,6 +159,19 @@ def main():
                 5 * T * s + bc)
             rec("scan_tm_fwd_uni_train" + tag, timeit(lambda: aum_hip.scan_tm_fwd(ut, dl_, A, Bx, Cx, D, zt, bias_, sp_, want_out_pre=True, ckpt=ck1)),
                 5 * T * s + bc + ck1.numel() * 4)
+    if want("scan_tmb"):      # backward of the time-serial scan (delta ready: the producer applied the softplus)
+        ut = torch.randn(Bsz, L, E, device=dev).to(dt)
+        xz = torch.randn(Bsz, L, 2 * E, device=dev).to(dt)
+        zt = xz[:, :, E:]
+        R = a.dmodel // 16
+        xdbl = torch.randn(Bsz, L, R + 2 * N, device=dev).to(dt)
+        Bt, Ct = xdbl[:, :, R:R + N], xdbl[:, :, R + N:]
+        dsp = torch.nn.functional.softplus(0.5 * torch.randn(Bsz, L, E, device=dev) + bias).to(dt)
+        dot = torch.randn(Bsz, L, E, device=dev).to(dt)
+        ck2 = aum_hip.scan_tm_ckpt(Bsz, L, E, N, True, dev)
+        _, pre = aum_hip.scan_tm_fwd(ut, dsp, A, Bt, Ct, D, zt, None, False, A_b=A_b, want_out_pre=True, ckpt=ck2)
+        bw_bytes = 8 * T * s + bc + 2 * Bsz * N * L * 4 + ck2.numel() * 4
+        rec("scan_tm_bwd_bidir", timeit(lambda: aum_hip.scan_tm_bwd(ut, dsp, A, Bt, Ct, D, zt, None, dot, pre, ck2, False, A_b=A_b), iters=5, warm=1), bw_bytes)
     if want("conv"):
         w = torch.randn(E, 4, device=dev)
         b = torch.randn(E, device=dev)
