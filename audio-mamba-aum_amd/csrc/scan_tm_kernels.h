@@ -441,7 +441,7 @@ AUM_DEV void scant_fwd(const AumScanTmFwdArgs& p, int wg, float* lds, unsigned l
 // first pass.
 // ================================================================================================
 template <class T> AUM_HOSTDEV constexpr int scant_bwd_lds_wave_floats() {
-    return 8 * ScanTTile<T>::FLOATS + 2 * SCANT_BC_BLOCK;      // u, delta, z, dout, ypre | du, ddelta, dz | B/C block | dB/dC block
+    return 9 * ScanTTile<T>::FLOATS + 2 * SCANT_BC_BLOCK;      // u, delta, z, dout, ypre | du, ddelta, dz | B/C block | dB/dC block | u (odd blocks)
 }
 // partials of one (batch entry, direction, channel group) wave
 struct ScanTBwdOut {
@@ -485,7 +485,10 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
               dz_tb = HAS_Z ? (int)p.dz_ts * ES : 0, B_tb = (int)p.B_ts * ES, C_tb = (int)p.C_ts * ES;
     const int dbc_tb = wo.nparts * (2 * N) * 4, dbc_col = part * (2 * N) * 4;
     auto tok = [&](int it) { return t0 + it * tstep; };
-    float* t_u = lds;
+    // u is read again in a block's last lines, after the next block's u arrived: two tiles, by block parity
+    float* t_u0 = lds;
+    float* t_u1 = lds + 8 * TL::FLOATS + 2 * SCANT_BC_BLOCK;
+    auto t_u_of = [&](int blk) { return (blk & 1) ? t_u1 : t_u0; };
     float* t_d = lds + TL::FLOATS;
     float* t_z = lds + 2 * TL::FLOATS;
     float* t_g = lds + 3 * TL::FLOATS;
@@ -502,6 +505,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     const vi el_off = lane * ES;
     const vi bc_slot = st_i * SCANT_BC_ROW + st_c * 2;
     const vi vo4 = ec * 4;
+    const vi dbc_slot = (((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 4) & 1)) * SCANT_BC_ROW + ((lane >> 5) & 1);
 
     // per-lane row of block `blk` in a global tensor: memory row st_r for blocks inside the phase (plus the scalar offset of the
     // block's lowest time step), the clamped row's time step for ragged ones
@@ -544,7 +548,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     auto fetch_block = [&](int blk) {
         const Rows r = rows_of(blk);
         ScanTStage<T> st;
-        load_tile(ubuf, u_tb, r, st); park_tile(t_u, st);
+        load_tile(ubuf, u_tb, r, st); park_tile(t_u_of(blk), st);
         load_tile(dbuf, d_tb, r, st); park_tile(t_d, st);
         load_tile(gbuf_, g_tb, r, st); park_tile(t_g, st);
         if (HAS_Z) {
@@ -576,26 +580,35 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
         const int s_hi = FULL ? SCANT_CK : (it1 < base + SCANT_CK ? it1 - base : SCANT_CK);
         const bool more = blk > blk_lo;
         // ---- per-step registers of the block; dz of its steps --------------------------------------------------
-        vf dl[SCANT_CK], uu[SCANT_CK], dy[SCANT_CK];
-        AUM_UNROLL
-        for (int s = 0; s < SCANT_CK; ++s) {
-            const vi off = el_off + s * ROWB;
-            uu[s] = raw_to_f32<T>(lds_read_raw<T>(t_u, off));
-            vf d = raw_to_f32<T>(lds_read_raw<T>(t_d, off)) + biasv;
-            if (SP) d = vsoftplus(d);
-            dl[s] = d;
-            const vf go = raw_to_f32<T>(lds_read_raw<T>(t_g, off));
-            if (HAS_Z) {
-                const vf zz = raw_to_f32<T>(lds_read_raw<T>(t_z, off));
-                const vf sg = vsigmoid(zz);
-                dy[s] = go * (zz * sg);
-                if (FINAL) {        // dz = dout ytot d(z sigmoid(z))/dz  (direction-independent: written by whoever finishes the step)
-                    const vf yt = raw_to_f32<T>(lds_read_raw<T>(t_y, off));
-                    lds_write_elem<T>(t_dz, off, go * yt * (sg * vfma(zz, splat(1.f) - sg, splat(1.f))));
+        // P[s] = (delta_s, delta_s u_s), Q[i] = (dy_2i, dy_2i+1): pairs of DIFFERENT values -- a packed instruction broadcasts either half
+        // of a register pair as an operand modifier, whereas a (d, d) operand kept across the pass loop is two registers
+        vf2 P[SCANT_CK], Q[SCANT_CK / 2];
+        float* const t_u = t_u_of(blk);
+        {
+            vf dyv[SCANT_CK];
+            AUM_UNROLL
+            for (int s = 0; s < SCANT_CK; ++s) {
+                const vi off = el_off + s * ROWB;
+                const vf us = raw_to_f32<T>(lds_read_raw<T>(t_u, off));
+                vf d = raw_to_f32<T>(lds_read_raw<T>(t_d, off)) + biasv;
+                if (SP) d = vsoftplus(d);
+                P[s] = mk2(d, d * us);
+                const vf go = raw_to_f32<T>(lds_read_raw<T>(t_g, off));
+                if (HAS_Z) {
+                    const vf zz = raw_to_f32<T>(lds_read_raw<T>(t_z, off));
+                    const vf sg = vsigmoid(zz);
+                    dyv[s] = go * (zz * sg);
+                    if (FINAL) {        // dz = dout ytot d(z sigmoid(z))/dz  (direction-independent: written by whoever finishes the step)
+                        const vf yt = raw_to_f32<T>(lds_read_raw<T>(t_y, off));
+                        lds_write_elem<T>(t_dz, off, go * yt * (sg * vfma(zz, splat(1.f) - sg, splat(1.f))));
+                    }
+                } else {
+                    dyv[s] = go;
                 }
-            } else {
-                dy[s] = go;
+                AUM_SCHED_FENCE();      // step by step: interleaved, the eight steps' temporaries do not fit beside the carries
             }
+            AUM_UNROLL
+            for (int i = 0; i < SCANT_CK / 2; ++i) Q[i] = mk2(dyv[2 * i], dyv[2 * i + 1]);
         }
         vf S1[SCANT_CK], S2[SCANT_CK];
         AUM_UNROLL
@@ -619,7 +632,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             // next block: one tensor requested per pass, parked at the top of the next pass (its tile is free since the registers
             // above were filled)
             if (more) {
-                if (j == 1) park_tile(t_u, st);
+                if (j == 1) park_tile(t_u_of(blk - 1), st);
                 if (j == 2) park_tile(t_d, st);
                 if (j == 3) park_tile(t_g, st);
                 if (HAS_Z && j == 4) park_tile(t_z, st);
@@ -642,6 +655,12 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                 if (j == 6) load_tile(ddbuf, dd_tb, rc, st);
             }
             AUM_SCHED_FENCE();        // passes are scheduled one by one: across them the scheduler's reordering costs registers (2.5 KB of scratch)
+            // the per-step values are loop invariants, and a packed operand (d, d) built OUTSIDE the loop is a real register pair
+            // (48 registers for 24 values); opaque to the compiler here, the broadcast is an operand modifier of the packed instruction
+            AUM_UNROLL
+            for (int s = 0; s < SCANT_CK; ++s) pin_value2(P[s]);
+            AUM_UNROLL
+            for (int i = 0; i < SCANT_CK / 2; ++i) pin_value2(Q[i]);
             vf2 x = xnext;
             const vf2 A2j = Anext * spl2(splat(LOG2E));
             if (j + 1 < N / 2) {
@@ -664,11 +683,11 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                 if (FULL || s < s_hi) {
                     vf q[2];
                     lds_read2_u(t_bc, s * SCANT_BC_ROW + 2 * j, q);
-                    const vf2 a = vexp2_2(spl2(dl[s]) * A2j);
+                    const vf2 a = vexp2_2(bc_lo(P[s]) * A2j);
                     w[s] = a * x;
-                    x = vfma2(spl2(dl[s] * uu[s]), mk2(q[0], q[1]), w[s]);
+                    x = vfma2(bc_hi(P[s]), mk2(q[0], q[1]), w[s]);
                     if (FULL || s >= s_lo) {
-                        const vf2 pcs = spl2(dy[s]) * x;
+                        const vf2 pcs = ((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1])) * x;
                         pc[2 * s] = lo2(pcs);
                         pc[2 * s + 1] = hi2(pcs);
                     }
@@ -690,9 +709,9 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                     vf qb[2], qc[2];
                     lds_read2_u(t_bc, s * SCANT_BC_ROW + 2 * j, qb);
                     lds_read2_u(t_bc, s * SCANT_BC_ROW + N + 2 * j, qc);
-                    const vf2 a = vexp2_2(spl2(dl[s]) * A2r);
-                    const vf2 g = vfma2(spl2(dy[s]), mk2(qc[0], qc[1]), hj);
-                    const vf2 pbs = g * spl2(dl[s] * uu[s]);
+                    const vf2 a = vexp2_2(bc_lo(P[s]) * A2r);
+                    const vf2 g = vfma2((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1]), mk2(qc[0], qc[1]), hj);
+                    const vf2 pbs = g * bc_hi(P[s]);
                     pb[2 * s] = lo2(pbs);
                     pb[2 * s + 1] = hi2(pbs);
                     const vf2 gb = g * mk2(qb[0], qb[1]);
@@ -702,17 +721,17 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                     const vf2 ar = A2j * r;
                     S2[s] = S2[s] + (lo2(ar) + hi2(ar));
                     pin_value(S2[s]);
-                    dAj = vfma2(spl2(dl[s]), r, dAj);
+                    dAj = vfma2(bc_lo(P[s]), r, dAj);
                     hj = a * g;
                 }
             }
             AUM_SCHED_FENCE();
             const vf dBsum = wave_sum16(pb);
-            // lane l < 16 holds the totals of (step l >> 1, state 2j + (l & 1))
+            // lane l holds the totals of value k = wave_sum16_value_of_lane(l) = (step k >> 1, state 2j + (k & 1)); one lane per quad writes
             {
-                const vi slot = (lane >> 1) * SCANT_BC_ROW + (lane & 1) + 2 * j;
-                lds_write_m(t_dbc, slot, dBsum, lane < 16);
-                lds_write_m(t_dbc, slot + N, dCsum, lane < 16);
+                const vi slot = dbc_slot + 2 * j;
+                lds_write_m(t_dbc, slot, dBsum, (lane & 3) == 0);
+                lds_write_m(t_dbc, slot + N, dCsum, (lane & 3) == 0);
             }
             vf16_set(hh, 2 * j, lo2(hj));
             vf16_set(hh, 2 * j + 1, hi2(hj));
@@ -725,20 +744,23 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
         for (int s = 0; s < SCANT_CK; ++s) {
             if (FULL || (s >= s_lo && s < s_hi)) {
                 const vi off = el_off + s * ROWB;
-                vf du = dl[s] * S1[s];
-                vf dd = vfma(uu[s], S1[s], S2[s] * LN2);
+                const vf dls = lo2(P[s]), dys = (s & 1) ? hi2(Q[s >> 1]) : lo2(Q[s >> 1]);
+                const vf us = raw_to_f32<T>(lds_read_raw<T>(t_u, off));
+                vf du = dls * S1[s];
+                vf dd = vfma(us, S1[s], S2[s] * LN2);
                 if (FINAL) {
-                    du = vfma(Dv, dy[s], du);
-                    dDacc = vfma(dy[s], uu[s], dDacc);
+                    du = vfma(Dv, dys, du);
+                    dDacc = vfma(dys, us, dDacc);
                     if (LD_PART) {
                         du = du + raw_to_f32<T>(lds_read_raw<T>(t_du, off));
                         dd = dd + raw_to_f32<T>(lds_read_raw<T>(t_dd, off));
                     }
-                    if (SP) dd = dd * (splat(1.f) - vexp2(dl[s] * (-LOG2E)));      // sigmoid(raw) = 1 - exp(-softplus(raw))
+                    if (SP) dd = dd * (splat(1.f) - vexp2(dls * (-LOG2E)));      // sigmoid(raw) = 1 - exp(-softplus(raw))
                     dbacc = dbacc + dd;
                 }
                 lds_write_elem<T>(t_du, off, du);
                 lds_write_elem<T>(t_dd, off, dd);
+                AUM_SCHED_FENCE();
             }
         }
         wave_lds_fence();

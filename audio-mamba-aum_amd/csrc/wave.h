@@ -251,6 +251,10 @@ AUM_DEV vi opaque_i(vi x) { asm volatile("" : "+v"(x)); return x; }
 // the value exists in a register HERE: keeps the optimiser from sinking a chain of accumulator updates to their distant use (and
 // carrying the operands of all of them in between)
 AUM_DEV void pin_value(vf& x) { asm volatile("" : "+v"(x)); }
+AUM_DEV void pin_value2(vf2& x) { asm volatile("" : "+v"(x)); }
+// (lo, lo) / (hi, hi) of a pair: operand modifiers (op_sel) of the packed instruction that consumes them
+AUM_DEV vf2 bc_lo(vf2 a) { return __builtin_shufflevector(a, a, 0, 0); }
+AUM_DEV vf2 bc_hi(vf2 a) { return __builtin_shufflevector(a, a, 1, 1); }
 // sixteen per-lane values addressed by a wave-uniform RUN-TIME index: a register vector the compiler indexes through M0
 // (s_set_gpr_idx / v_movrel), so a loop over state pairs need not be unrolled to keep its per-pair carries in registers
 struct vf16 { float __attribute__((ext_vector_type(16))) r; };
@@ -561,6 +565,9 @@ inline vf writelane(const vf& v, float s, int lane) { vf r = v; r.v[lane] = s; r
 template <class T> inline float gload_s(const T* p, int idx) { return elem_to_f32(p[idx]); }
 inline vi opaque_i(const vi& x) { return x; }
 inline void pin_value(vf&) {}
+inline void pin_value2(vf2&) {}
+inline vf2 bc_lo(const vf2& a) { return vf2{a.x, a.x}; }
+inline vf2 bc_hi(const vf2& a) { return vf2{a.y, a.y}; }
 struct vf16 { vf v[16]; };
 inline vf vf16_get(const vf16& a, int i) { return a.v[i]; }
 inline void vf16_set(vf16& a, int i, const vf& v) { a.v[i] = v; }
@@ -831,13 +838,19 @@ AUM_DEV float wave_sum(vf x) {
 // v_permlane16_swap, and the last level adds the two halves of the wave (v_permlane32_swap).
 // ------------------------------------------------------------------------------------------------
 constexpr int wave_sum32_value_of_lane(int l) { return 2 * (l & 15) + ((l >> 4) & 1); }
-// the same for 16 values: lane l holds the total of value l & 15 (every 16-lane row holds all sixteen)
+// The same for 16 values, in place and without temporaries: lane l holds the total of value
+// 8 * bit3(l) + 4 * bit2(l) + 2 * bit4(l) + bit5(l) (the four lanes of a quad hold the same total).  The two widest levels pair lanes
+// inside a 16-lane row and are ONE masked v_add_f32_dpp per lane half and result (bank_mask write-enables the lanes whose bit
+// selects the value; the others keep what they have): 2 instructions per result instead of two selects, a move and an add.  The
+// next two levels cross rows with v_permlane16_swap / v_permlane32_swap, which exchange exactly the halves a transposing level
+// hands over; bits 1 and 0 are plain sums.  32 instructions for 16 values.
+constexpr int wave_sum16_value_of_lane(int l) { return 8 * ((l >> 3) & 1) + 4 * ((l >> 2) & 1) + 2 * ((l >> 4) & 1) + ((l >> 5) & 1); }
 #ifdef AUM_EMU
 inline vf wave_sum16(vf (&v)[16]) {
     vf r;
     AUM_LANES {
         float acc = 0.f;
-        for (int m = 0; m < WAVE; ++m) acc += v[l & 15].v[m];
+        for (int m = 0; m < WAVE; ++m) acc += v[wave_sum16_value_of_lane(l)].v[m];
         r.v[l] = acc;
     }
     return r;
@@ -880,26 +893,58 @@ AUM_DEV void wave_sum_low3(vf (&v)[32], int lane) {
         v[0] = keep + dpp_fetch<0xB1>(send);
     }
 }
-AUM_DEV vf wave_sum16(vf (&v16)[16]) {
-    const int lane = (int)(threadIdx.x & 63u);
-    vf v[32];
-    {   // bit 3 (xor 8: row_ror:8), 8 results
-        const bool up = (lane & 8) != 0;
-        AUM_UNROLL
-        for (int i = 0; i < 8; ++i) {
-            const vf keep = up ? v16[8 + i] : v16[i], send = up ? v16[i] : v16[8 + i];
-            v[i] = keep + dpp_fetch<0x128>(send);
-        }
-    }
-    wave_sum_low3(v, lane);
-    vf r = v[0];
-    {   // rows: xor 16, then xor 32 (plain sums: every row ends with all sixteen totals)
-        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, r), __builtin_bit_cast(unsigned, r), false, false);
-        r = r + __builtin_bit_cast(float, (lane & 16) ? sw[0] : sw[1]);
-        const auto sx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, r), __builtin_bit_cast(unsigned, r), false, false);
-        r = r + __builtin_bit_cast(float, (lane & 32) ? sx[0] : sx[1]);
-    }
-    return r;
+AUM_DEV vf wave_sum16(vf (&v)[16]) {
+    // levels over lane bits 3 and 2.  Inline assembly is not covered by the compiler's hazard recogniser: a DPP or permlane read
+    // needs two wait states after a VALU write of the same register, hence the s_nop at both ends and around the swaps; in the DPP
+    // levels no instruction reads a register written by one of the two before it.  (The swaps are written here as well: the
+    // builtin with two DIFFERENT operands came back from the compiler as a sum of the first result with itself.)
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        // bit 4: v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second, so the sum of the
+        // two results is (value i summed over the row pair) in even rows and (value i + 2) in odd rows; bit 5 likewise with the
+        // halves of the wave (v_permlane32_swap); bits 1 and 0 are plain sums inside a quad
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %2\n\t"
+        "v_permlane16_swap_b32 %1, %3\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32 %0, %0, %2\n\t"
+        "v_add_f32 %1, %1, %3\n\t"
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32 %0, %0, %1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+        : "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    return v[0];
 }
 AUM_DEV vf wave_sum32(vf (&v)[32]) {
     const int lane = (int)(threadIdx.x & 63u);

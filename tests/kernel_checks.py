@@ -151,7 +151,8 @@ def check_wave_sum32(lib, dev):
     got = N(aum_hip.selftest_wave_sum32(T(v, dev), lib=lib))
     ref = np.array([v[2 * (l & 15) + ((l >> 4) & 1)].astype(np.float64).sum() for l in range(64)])
     assert rel_err(got[0], ref) < 1e-5, ("wave_sum32", got[0], ref)
-    ref16 = np.array([v[l & 15].astype(np.float64).sum() for l in range(64)])
+    k16 = lambda l: 8 * ((l >> 3) & 1) + 4 * ((l >> 2) & 1) + 2 * ((l >> 4) & 1) + ((l >> 5) & 1)      # wave_sum16_value_of_lane
+    ref16 = np.array([v[k16(l)].astype(np.float64).sum() for l in range(64)])
     assert rel_err(got[1], ref16) < 1e-5, ("wave_sum16", got[1], ref16)
 
 
