@@ -436,12 +436,16 @@ AUM_DEV void scant_fwd(const AumScanTmFwdArgs& p, int wg, float* lds, unsigned l
 // Fo-Bi: the two direction waves of a channel group walk time in opposite order; as in the forward each first writes its half of
 // du / ddelta as partials, they meet at one barrier, and each then finishes the other's half (adding the partial, applying the
 // softplus derivative, dz, dD, ddelta_bias).
-// Memory: tiles as in the forward.  The next block's tensors are requested ONE PER PASS (four registers in flight) and parked a
-// pass later -- the input tiles are free by then, because a block turns them into per-step registers (delta, u, dy) before its
-// first pass.
+// Memory: every tensor of a block arrives by global -> LDS loads that bypass the registers (buffer_load ... lds), issued a whole
+// block (eight passes) ahead: the input tiles are free as soon as a block has turned them into per-step registers (delta, delta u,
+// dy) before its first pass, the checkpointed entry states of the next block replace the current block's rows pair by pair as the
+// passes consume them, and A sits in LDS for the whole kernel.  Loads parked through registers one pass ahead cost 0.6 ms of a
+// 1.4 ms kernel: one pass is shorter than a loaded HBM round trip and two waves per SIMD cannot hide the difference.
+// LDS tiles are planes of 8 rows x 128 bytes (lane l's 16 bytes of a load at l * 16), the order the direct loads write in.
 // ================================================================================================
 template <class T> AUM_HOSTDEV constexpr int scant_bwd_lds_wave_floats() {
-    return 9 * ScanTTile<T>::FLOATS + 2 * SCANT_BC_BLOCK;      // u, delta, z, dout, ypre | du, ddelta, dz | B/C block | dB/dC block | u (odd blocks)
+    // u, delta, z, dout, ypre | du, ddelta, dz | B/C block | dB/dC block | u (odd blocks) | entry states [16][64] | A [16][64] | raw B, C pairs
+    return 9 * ScanTTile<T>::FLOATS + 2 * SCANT_BC_BLOCK + 2 * SCANT_N * WAVE + 2 * ScanTTile<T>::NLD * WAVE;
 }
 // partials of one (batch entry, direction, channel group) wave
 struct ScanTBwdOut {
@@ -450,21 +454,24 @@ struct ScanTBwdOut {
     float* dD;         // [ndir][batch][dim]
     float* dbias;      // [ndir][batch][dim]
     int nparts;
+    unsigned long long* trace;      // -DAUM_SCANT_TRACE builds (tools/tm_trace.py): 16 x uint64 per wave behind the partials; else unused
 };
 
+#ifndef AUM_SCANT_BABL
+#define AUM_SCANT_BABL 0      // timing experiments only (wrong results): 1 no butterflies, 2 no exponentials, 4 carries at a fixed register index,
+#endif                        // 8 no loads of the next block, 16 no entry-state loads, 32 no B/C reads from LDS
 template <class T, int N, int PHASE, bool SP, bool HAS_Z>
 AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int b, int e0, int dir, int part, int t0, int tstep, int it0,
-                           int it1, const float* Aptr, float dmul, vf16& hh, vf16& dAacc, vf& dDacc, vf& dbacc, float* lds) {
+                           int it1, const float* Aptr, float dmul, vf16& hh, vf16& dAacc, vf& dDacc, vf& dbacc, float* lds,
+                           unsigned long long* tacc = nullptr) {
     using TL = ScanTTile<T>;
-    constexpr int ES = TL::ES, ROWB = TL::ROWB, NLD = TL::NLD;
+    constexpr int ES = TL::ES, NLD = TL::NLD;
+    constexpr int LROW = 128, PLANE = SCANT_CK * LROW;          // bytes: a tile row segment, a plane of eight of them
     constexpr bool FINAL = PHASE != 1, LD_PART = PHASE == 2;
     static_assert(N == 16 && SCANT_CK == 8, "8 steps x 8 state pairs");
     const int L = p.len;
     const vi lane = lane_id();
     const vi ec = lane + e0;
-    // A of a state pair is fetched a pass ahead (two loads that hit L1/L2) rather than held for all sixteen states: the registers go to
-    // the block's per-step values
-    auto load_A = [&](int j_) { return mk2(gload_u(Aptr, ec * N + 2 * j_), gload_u(Aptr, ec * N + 2 * j_ + 1)); };
     const vf biasv = p.delta_bias ? gload_u(p.delta_bias, ec) : splat(0.f);
     const vf Dv = p.D ? gload_u(p.D, ec) * dmul : splat(0.f);
     const gbuf<T> ubuf = make_gbuf(row_ptr<T>(p.u, (int64_t)b * p.u_bs));
@@ -477,6 +484,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     const gbuf<T> dzbuf = make_gbuf(HAS_Z ? row_ptr<T>(p.dz, (int64_t)b * p.dz_bs) : row_ptr<T>(p.du, 0));
     const gbuf<T> Bbuf = make_gbuf(row_ptr<T>(p.B, (int64_t)b * p.B_bs));
     const gbuf<T> Cbuf = make_gbuf(row_ptr<T>(p.C, (int64_t)b * p.C_bs));
+    const gbuf<float> Abuf = make_gbuf(Aptr);
     const int nck = scant_nck(L);
     const gbuf<float> ckbuf = make_gbuf(p.ckpt + ((int64_t)dir * p.batch + b) * (nck > 0 ? nck : 1) * N * p.dim);
     const gbuf<float> dbcbuf = make_gbuf(wo.dbc + (int64_t)b * L * wo.nparts * (2 * N));
@@ -487,8 +495,6 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     auto tok = [&](int it) { return t0 + it * tstep; };
     // u is read again in a block's last lines, after the next block's u arrived: two tiles, by block parity
     float* t_u0 = lds;
-    float* t_u1 = lds + 8 * TL::FLOATS + 2 * SCANT_BC_BLOCK;
-    auto t_u_of = [&](int blk) { return (blk & 1) ? t_u1 : t_u0; };
     float* t_d = lds + TL::FLOATS;
     float* t_z = lds + 2 * TL::FLOATS;
     float* t_g = lds + 3 * TL::FLOATS;
@@ -498,11 +504,19 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     float* t_dz = lds + 7 * TL::FLOATS;
     float* t_bc = lds + 8 * TL::FLOATS;
     float* t_dbc = t_bc + SCANT_BC_BLOCK;
-    const vi st_r = lane >> 3, st_c = lane & 7;
-    const vi st_i = tstep > 0 ? st_r : (SCANT_CK - 1) - st_r;
+    float* t_u1 = t_dbc + SCANT_BC_BLOCK;
+    float* t_ck = t_u1 + TL::FLOATS;               // entry state of the block: row n = state n, one float per lane
+    float* t_A = t_ck + N * WAVE;                  // A[e][n] likewise
+    float* t_rawB = t_A + N * WAVE;                // the next block's B / C pairs as loaded (NLD dwords per lane and tensor)
+    float* t_rawC = t_rawB + NLD * WAVE;
+    auto t_u_of = [&](int blk) { return (blk & 1) ? t_u1 : t_u0; };
+    // lane = (row st_i, 16-byte column st_c) of a 8 x 128-byte plane; the row is the block's step st_i IN ITERATION ORDER, which a
+    // reversed direction finds at memory row 7 - st_i of the block
+    const vi st_i = lane >> 3, st_c = lane & 7;
+    const vi st_r = tstep > 0 ? st_i : (SCANT_CK - 1) - st_i;
     const vi st_gcol = st_c * 16 + e0 * ES;
-    const vi st_lds = st_i * ROWB + st_c * 16;
-    const vi el_off = lane * ES;
+    const vi st_lds = lane * 16;
+    const vi el_off = ((lane * ES) >> 7) * PLANE + ((lane * ES) & (LROW - 1));       // this lane's channel in row 0 of a tile
     const vi bc_slot = st_i * SCANT_BC_ROW + st_c * 2;
     const vi vo4 = ec * 4;
     const vi dbc_slot = (((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 4) & 1)) * SCANT_BC_ROW + ((lane >> 5) & 1);
@@ -528,50 +542,65 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
         }
         return r;
     };
-    auto load_tile = [&](const gbuf<T>& buf, int tb, const Rows& r, ScanTStage<T>& st) {
+    auto load_tile = [&](const gbuf<T>& buf, int tb, const Rows& r, float* tile) {
         AUM_UNROLL
-        for (int i = 0; i < NLD; ++i) st.q[i] = gbuf_load16(buf, r.rowt * tb + st_gcol + 128 * i, r.t_lo * tb);
-    };
-    auto park_tile = [&](float* tile, const ScanTStage<T>& st) {
-        AUM_UNROLL
-        for (int i = 0; i < NLD; ++i) lds_write16(tile, st_lds + 128 * i, st.q[i]);
+        for (int i = 0; i < NLD; ++i) gbuf_load16_lds(buf, r.rowt * tb + st_gcol + LROW * i, r.t_lo * tb, tile + (PLANE / 4) * i);
     };
     auto store_tile = [&](const gbuf<T>& buf, int tb, const float* tile, const Rows& r) {
         AUM_UNROLL
         for (int i = 0; i < NLD; ++i) {
-            const vq q = lds_read16(tile, st_lds + 128 * i);
-            if (r.inside) gbuf_store16(buf, r.rowt * tb + st_gcol + 128 * i, r.t_lo * tb, q);
-            else gbuf_store16_m(buf, r.rowt * tb + st_gcol + 128 * i, 0, q, r.valid);
+            const vq q = lds_read16(tile, st_lds + PLANE * i);
+            if (r.inside) gbuf_store16(buf, r.rowt * tb + st_gcol + LROW * i, r.t_lo * tb, q);
+            else gbuf_store16_m(buf, r.rowt * tb + st_gcol + LROW * i, 0, q, r.valid);
         }
     };
-    // everything block `blk` needs, fetched in one go (the prologue of a phase)
-    auto fetch_block = [&](int blk) {
-        const Rows r = rows_of(blk);
-        ScanTStage<T> st;
-        load_tile(ubuf, u_tb, r, st); park_tile(t_u_of(blk), st);
-        load_tile(dbuf, d_tb, r, st); park_tile(t_d, st);
-        load_tile(gbuf_, g_tb, r, st); park_tile(t_g, st);
+    // the input tensors of block `blk` (7 x NLD loads); B / C as the pairs each lane will convert
+    auto request_block = [&](int blk, const Rows& r) {
+        load_tile(ubuf, u_tb, r, t_u_of(blk));
+        load_tile(dbuf, d_tb, r, t_d);
+        load_tile(gbuf_, g_tb, r, t_g);
         if (HAS_Z) {
-            load_tile(zbuf, z_tb, r, st); park_tile(t_z, st);
-            load_tile(ybuf, y_tb, r, st); park_tile(t_y, st);
+            load_tile(zbuf, z_tb, r, t_z);
+            load_tile(ybuf, y_tb, r, t_y);
         }
+        AUM_UNROLL
+        for (int i = 0; i < NLD; ++i) {
+            gbuf_load4_lds(Bbuf, r.rowt * B_tb + st_c * (2 * ES) + 4 * i, r.t_lo * B_tb, t_rawB + WAVE * i);
+            gbuf_load4_lds(Cbuf, r.rowt * C_tb + st_c * (2 * ES) + 4 * i, r.t_lo * C_tb, t_rawC + WAVE * i);
+        }
+    };
+    // rows [n0, n1) of the entry state of block `blk` (the checkpoint after block blk - 1; zero for the first block)
+    auto request_entry = [&](int blk, int n0, int n1) {
+        if (AUM_SCANT_BABL & 16) return;
+        for (int n = n0; n < n1; ++n) {
+            if (blk > 0) gbuf_load4_lds(ckbuf, vo4, ((blk - 1) * N + n) * p.dim * 4, t_ck + n * WAVE);
+            else lds_write(t_ck, lane + n * WAVE, splat(0.f));
+        }
+    };
+    // the raw B / C pairs in LDS -> fp32 [step][B_0..15 | C_0..15]
+    auto convert_bc = [&]() {
         vf b0, b1, c0, c1;
-        pair_raw_to_f32<T>(gbuf_load_pair_raw(Bbuf, r.rowt * B_tb + st_c * (2 * ES), r.t_lo * B_tb), b0, b1);
-        pair_raw_to_f32<T>(gbuf_load_pair_raw(Cbuf, r.rowt * C_tb + st_c * (2 * ES), r.t_lo * C_tb), c0, c1);
+        lds_pair_to_f32<T>(t_rawB, b0, b1);
+        lds_pair_to_f32<T>(t_rawC, c0, c1);
         lds_write2(t_bc, bc_slot, b0, b1);
         lds_write2(t_bc, bc_slot + N, c0, c1);
-        wave_lds_fence();
     };
 
     if (it0 >= it1) return;
     const int blk_lo = it0 / SCANT_CK, blk_hi = (it1 + SCANT_CK - 1) / SCANT_CK;       // blocks blk_hi-1 down to blk_lo
-    fetch_block(blk_hi - 1);
-    vf2 Afirst = load_A(0);
-    vf2 xfirst = spl2(splat(0.f));       // entry state of the next block to process, first pair (requested a block ahead)
-    if (blk_hi - 1 > 0) {
-        const int off = (blk_hi - 2) * N * p.dim * 4;
-        xfirst = mk2(gbuf_load(ckbuf, vo4, off), gbuf_load(ckbuf, vo4, off + p.dim * 4));
-    }
+#if defined(AUM_SCANT_TRACE) && !defined(AUM_EMU)
+#define AUM_TMB_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - stamp_; stamp_ = now_; } while (0)
+    unsigned long long stamp_ = __builtin_readcyclecounter();
+#else
+#define AUM_TMB_STAMP(k) do { } while (0)
+#endif
+    // prologue of the phase: everything the first block needs, and A
+    wave_lds_fence();
+    request_block(blk_hi - 1, rows_of(blk_hi - 1));
+    request_entry(blk_hi - 1, 0, N);
+    for (int n = 0; n < N; ++n) gbuf_load4_lds(Abuf, ec * (N * 4), n * 4, t_A + n * WAVE);
+    constexpr int NST = 2 * NLD + ((HAS_Z && FINAL) ? NLD : 0) + 1;       // stores at the end of a block: du, ddelta, dz, dB/dC
+    AUM_TMB_STAMP(0);
     // one block; FULL: all eight steps belong to the phase (no per-step conditions)
     auto do_block = [&](auto full_tag, int blk) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -579,6 +608,12 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
         const int s_lo = FULL ? 0 : (it0 > base ? it0 - base : 0);                       // steps [s_lo, s_hi) of the block are this phase's
         const int s_hi = FULL ? SCANT_CK : (it1 < base + SCANT_CK ? it1 - base : SCANT_CK);
         const bool more = blk > blk_lo;
+        const bool cknext = more && blk - 1 > 0;        // the next block has a checkpoint to fetch (else its entry rows are zeroed)
+        // the block's loads are the oldest operations in flight: all but the previous block's stores have to be back
+        if (blk == blk_hi - 1) AUM_WAIT_VM(0);
+        else AUM_WAIT_VM(NST);
+        wave_lds_fence();
+        convert_bc();
         // ---- per-step registers of the block; dz of its steps --------------------------------------------------
         // P[s] = (delta_s, delta_s u_s), Q[i] = (dy_2i, dy_2i+1): pairs of DIFFERENT values -- a packed instruction broadcasts either half
         // of a register pair as an operand modifier, whereas a (d, d) operand kept across the pass loop is two registers
@@ -588,7 +623,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             vf dyv[SCANT_CK];
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) {
-                const vi off = el_off + s * ROWB;
+                const vi off = el_off + s * LROW;
                 const vf us = raw_to_f32<T>(lds_read_raw<T>(t_u, off));
                 vf d = raw_to_f32<T>(lds_read_raw<T>(t_d, off)) + biasv;
                 if (SP) d = vsoftplus(d);
@@ -610,50 +645,43 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             AUM_UNROLL
             for (int i = 0; i < SCANT_CK / 2; ++i) Q[i] = mk2(dyv[2 * i], dyv[2 * i + 1]);
         }
-        vf S1[SCANT_CK], S2[SCANT_CK];
+        vf2 S1[SCANT_CK], S2[SCANT_CK];      // per state PAIR: one packed fma per step and sum; the two halves are added once per block
         AUM_UNROLL
-        for (int s = 0; s < SCANT_CK; ++s) S1[s] = S2[s] = splat(0.f);
+        for (int s = 0; s < SCANT_CK; ++s) S1[s] = S2[s] = spl2(splat(0.f));
         wave_lds_fence();
-        const Rows rn = rows_of(more ? blk - 1 : blk);
         const Rows rc = rows_of(blk);
-        ScanTStage<T> st;                 // the tensor in flight during a pass
-        vpair_raw bpn, cpn;
-        // entry state of the block for the first pair; the later pairs' a pass ahead
-        auto load_entry = [&](int blk_, int j_) {
-            if (blk_ <= 0) return spl2(splat(0.f));
-            const int off = ((blk_ - 1) * N + 2 * j_) * p.dim * 4;
-            return mk2(gbuf_load(ckbuf, vo4, off), gbuf_load(ckbuf, vo4, off + p.dim * 4));
-        };
-        vf2 xnext = xfirst, Anext = Afirst;
+        // the input tiles are registers now: the next block's tensors, and (second phase) the other direction's partial du / ddelta of
+        // THIS block into the output tiles, which idle until the block's last lines
+        if (!(AUM_SCANT_BABL & 8)) {
+            if (more) request_block(blk - 1, rows_of(blk - 1));
+            if (LD_PART) {
+                load_tile(dubuf, du_tb, rc, t_du);
+                load_tile(ddbuf, dd_tb, rc, t_dd);
+            }
+        }
+        AUM_TMB_STAMP(1);
         // ---- passes over the state pairs: a real loop (unrolled, the optimiser spread its work over all eight passes and needed more
         // than 340 registers); the pairs' carries sit in register vectors indexed by the loop counter
         _Pragma("nounroll")
         for (int j = 0; j < N / 2; ++j) {
-            // next block: one tensor requested per pass, parked at the top of the next pass (its tile is free since the registers
-            // above were filled)
-            if (more) {
-                if (j == 1) park_tile(t_u_of(blk - 1), st);
-                if (j == 2) park_tile(t_d, st);
-                if (j == 3) park_tile(t_g, st);
-                if (HAS_Z && j == 4) park_tile(t_z, st);
-                if (HAS_Z && j == 5) park_tile(t_y, st);
-                if (j == 0) load_tile(ubuf, u_tb, rn, st);
-                if (j == 1) load_tile(dbuf, d_tb, rn, st);
-                if (j == 2) load_tile(gbuf_, g_tb, rn, st);
-                if (HAS_Z && j == 3) load_tile(zbuf, z_tb, rn, st);
-                if (HAS_Z && j == 4) load_tile(ybuf, y_tb, rn, st);
-                if (j == 6) {
-                    bpn = gbuf_load_pair_raw(Bbuf, rn.rowt * B_tb + st_c * (2 * ES), rn.t_lo * B_tb);
-                    cpn = gbuf_load_pair_raw(Cbuf, rn.rowt * C_tb + st_c * (2 * ES), rn.t_lo * C_tb);
+            // B and C of the pass's state pair for all eight steps, the pair's entry state and A, requested before anything else: the
+            // exponentials cover their latency (read step by step inside the sweeps, every read was waited for on the spot:
+            // twelve LDS round trips per pass in a chain that two waves per SIMD cannot hide)
+            // (the LDS answers in order: A first, the exponentials wait for nothing else)
+            const vf2 Aj = mk2(lds_read(t_A, lane + (2 * j) * WAVE), lds_read(t_A, lane + (2 * j + 1) * WAVE));
+            vf2 x = mk2(lds_read(t_ck, lane + (2 * j) * WAVE), lds_read(t_ck, lane + (2 * j + 1) * WAVE));
+            vf qb[SCANT_CK][2], qc[SCANT_CK][2];
+            AUM_UNROLL
+            for (int s = 0; s < SCANT_CK; ++s) {
+                if (AUM_SCANT_BABL & 32) {
+                    qb[s][0] = qb[s][1] = qc[s][0] = qc[s][1] = biasv;
+                    continue;
                 }
+                lds_read2_u(t_bc, s * SCANT_BC_ROW + 2 * j, qb[s]);
+                lds_read2_u(t_bc, s * SCANT_BC_ROW + N + 2 * j, qc[s]);
             }
-            // the other direction's partial du / ddelta of THIS block (second phase): their tiles are idle until the block's last lines
-            if (LD_PART) {
-                if (j == 6) park_tile(t_du, st);
-                if (j == 7) park_tile(t_dd, st);
-                if (j == 5) load_tile(dubuf, du_tb, rc, st);
-                if (j == 6) load_tile(ddbuf, dd_tb, rc, st);
-            }
+            const vf2 A2j = Aj * spl2(splat(LOG2E));
+            AUM_TMB_STAMP(2);
             AUM_SCHED_FENCE();        // passes are scheduled one by one: across them the scheduler's reordering costs registers (2.5 KB of scratch)
             // the per-step values are loop invariants, and a packed operand (d, d) built OUTSIDE the loop is a real register pair
             // (48 registers for 24 values); opaque to the compiler here, the broadcast is an operand modifier of the packed instruction
@@ -661,18 +689,13 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             for (int s = 0; s < SCANT_CK; ++s) pin_value2(P[s]);
             AUM_UNROLL
             for (int i = 0; i < SCANT_CK / 2; ++i) pin_value2(Q[i]);
-            vf2 x = xnext;
-            const vf2 A2j = Anext * spl2(splat(LOG2E));
-            if (j + 1 < N / 2) {
-                xnext = load_entry(blk, j + 1);
-                Anext = load_A(j + 1);
-            } else {
-                if (more) xfirst = load_entry(blk - 1, 0);
-                Afirst = load_A(0);
-            }
-            vf2 hj = mk2(vf16_get(hh, 2 * j), vf16_get(hh, 2 * j + 1)), dAj = mk2(vf16_get(dAacc, 2 * j), vf16_get(dAacc, 2 * j + 1));
-            vf2 w[SCANT_CK];
+            const int jr = (AUM_SCANT_BABL & 4) ? 0 : j;
+            vf2 hj = mk2(vf16_get(hh, 2 * jr), vf16_get(hh, 2 * jr + 1)), dAj = mk2(vf16_get(dAacc, 2 * jr), vf16_get(dAacc, 2 * jr + 1));
+            vf2 w[SCANT_CK], a[SCANT_CK];
             vf pc[16], pb[16];
+            // a = exp2(delta A2) of the eight steps: independent of the recurrences, used by both sweeps
+            AUM_UNROLL
+            for (int s = 0; s < SCANT_CK; ++s) a[s] = (AUM_SCANT_BABL & 2) ? bc_lo(P[s]) * A2j : vexp2_2(bc_lo(P[s]) * A2j);
             // forward sweep: steps 0 .. s_hi-1
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) {
@@ -681,11 +704,8 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                     pb[2 * s] = pb[2 * s + 1] = splat(0.f);
                 }
                 if (FULL || s < s_hi) {
-                    vf q[2];
-                    lds_read2_u(t_bc, s * SCANT_BC_ROW + 2 * j, q);
-                    const vf2 a = vexp2_2(bc_lo(P[s]) * A2j);
-                    w[s] = a * x;
-                    x = vfma2(bc_hi(P[s]), mk2(q[0], q[1]), w[s]);
+                    w[s] = a[s] * x;
+                    x = vfma2(bc_hi(P[s]), mk2(qb[s][0], qb[s][1]), w[s]);
                     if (FULL || s >= s_lo) {
                         const vf2 pcs = ((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1])) * x;
                         pc[2 * s] = lo2(pcs);
@@ -693,61 +713,64 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                     }
                 }
             }
+            // the entry rows this pass consumed make room for the next block's (fourteen of the sixteen here, the last pair at the end
+            // of the block -- AUM_WAIT_VM there counts on exactly these loads being the youngest)
+            if (cknext && j < N / 2 - 1) request_entry(blk - 1, 2 * j, 2 * j + 2);
             AUM_SCHED_FENCE();
-            const vf dCsum = wave_sum16(pc);
+            AUM_TMB_STAMP(3);
+            const vf dCsum = (AUM_SCANT_BABL & 1) ? pc[0] + pc[5] : wave_sum16(pc);
             AUM_SCHED_FENCE();
-            // the reverse sweep recomputes a = exp2(delta A2) (an opaque copy of A2 keeps the compiler from carrying the forward sweep's
-            // sixteen values across: those registers do not exist at three waves per SIMD)
-            vf A2r_lo = lo2(A2j), A2r_hi = hi2(A2j);
-            pin_value(A2r_lo);
-            pin_value(A2r_hi);
-            const vf2 A2r = mk2(A2r_lo, A2r_hi);
+            AUM_TMB_STAMP(4);
             // reverse sweep: steps s_hi-1 .. s_lo
             AUM_UNROLL
             for (int s = SCANT_CK - 1; s >= 0; --s) {
                 if (FULL || (s >= s_lo && s < s_hi)) {
-                    vf qb[2], qc[2];
-                    lds_read2_u(t_bc, s * SCANT_BC_ROW + 2 * j, qb);
-                    lds_read2_u(t_bc, s * SCANT_BC_ROW + N + 2 * j, qc);
-                    const vf2 a = vexp2_2(bc_lo(P[s]) * A2r);
-                    const vf2 g = vfma2((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1]), mk2(qc[0], qc[1]), hj);
+                    const vf2 g = vfma2((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1]), mk2(qc[s][0], qc[s][1]), hj);
                     const vf2 pbs = g * bc_hi(P[s]);
                     pb[2 * s] = lo2(pbs);
                     pb[2 * s + 1] = hi2(pbs);
-                    const vf2 gb = g * mk2(qb[0], qb[1]);
-                    S1[s] = S1[s] + (lo2(gb) + hi2(gb));
-                    pin_value(S1[s]);
+                    S1[s] = vfma2(g, mk2(qb[s][0], qb[s][1]), S1[s]);
                     const vf2 r = g * w[s];
-                    const vf2 ar = A2j * r;
-                    S2[s] = S2[s] + (lo2(ar) + hi2(ar));
-                    pin_value(S2[s]);
+                    S2[s] = vfma2(A2j, r, S2[s]);
                     dAj = vfma2(bc_lo(P[s]), r, dAj);
-                    hj = a * g;
+                    hj = a[s] * g;
                 }
             }
             AUM_SCHED_FENCE();
-            const vf dBsum = wave_sum16(pb);
-            // lane l holds the totals of value k = wave_sum16_value_of_lane(l) = (step k >> 1, state 2j + (k & 1)); one lane per quad writes
+            AUM_TMB_STAMP(5);
+            const vf dBsum = (AUM_SCANT_BABL & 1) ? pb[0] + pb[7] : wave_sum16(pb);
+            // lane l holds the totals of value k = wave_sum16_value_of_lane(l) = (step k >> 1, state 2j + (k & 1)).  The four lanes of a
+            // quad hold the same total and all write it to the same slot: a lane mask here is a branch, and everything the scheduler
+            // sinks below it loses its packed-operand broadcasts (they are folded per basic block)
             {
                 const vi slot = dbc_slot + 2 * j;
-                lds_write_m(t_dbc, slot, dBsum, (lane & 3) == 0);
-                lds_write_m(t_dbc, slot + N, dCsum, (lane & 3) == 0);
+                lds_write(t_dbc, slot, dBsum);
+                lds_write(t_dbc, slot + N, dCsum);
             }
-            vf16_set(hh, 2 * j, lo2(hj));
-            vf16_set(hh, 2 * j + 1, hi2(hj));
-            vf16_set(dAacc, 2 * j, lo2(dAj));
-            vf16_set(dAacc, 2 * j + 1, hi2(dAj));
+            vf16_set(hh, 2 * jr, lo2(hj));
+            vf16_set(hh, 2 * jr + 1, hi2(hj));
+            vf16_set(dAacc, 2 * jr, lo2(dAj));
+            vf16_set(dAacc, 2 * jr + 1, hi2(dAj));
+            AUM_TMB_STAMP(6);
         }
         // ---- the block's du, ddelta; partials / finish ----------------------------------------------------------
+        // the loads issued after the block's first lines are back (all but the fourteen entry rows requested during the passes)
+        if (cknext) AUM_WAIT_VM(14);
+        else AUM_WAIT_VM(0);
         wave_lds_fence();
+        if (more) {
+            if (cknext) request_entry(blk - 1, N - 2, N);
+            else request_entry(0, 0, N);
+        }
         AUM_UNROLL
         for (int s = 0; s < SCANT_CK; ++s) {
             if (FULL || (s >= s_lo && s < s_hi)) {
-                const vi off = el_off + s * ROWB;
+                const vi off = el_off + s * LROW;
                 const vf dls = lo2(P[s]), dys = (s & 1) ? hi2(Q[s >> 1]) : lo2(Q[s >> 1]);
                 const vf us = raw_to_f32<T>(lds_read_raw<T>(t_u, off));
-                vf du = dls * S1[s];
-                vf dd = vfma(us, S1[s], S2[s] * LN2);
+                const vf s1 = lo2(S1[s]) + hi2(S1[s]), s2 = lo2(S2[s]) + hi2(S2[s]);
+                vf du = dls * s1;
+                vf dd = vfma(us, s1, s2 * LN2);
                 if (FINAL) {
                     du = vfma(Dv, dys, du);
                     dDacc = vfma(dys, us, dDacc);
@@ -764,6 +787,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             }
         }
         wave_lds_fence();
+        AUM_TMB_STAMP(7);
         store_tile(dubuf, du_tb, t_du, rc);
         store_tile(ddbuf, dd_tb, t_dd, rc);
         if (HAS_Z && FINAL) store_tile(dzbuf, dz_tb, t_dz, rc);
@@ -773,26 +797,18 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             else gbuf_store16_m(dbcbuf, rc.rowt * dbc_tb + st_c * 16 + dbc_col, 0, q, rc.valid);
         }
         wave_lds_fence();
-        if (more) {
-            // the last tensors of the next block: z / ytot parked above when present; the partials and B/C now
-
-            vf b0, b1, c0, c1;
-            pair_raw_to_f32<T>(bpn, b0, b1);
-            pair_raw_to_f32<T>(cpn, c0, c1);
-            lds_write2(t_bc, bc_slot, b0, b1);
-            lds_write2(t_bc, bc_slot + N, c0, c1);
-            wave_lds_fence();
-        }
+        AUM_TMB_STAMP(8);
     };
     for (int blk = blk_hi - 1; blk >= blk_lo; --blk) {
         if (blk * SCANT_CK >= it0 && blk * SCANT_CK + SCANT_CK <= it1) do_block(ScanTTag<true>{}, blk);
         else do_block(ScanTTag<false>{}, blk);
     }
+#undef AUM_TMB_STAMP
 }
 
 // workgroup = four waves as in the forward.  Workspace partials are summed by scant_bwd_reduce.
 template <class T, bool SP, bool HAS_Z, bool BIDIR>
-AUM_DEV void scant_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int wg, float* lds) {
+AUM_DEV void scant_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int wg, float* lds, unsigned long long* tacc = nullptr) {
     constexpr int N = SCANT_N;
     constexpr int NW = SCANT_NW;
     constexpr int UPW = scant_units_per_wg<BIDIR>();
@@ -825,7 +841,7 @@ AUM_DEV void scant_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int wg,
             if (unit < units) {
                 init(w);
                 scant_bwd_run<T, N, 0, SP, HAS_Z>(p, wo, unit / gpb, (unit % gpb) * WAVE, 0, unit % gpb, rev ? L - 1 : 0, rev ? -1 : 1, 0, L, p.A, 1.f,
-                                                  hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)], dbias[AUM_W(w)], lds + w * scant_bwd_lds_wave_floats<T>());
+                                                  hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)], dbias[AUM_W(w)], lds + w * scant_bwd_lds_wave_floats<T>(), tacc);
                 finish(w, unit, 0);
             }
         }
@@ -839,7 +855,7 @@ AUM_DEV void scant_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int wg,
             init(w);
             scant_bwd_run<T, N, 1, SP, HAS_Z>(p, wo, unit / gpb, (unit % gpb) * WAVE, d, (unit % gpb) * 2 + d, d ? L - 1 : 0, d ? -1 : 1,
                                               scant_first_half(L, d), L, d ? p.A_b : p.A, 2.f, hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)],
-                                              dbias[AUM_W(w)], lds + w * scant_bwd_lds_wave_floats<T>());
+                                              dbias[AUM_W(w)], lds + w * scant_bwd_lds_wave_floats<T>(), tacc);
         }
     }
     AUM_WG_BARRIER();
@@ -848,7 +864,7 @@ AUM_DEV void scant_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int wg,
         if (unit < units) {
             scant_bwd_run<T, N, 2, SP, HAS_Z>(p, wo, unit / gpb, (unit % gpb) * WAVE, d, (unit % gpb) * 2 + d, d ? L - 1 : 0, d ? -1 : 1, 0,
                                               scant_first_half(L, d), d ? p.A_b : p.A, 2.f, hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)],
-                                              dbias[AUM_W(w)], lds + w * scant_bwd_lds_wave_floats<T>());
+                                              dbias[AUM_W(w)], lds + w * scant_bwd_lds_wave_floats<T>(), tacc);
             finish(w, unit, d);
         }
     }

@@ -419,6 +419,31 @@ AUM_DEV vq lds_read16(const float* lds, vi byte_off) {
     q.w[0] = v.x; q.w[1] = v.y; q.w[2] = v.z; q.w[3] = v.w;
     return q;
 }
+// Global -> LDS without registers (buffer_load_dword / _dwordx4 ... lds): lane l's 4 or 16 bytes land at lds_dst + l * 4 / l * 16, the
+// data never passes through VGPRs and nothing has to be "parked" later.  Completion is counted in vmcnt like any load: AUM_WAIT_VM(n)
+// (memory operations complete in issue order, n = the number of YOUNGER ones that may stay in flight) before the LDS data is read.
+// (the LDS address-space cast does not parse in the host pass of the same source, which never runs these bodies)
+template <class T> AUM_DEV void gbuf_load16_lds(const gbuf<T>& b, vi voff_bytes, int soff_bytes, float* lds_dst) {
+#ifdef __HIP_DEVICE_COMPILE__
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff_bytes, soff_bytes, 0, 0);
+#endif
+}
+template <class T> AUM_DEV void gbuf_load4_lds(const gbuf<T>& b, vi voff_bytes, int soff_bytes, float* lds_dst) {
+#ifdef __HIP_DEVICE_COMPILE__
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_dst, 4, voff_bytes, soff_bytes, 0, 0);
+#endif
+}
+#define AUM_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// the two consecutive elements of T this lane fetched with gbuf_load4_lds (one dword for the 16-bit types; two for float, the second
+// WAVE dwords further)
+template <class T> AUM_DEV void lds_pair_to_f32(const float* lds, vf& lo, vf& hi) {
+    const int l4 = (int)(threadIdx.x & 63u) * 4;
+    vpair_raw r;
+    r.w[0] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(lds) + l4);
+    r.w[1] = 0;
+    if constexpr (sizeof(T) == 4) r.w[1] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(lds) + l4 + WAVE * 4);
+    pair_raw_to_f32<T>(r, lo, hi);
+}
 template <class T> AUM_DEV vi lds_read_raw(const float* lds, vi byte_off) {
     if constexpr (sizeof(T) == 4) return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(lds) + byte_off);
     else return (int)*reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(lds) + byte_off);
@@ -659,6 +684,26 @@ inline vq lds_read16(const float* lds, const vi& byte_off) {
         for (int k = 0; k < 4; ++k) q.w[k].v[l] = t[k];
     }
     return q;
+}
+template <class T> inline void gbuf_load16_lds(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes, float* lds_dst) {
+    AUM_LANES std::memcpy((char*)lds_dst + l * 16, (const char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes, 16);
+}
+template <class T> inline void gbuf_load4_lds(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes, float* lds_dst) {
+    AUM_LANES std::memcpy((char*)lds_dst + l * 4, (const char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes, 4);
+}
+#define AUM_WAIT_VM(n) do { } while (0)
+template <class T> inline void lds_pair_to_f32(const float* lds, vf& lo, vf& hi) {
+    AUM_LANES {
+        if constexpr (sizeof(T) == 4) {
+            lo.v[l] = lds[l];
+            hi.v[l] = lds[WAVE + l];
+        } else {
+            T e[2];
+            std::memcpy(e, &lds[l], 4);
+            lo.v[l] = elem_to_f32(e[0]);
+            hi.v[l] = elem_to_f32(e[1]);
+        }
+    }
 }
 template <class T> inline vi lds_read_raw(const float* lds, const vi& byte_off) {
     vi r;

@@ -12,6 +12,36 @@ sys.path.insert(0, os.path.join(ROOT, "audio-mamba-aum_amd"))
 import aum_hip  # noqa: E402
 
 
+def bwd_trace(lib, u, dl, A, Bm, Cm, z, Bsz, E, L, N, dev):
+    """backward of the bidirectional scan: per-wave placement and the shader-clock cycles of each part of scant_bwd_run"""
+    import numpy as np
+    ref = aum_hip.get()
+    D, A_b = torch.ones(E, device=dev), A * 1.05
+    ck = aum_hip.scan_tm_ckpt(Bsz, L, E, N, True, dev)
+    _, pre = aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, D, z, None, False, A_b=A_b, want_out_pre=True, ckpt=ck, lib=ref)
+    dout = torch.randn(Bsz, L, E, device=dev).to(u.dtype)
+    for rep in range(3):
+        r = aum_hip.scan_tm_bwd(u, dl, A, Bm, Cm, D, z, None, dout, pre, ck, False, A_b=A_b, lib=lib)
+        torch.cuda.synchronize()
+    nw = Bsz * (E // 64) * 2
+    tr = r["_ws"].view(torch.int64)[-nw * 16:].view(nw // 4, 4, 16).cpu().numpy()
+    hw, xcc, t0, t1 = tr[..., 0], tr[..., 1] & 0xF, tr[..., 2], tr[..., 3]
+    dur = (t1 - t0) / 100.0
+    print(f"bwd: {nw} waves; kernel span {(t1.max() - t0.min()) / 100:.1f} us; wave duration us 5/50/95/100 %: "
+          + " ".join(f"{np.percentile(dur, q):.0f}" for q in (5, 50, 95, 100)))
+    cuid = xcc * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 10 + ((hw >> 8) & 0xF)
+    per_simd = collections.Counter((cuid * 4 + ((hw >> 4) & 3)).flatten().tolist())
+    print("waves per SIMD histogram:", sorted(collections.Counter(per_simd.values()).items()))
+    names = ["prologue", "block start", "pass: staging", "pass: forward sweep", "pass: dC butterfly", "pass: reverse sweep",
+             "pass: dB butterfly + carries", "block end: du/ddelta", "block end: stores, B/C", "", "", ""]
+    acc = tr[..., 4:16].reshape(-1, 12).astype(np.float64)
+    tot = acc.sum(1).mean()
+    print(f"mean shader-clock cycles per wave {tot:.0f} ({tot / dur.mean() / 1e3:.2f} GHz if the wave were stamping all the time)")
+    for k, n in enumerate(names):
+        if n:
+            print(f"  {n:32s} {acc[:, k].mean():12.0f} cycles  {100 * acc[:, k].mean() / tot:5.1f} %")
+
+
 def main():
     variant, mode = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "bidir")
     lib = aum_hip.Lib(os.path.join(ROOT, "audio-mamba-aum_amd", "aum_hip", "variants", f"libaum_hip_{variant}.so"))
@@ -24,6 +54,8 @@ def main():
     xdbl = torch.randn(Bsz, L, 48 + 2 * N, device=dev).to(dt)
     Bm, Cm = xdbl[:, :, 48:48 + N], xdbl[:, :, 48 + N:]
     A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(E, 1)
+    if mode == "bwd":
+        return bwd_trace(lib, u, dl, A, Bm, Cm, z, Bsz, E, L, N, dev)
     bidir = mode == "bidir"
     ck = aum_hip.scan_tm_ckpt(Bsz, L, E, N, bidir, dev)          # used as the trace buffer by this build
     for rep in range(3):

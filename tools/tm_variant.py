@@ -4,7 +4,8 @@ with extra -D flags and links them with the other objects of the regular build i
 audio-mamba-aum_amd/aum_hip/variants/libaum_hip_<name>.so (git-ignored, travels with the gpurun snapshot; tools/tm_time.py
 and tools/tm_gpu_check.py take the variant name).
 
-  python tools/tm_variant.py <name> [-DFOO=1 ...] [--asm]      (--asm also writes /tmp/aumt/<name>_p6.s)"""
+  python tools/tm_variant.py <name> [-DFOO=1 ...] [--asm] [--api]
+--asm also writes /tmp/aumt/<name>_p6.s; --api recompiles the host part as well (flags that change it: AUM_SCANT_TRACE)"""
 import os
 import subprocess
 import sys
@@ -17,7 +18,7 @@ import build as B  # noqa: E402
 
 def main():
     name = sys.argv[1]
-    defs = [a for a in sys.argv[2:] if a.startswith("-")and a != "--asm"]
+    defs = [a for a in sys.argv[2:] if a.startswith("-D")]
     B.build()
     vdir = os.path.join(B.OUT_DIR, "variants")
     odir = os.path.join(B.OBJ_DIR, "variants")
@@ -25,7 +26,7 @@ def main():
     os.makedirs(odir, exist_ok=True)
     objs, procs = [], []
     for oname, odefs in B.parts():
-        if oname in ("scantm_p5_d1.o", "scantm_p6_d1.o"):
+        if oname in ("scantm_p5_d1.o", "scantm_p6_d1.o") or (oname == "api.o" and "--api" in sys.argv):
             o = os.path.join(odir, f"{name}_{oname}")
             procs.append(subprocess.Popen([B.HIPCC] + B.FLAGS + odefs + defs + ["-c", B.SRC, "-o", o]))
             if "--asm" in sys.argv and "p6" in oname:

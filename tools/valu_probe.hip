@@ -28,11 +28,13 @@
 #define I_BPERM(i) "ds_bpermute_b32 %" #i ", %8, %" #i "\n\t"
 
 enum { K_FMA, K_MUL, K_EXP, K_RCP, K_FMAS, K_PKFMA, K_DPP_SHR, K_DPP_ROR8, K_DPP_QP, K_SHL, K_CVT, K_SWAP32, K_SWAP16, K_READLANE, K_BPERM,
-       K_MIX, K_MIXPK, K_COUNT };
+       K_MIX, K_MIXPK, K_DEP_FMA, K_DEP_PK, K_DEP_PK2, K_DEP_DPP, K_DEP_EXP, K_LDS_RT, K_COUNT };
 static const char* kNames[K_COUNT] = {"v_fma_f32", "v_mul_f32", "v_exp_f32", "v_rcp_f32", "v_fma_f32 (sgpr src)", "v_pk_fma_f32 (2 flop-lanes)", "v_add_f32_dpp row_shr",
                                       "v_add_f32_dpp row_ror:8 bank_mask", "v_add_f32_dpp quad_perm", "v_lshlrev_b32", "v_cvt_pk_bf16_f32",
                                       "v_permlane32_swap", "v_permlane16_swap", "v_readlane_b32", "ds_bpermute_b32",
-                                      "mix 8 exp + 24 fma", "mix 8 exp + 12 pk_fma"};
+                                      "mix 8 exp + 24 fma", "mix 8 exp + 12 pk_fma", "DEPENDENT v_fma_f32 chain", "DEPENDENT v_pk_fma_f32 chain (s_nop 0 between)",
+                                      "two interleaved dependent v_pk_fma_f32 chains", "DEPENDENT v_add_f32_dpp chain (s_nop 1 between)",
+                                      "DEPENDENT v_exp_f32 chain", "ds_read_b64 + s_waitcnt round trip"};
 
 template <int KIND> __global__ __launch_bounds__(256) void k_probe(float* out, long long* cyc, int iters, float a, float b) {
     float r0 = threadIdx.x * 1e-3f, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
@@ -64,6 +66,19 @@ template <int KIND> __global__ __launch_bounds__(256) void k_probe(float* out, l
             asm volatile(X4(X4("v_readlane_b32 %0, %4, 5\n\tv_readlane_b32 %1, %5, 9\n\t")) "v_readlane_b32 %2, %6, 1\n\tv_readlane_b32 %3, %7, 2\n\t"
                          : "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3) : "v"(r0), "v"(r1), "v"(r2), "v"(r3));
             sacc += s0 + s1 + s2 + s3;
+        }
+        if constexpr (KIND == K_DEP_FMA) asm volatile(X4(X4("v_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %0, %0, %8, %9\n\t")) : REGS : "v"(a), "v"(b));
+        if constexpr (KIND == K_DEP_PK)
+            asm volatile(X4(X4("v_pk_fma_f32 %0, %0, %4, %5\n\ts_nop 0\n\tv_pk_fma_f32 %0, %0, %4, %5\n\ts_nop 0\n\t")) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pa), "v"(pb));
+        if constexpr (KIND == K_DEP_PK2)
+            asm volatile(X4(X4("v_pk_fma_f32 %0, %0, %4, %5\n\tv_pk_fma_f32 %1, %1, %4, %5\n\t")) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pa), "v"(pb));
+        if constexpr (KIND == K_DEP_DPP)
+            asm volatile(X4(X4("v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t")) : REGS : "v"(a), "v"(b));
+        if constexpr (KIND == K_DEP_EXP) asm volatile(X4(X4("v_exp_f32 %0, %0\n\tv_exp_f32 %0, %0\n\t")) : REGS : "v"(a), "v"(b));
+        if constexpr (KIND == K_LDS_RT) {
+            f2 q;
+            asm volatile(X4(X4("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_read_b64 %0, %1 offset:64\n\ts_waitcnt lgkmcnt(0)\n\t")) : "=&v"(q) : "v"(0));
+            p0 += q;
         }
         if constexpr (KIND == K_MIX) {      // per state: exp, then 3 dependent-free fma/mul -- the scan's forward mix (1 : 3), 8 + 24
             asm volatile(R8(I_EXP) R8(I_FMA) R8(I_MUL) R8(I_FMA) : REGS : "v"(a), "v"(b));
@@ -120,5 +135,7 @@ int main() {
     sweep<K_DPP_SHR>(out, cyc); sweep<K_DPP_ROR8>(out, cyc); sweep<K_DPP_QP>(out, cyc);
     sweep<K_SWAP32>(out, cyc); sweep<K_SWAP16>(out, cyc); sweep<K_READLANE>(out, cyc); sweep<K_BPERM>(out, cyc);
     sweep<K_SHL>(out, cyc); sweep<K_CVT>(out, cyc);
+    sweep<K_DEP_FMA>(out, cyc); sweep<K_DEP_PK>(out, cyc); sweep<K_DEP_PK2>(out, cyc); sweep<K_DEP_DPP>(out, cyc); sweep<K_DEP_EXP>(out, cyc);
+    sweep<K_LDS_RT>(out, cyc);
     return 0;
 }
