@@ -380,6 +380,8 @@ AUM_HOSTDEV constexpr int scant_first_half(int len, int dir) { return dir == 0 ?
 // time of the same group) or four channel groups.  Units (batch entry, channel group) are numbered batch-major.
 constexpr int SCANT_NW = 4;
 template <bool BIDIR> AUM_HOSTDEV constexpr int scant_units_per_wg() { return BIDIR ? SCANT_NW / 2 : SCANT_NW; }
+// workgroups of the backward: four one-direction units, or three Fo-Bi pairs in three stages (scant_bwd)
+template <bool BIDIR> AUM_HOSTDEV constexpr int scant_bwd_wgs(int units) { return BIDIR ? (units + 2) / 3 : (units + SCANT_NW - 1) / SCANT_NW; }
 
 template <class T, bool SP, bool HAS_Z, bool HAS_PRE, bool BIDIR>
 AUM_DEV void scant_fwd(const AumScanTmFwdArgs& p, int wg, float* lds, unsigned long long* tacc = nullptr) {
@@ -454,6 +456,7 @@ struct ScanTBwdOut {
     float* dD;         // [ndir][batch][dim]
     float* dbias;      // [ndir][batch][dim]
     int nparts;
+    float* carry;      // bidirectional: [workgroup][direction][34][64] -- the carries of the pair whose two phases run on different waves
     unsigned long long* trace;      // -DAUM_SCANT_TRACE builds (tools/tm_trace.py): 16 x uint64 per wave behind the partials; else unused
 };
 
@@ -599,7 +602,13 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     request_block(blk_hi - 1, rows_of(blk_hi - 1));
     request_entry(blk_hi - 1, 0, N);
     for (int n = 0; n < N; ++n) gbuf_load4_lds(Abuf, ec * (N * 4), n * 4, t_A + n * WAVE);
+    // Memory operations complete in issue order, and s_waitcnt vmcnt(n) returns once at most n are in flight: every wait below names
+    // exactly the operations YOUNGER than the data it needs.  Issue order around a block:
+    //   [previous block's passes: 16 entry rows of this block] [its end: NST stores] [this block's first lines: RBN loads of the next
+    //   block's tensors, PART loads of this block's partial du / ddelta] [this block's passes: 2 entry rows of the next block each]
     constexpr int NST = 2 * NLD + ((HAS_Z && FINAL) ? NLD : 0) + 1;       // stores at the end of a block: du, ddelta, dz, dB/dC
+    constexpr int RBN = ((HAS_Z ? 5 : 3) + 2) * NLD;                      // request_block
+    constexpr int PART = LD_PART ? 2 * NLD : 0;
     AUM_TMB_STAMP(0);
     // one block; FULL: all eight steps belong to the phase (no per-step conditions)
     auto do_block = [&](auto full_tag, int blk) {
@@ -609,10 +618,13 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
         const int s_hi = FULL ? SCANT_CK : (it1 < base + SCANT_CK ? it1 - base : SCANT_CK);
         const bool more = blk > blk_lo;
         const bool cknext = more && blk - 1 > 0;        // the next block has a checkpoint to fetch (else its entry rows are zeroed)
-        // the block's loads are the oldest operations in flight: all but the previous block's stores have to be back
+        // the block's tensors (requested in the previous block's first lines) are older than that block's partials, the entry rows
+        // its passes requested and its stores
         if (blk == blk_hi - 1) AUM_WAIT_VM(0);
-        else AUM_WAIT_VM(NST);
+        else if (blk > 0) AUM_WAIT_VM(PART + 16 + NST);
+        else AUM_WAIT_VM(PART + NST);
         wave_lds_fence();
+        AUM_TMB_STAMP(9);
         convert_bc();
         // ---- per-step registers of the block; dz of its steps --------------------------------------------------
         // P[s] = (delta_s, delta_s u_s), Q[i] = (dy_2i, dy_2i+1): pairs of DIFFERENT values -- a packed instruction broadcasts either half
@@ -620,31 +632,43 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
         vf2 P[SCANT_CK], Q[SCANT_CK / 2];
         float* const t_u = t_u_of(blk);
         {
+            // all LDS reads first (raw: 40 registers that are free here), then the arithmetic step by step
+            vi ru[SCANT_CK], rd[SCANT_CK], rg[SCANT_CK], rz[SCANT_CK], ry[SCANT_CK];
+            AUM_UNROLL
+            for (int s = 0; s < SCANT_CK; ++s) {
+                const vi off = el_off + s * LROW;
+                ru[s] = lds_read_raw<T>(t_u, off);
+                rd[s] = lds_read_raw<T>(t_d, off);
+                rg[s] = lds_read_raw<T>(t_g, off);
+                if (HAS_Z) rz[s] = lds_read_raw<T>(t_z, off);
+                if (HAS_Z && FINAL) ry[s] = lds_read_raw<T>(t_y, off);
+            }
+            AUM_SCHED_FENCE();
             vf dyv[SCANT_CK];
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) {
                 const vi off = el_off + s * LROW;
-                const vf us = raw_to_f32<T>(lds_read_raw<T>(t_u, off));
-                vf d = raw_to_f32<T>(lds_read_raw<T>(t_d, off)) + biasv;
+                const vf us = raw_to_f32<T>(ru[s]);
+                vf d = raw_to_f32<T>(rd[s]) + biasv;
                 if (SP) d = vsoftplus(d);
                 P[s] = mk2(d, d * us);
-                const vf go = raw_to_f32<T>(lds_read_raw<T>(t_g, off));
+                const vf go = raw_to_f32<T>(rg[s]);
                 if (HAS_Z) {
-                    const vf zz = raw_to_f32<T>(lds_read_raw<T>(t_z, off));
+                    const vf zz = raw_to_f32<T>(rz[s]);
                     const vf sg = vsigmoid(zz);
                     dyv[s] = go * (zz * sg);
                     if (FINAL) {        // dz = dout ytot d(z sigmoid(z))/dz  (direction-independent: written by whoever finishes the step)
-                        const vf yt = raw_to_f32<T>(lds_read_raw<T>(t_y, off));
+                        const vf yt = raw_to_f32<T>(ry[s]);
                         lds_write_elem<T>(t_dz, off, go * yt * (sg * vfma(zz, splat(1.f) - sg, splat(1.f))));
                     }
                 } else {
                     dyv[s] = go;
                 }
-                AUM_SCHED_FENCE();      // step by step: interleaved, the eight steps' temporaries do not fit beside the carries
             }
             AUM_UNROLL
             for (int i = 0; i < SCANT_CK / 2; ++i) Q[i] = mk2(dyv[2 * i], dyv[2 * i + 1]);
         }
+        AUM_TMB_STAMP(10);
         vf2 S1[SCANT_CK], S2[SCANT_CK];      // per state PAIR: one packed fma per step and sum; the two halves are added once per block
         AUM_UNROLL
         for (int s = 0; s < SCANT_CK; ++s) S1[s] = S2[s] = spl2(splat(0.f));
@@ -667,6 +691,13 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             // B and C of the pass's state pair for all eight steps, the pair's entry state and A, requested before anything else: the
             // exponentials cover their latency (read step by step inside the sweeps, every read was waited for on the spot:
             // twelve LDS round trips per pass in a chain that two waves per SIMD cannot hide)
+            // this pass's entry rows: younger are the later rows (14 - 2j), the previous block's stores, this block's requests and the 2j
+            // rows of the next block requested so far -- a constant; fewer were issued near the ends of a phase
+            if (blk != blk_hi - 1) {
+                if (more && cknext) AUM_WAIT_VM(14 + NST + RBN + PART);
+                else if (more) AUM_WAIT_VM(NST + RBN + PART);
+                else AUM_WAIT_VM(NST + PART);
+            }
             // (the LDS answers in order: A first, the exponentials wait for nothing else)
             const vf2 Aj = mk2(lds_read(t_A, lane + (2 * j) * WAVE), lds_read(t_A, lane + (2 * j + 1) * WAVE));
             vf2 x = mk2(lds_read(t_ck, lane + (2 * j) * WAVE), lds_read(t_ck, lane + (2 * j + 1) * WAVE));
@@ -713,9 +744,8 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                     }
                 }
             }
-            // the entry rows this pass consumed make room for the next block's (fourteen of the sixteen here, the last pair at the end
-            // of the block -- AUM_WAIT_VM there counts on exactly these loads being the youngest)
-            if (cknext && j < N / 2 - 1) request_entry(blk - 1, 2 * j, 2 * j + 2);
+            // the entry rows this pass consumed make room for the next block's
+            if (cknext) request_entry(blk - 1, 2 * j, 2 * j + 2);
             AUM_SCHED_FENCE();
             AUM_TMB_STAMP(3);
             const vf dCsum = (AUM_SCANT_BABL & 1) ? pc[0] + pc[5] : wave_sum16(pc);
@@ -754,20 +784,28 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             AUM_TMB_STAMP(6);
         }
         // ---- the block's du, ddelta; partials / finish ----------------------------------------------------------
-        // the loads issued after the block's first lines are back (all but the fourteen entry rows requested during the passes)
-        if (cknext) AUM_WAIT_VM(14);
+        // this block's partial du / ddelta are back (younger: the sixteen entry rows requested during the passes)
+        if (cknext) AUM_WAIT_VM(16);
         else AUM_WAIT_VM(0);
         wave_lds_fence();
-        if (more) {
-            if (cknext) request_entry(blk - 1, N - 2, N);
-            else request_entry(0, 0, N);
+        if (more && !cknext) request_entry(0, 0, N);        // the first block starts from zero
+        vi rus[SCANT_CK], rpu[SCANT_CK], rpd[SCANT_CK];
+        AUM_UNROLL
+        for (int s = 0; s < SCANT_CK; ++s) {
+            const vi off = el_off + s * LROW;
+            rus[s] = lds_read_raw<T>(t_u, off);
+            if (FINAL && LD_PART) {
+                rpu[s] = lds_read_raw<T>(t_du, off);
+                rpd[s] = lds_read_raw<T>(t_dd, off);
+            }
         }
+        AUM_SCHED_FENCE();
         AUM_UNROLL
         for (int s = 0; s < SCANT_CK; ++s) {
             if (FULL || (s >= s_lo && s < s_hi)) {
                 const vi off = el_off + s * LROW;
                 const vf dls = lo2(P[s]), dys = (s & 1) ? hi2(Q[s >> 1]) : lo2(Q[s >> 1]);
-                const vf us = raw_to_f32<T>(lds_read_raw<T>(t_u, off));
+                const vf us = raw_to_f32<T>(rus[s]);
                 const vf s1 = lo2(S1[s]) + hi2(S1[s]), s2 = lo2(S2[s]) + hi2(S2[s]);
                 vf du = dls * s1;
                 vf dd = vfma(us, s1, s2 * LN2);
@@ -775,15 +813,14 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                     du = vfma(Dv, dys, du);
                     dDacc = vfma(dys, us, dDacc);
                     if (LD_PART) {
-                        du = du + raw_to_f32<T>(lds_read_raw<T>(t_du, off));
-                        dd = dd + raw_to_f32<T>(lds_read_raw<T>(t_dd, off));
+                        du = du + raw_to_f32<T>(rpu[s]);
+                        dd = dd + raw_to_f32<T>(rpd[s]);
                     }
                     if (SP) dd = dd * (splat(1.f) - vexp2(dls * (-LOG2E)));      // sigmoid(raw) = 1 - exp(-softplus(raw))
                     dbacc = dbacc + dd;
                 }
                 lds_write_elem<T>(t_du, off, du);
                 lds_write_elem<T>(t_dd, off, dd);
-                AUM_SCHED_FENCE();
             }
         }
         wave_lds_fence();
@@ -847,26 +884,59 @@ AUM_DEV void scant_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int wg,
         }
         return;
     }
-    // the backward walks a direction's iterations from the last to the first: its first phase is the iterations the forward's second
-    // phase ran, [first_half, L), its second phase [0, first_half)
-    AUM_FOR_EACH_WAVE(w, NW) {
-        const int unit = wg * UPW + (w >> 1), d = w & 1;
-        if (unit < units) {
-            init(w);
-            scant_bwd_run<T, N, 1, SP, HAS_Z>(p, wo, unit / gpb, (unit % gpb) * WAVE, d, (unit % gpb) * 2 + d, d ? L - 1 : 0, d ? -1 : 1,
-                                              scant_first_half(L, d), L, d ? p.A_b : p.A, 2.f, hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)],
-                                              dbias[AUM_W(w)], lds + w * scant_bwd_lds_wave_floats<T>(), tacc);
+    // Bidirectional.  The backward walks a direction's iterations from the last to the first: its first phase is the iterations the
+    // forward's second phase ran, [first_half, L), its second phase [0, first_half).  The kernel holds 256 registers per lane, two
+    // waves per SIMD, and B = 64, E = 1536 is THREE direction waves per SIMD: a workgroup per channel-group pair would leave the last
+    // third of the run to lone waves that take as long as paired ones (the pass is a latency chain).  So a workgroup of four waves
+    // takes three pairs X, Y, Z through three stages of one phase each -- 512 workgroups, two per CU, every SIMD holds two waves for
+    // the whole kernel:
+    //     waves 0,1:  X phase 1 | X phase 2 | Y phase 2          waves 2,3:  Y phase 1 | Z phase 1 | Z phase 2
+    // Y's carries (adjoint state, dA, dD, ddelta_bias partial sums: 34 values per lane) cross from waves 2,3 to waves 0,1 through
+    // global memory, ordered by the two barriers in between like the du / ddelta partials of a pair.
+    const int npairs = units;
+    _Pragma("nounroll")
+    for (int stage = 0; stage < 3; ++stage) {
+        AUM_FOR_EACH_WAVE(w, NW) {
+            const int h = w >> 1, d = w & 1;
+            const int slot = h == 0 ? (stage == 2 ? 1 : 0) : (stage == 0 ? 1 : 2);       // X, Y, Z = 0, 1, 2
+            const int phase = h == 0 ? (stage == 0 ? 1 : 2) : (stage == 2 ? 2 : 1);
+            const int unit = wg * 3 + slot;
+            if (unit < npairs) {
+                const int b = unit / gpb, e0 = (unit % gpb) * WAVE, prt = (unit % gpb) * 2 + d;
+                float* cy = wo.carry + ((int64_t)wg * 2 + d) * (2 * N + 2) * WAVE;
+                const vi lane = lane_id();
+                if (phase == 1) {
+                    init(w);
+                    scant_bwd_run<T, N, 1, SP, HAS_Z>(p, wo, b, e0, d, prt, d ? L - 1 : 0, d ? -1 : 1, scant_first_half(L, d), L, d ? p.A_b : p.A, 2.f,
+                                                      hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)], dbias[AUM_W(w)],
+                                                      lds + w * scant_bwd_lds_wave_floats<T>(), tacc);
+                    if (slot == 1) {        // Y: phase 2 runs on the other two waves
+                        AUM_UNROLL
+                        for (int n = 0; n < N; ++n) {
+                            gstore(cy + n * WAVE, lane, vf16_get(hh[AUM_W(w)], n), lane >= 0);
+                            gstore(cy + (N + n) * WAVE, lane, vf16_get(dA[AUM_W(w)], n), lane >= 0);
+                        }
+                        gstore(cy + 2 * N * WAVE, lane, dD[AUM_W(w)], lane >= 0);
+                        gstore(cy + (2 * N + 1) * WAVE, lane, dbias[AUM_W(w)], lane >= 0);
+                    }
+                } else {
+                    if (slot == 1) {
+                        AUM_UNROLL
+                        for (int n = 0; n < N; ++n) {
+                            vf16_set(hh[AUM_W(w)], n, gload_u(cy + n * WAVE, lane));
+                            vf16_set(dA[AUM_W(w)], n, gload_u(cy + (N + n) * WAVE, lane));
+                        }
+                        dD[AUM_W(w)] = gload_u(cy + 2 * N * WAVE, lane);
+                        dbias[AUM_W(w)] = gload_u(cy + (2 * N + 1) * WAVE, lane);
+                    }
+                    scant_bwd_run<T, N, 2, SP, HAS_Z>(p, wo, b, e0, d, prt, d ? L - 1 : 0, d ? -1 : 1, 0, scant_first_half(L, d), d ? p.A_b : p.A, 2.f,
+                                                      hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)], dbias[AUM_W(w)],
+                                                      lds + w * scant_bwd_lds_wave_floats<T>(), tacc);
+                    finish(w, unit, d);
+                }
+            }
         }
-    }
-    AUM_WG_BARRIER();
-    AUM_FOR_EACH_WAVE(w, NW) {
-        const int unit = wg * UPW + (w >> 1), d = w & 1;
-        if (unit < units) {
-            scant_bwd_run<T, N, 2, SP, HAS_Z>(p, wo, unit / gpb, (unit % gpb) * WAVE, d, (unit % gpb) * 2 + d, d ? L - 1 : 0, d ? -1 : 1, 0,
-                                              scant_first_half(L, d), d ? p.A_b : p.A, 2.f, hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)],
-                                              dbias[AUM_W(w)], lds + w * scant_bwd_lds_wave_floats<T>(), tacc);
-            finish(w, unit, d);
-        }
+        if (stage < 2) AUM_WG_BARRIER();
     }
 }
 

@@ -50,5 +50,34 @@ ref = pf.float() + pb.float()
 err = (outs[0][1].float() - ref).abs().max().item() / ref.abs().max().item()
 print(f"bench-shape pair vs two one-direction launches: out_pre max rel diff {err:.2e}")
 bad += (not same) + (err > 1e-2)
+if bwd:
+    # backward at the bench shape: bitwise repeatable (no atomics; every hand-over through memory is ordered by a counted wait or a
+    # barrier -- a wait that names too few operations shows up here as a run-to-run difference), and the pair against two
+    # one-direction launches
+    ck = aum_hip.scan_tm_ckpt(Bsz, L, E, N, True, "cuda")
+    _, pre = aum_hip.scan_tm_fwd(u, dl, A, bc[:, :, :N], bc[:, :, N:], D, z, bias, True, A_b=A * 1.05, want_out_pre=True, ckpt=ck)
+    dout = torch.randn(Bsz, L, E, device="cuda").bfloat16()
+    runs = []
+    for i in range(4):
+        r = aum_hip.scan_tm_bwd(u, dl, A, bc[:, :, :N], bc[:, :, N:], D, z, bias, dout, pre, ck, True, A_b=A * 1.05)
+        runs.append({k: v.clone() for k, v in r.items() if v is not None and not k.startswith("_")})
+    same_b = all(torch.equal(runs[0][k], r[k]) for r in runs[1:] for k in runs[0])
+    fin = all(bool(torch.isfinite(v.float()).all()) for v in runs[0].values())
+    print("bench-shape bidirectional backward bitwise repeatable over 4 launches:", same_b, "finite:", fin)
+    ckf = aum_hip.scan_tm_ckpt(Bsz, L, E, N, False, "cuda")
+    ckb = aum_hip.scan_tm_ckpt(Bsz, L, E, N, False, "cuda")
+    aum_hip.scan_tm_fwd(u, dl, A, bc[:, :, :N], bc[:, :, N:], D, z, bias, True, want_out_pre=True, ckpt=ckf)
+    aum_hip.scan_tm_fwd(u, dl, A * 1.05, bc[:, :, :N], bc[:, :, N:], D, z, bias, True, reverse=True, want_out_pre=True, ckpt=ckb)
+    # one-direction backwards with the PAIR's pre-gate output (dz depends on the total)
+    rf = aum_hip.scan_tm_bwd(u, dl, A, bc[:, :, :N], bc[:, :, N:], D, z, bias, dout, pre, ckf, True)
+    rb = aum_hip.scan_tm_bwd(u, dl, A * 1.05, bc[:, :, :N], bc[:, :, N:], D, z, bias, dout, pre, ckb, True, reverse=True)
+    worst = 0.0
+    for k in ("du", "ddelta", "dBC", "dD", "ddelta_bias"):
+        ref = rf[k].float() + rb[k].float()
+        worst = max(worst, (runs[0][k].float() - ref).abs().max().item() / ref.abs().max().item())
+    for k, ref in (("dA", rf["dA"]), ("dA_b", rb["dA"]), ("dz", rf["dz"].float())):
+        worst = max(worst, (runs[0][k].float() - ref.float()).abs().max().item() / ref.float().abs().max().item())
+    print(f"bench-shape backward pair vs two one-direction launches: max rel diff {worst:.2e}")
+    bad += (not same_b) + (not fin) + (worst > 2e-2)
 print("FAILED" if bad else "ALL OK")
 sys.exit(1 if bad else 0)

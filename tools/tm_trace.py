@@ -23,7 +23,7 @@ def bwd_trace(lib, u, dl, A, Bm, Cm, z, Bsz, E, L, N, dev):
     for rep in range(3):
         r = aum_hip.scan_tm_bwd(u, dl, A, Bm, Cm, D, z, None, dout, pre, ck, False, A_b=A_b, lib=lib)
         torch.cuda.synchronize()
-    nw = Bsz * (E // 64) * 2
+    nw = (Bsz * (E // 64) + 2) // 3 * 4          # three Fo-Bi pairs per workgroup of four waves
     tr = r["_ws"].view(torch.int64)[-nw * 16:].view(nw // 4, 4, 16).cpu().numpy()
     hw, xcc, t0, t1 = tr[..., 0], tr[..., 1] & 0xF, tr[..., 2], tr[..., 3]
     dur = (t1 - t0) / 100.0
@@ -32,8 +32,9 @@ def bwd_trace(lib, u, dl, A, Bm, Cm, z, Bsz, E, L, N, dev):
     cuid = xcc * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 10 + ((hw >> 8) & 0xF)
     per_simd = collections.Counter((cuid * 4 + ((hw >> 4) & 3)).flatten().tolist())
     print("waves per SIMD histogram:", sorted(collections.Counter(per_simd.values()).items()))
-    names = ["prologue", "block start", "pass: staging", "pass: forward sweep", "pass: dC butterfly", "pass: reverse sweep",
-             "pass: dB butterfly + carries", "block end: du/ddelta", "block end: stores, B/C", "", "", ""]
+    names = ["prologue", "block start: requests", "pass: staging", "pass: forward sweep", "pass: dC butterfly", "pass: reverse sweep",
+             "pass: dB butterfly + carries", "block end: du/ddelta", "block end: stores, B/C", "block start: wait for the tensors",
+             "block start: B/C, per-step values", ""]
     acc = tr[..., 4:16].reshape(-1, 12).astype(np.float64)
     tot = acc.sum(1).mean()
     print(f"mean shader-clock cycles per wave {tot:.0f} ({tot / dur.mean() / 1e3:.2f} GHz if the wave were stamping all the time)")
