@@ -25,7 +25,7 @@ _ERR = {-1: "AUM_E_NULL", -2: "AUM_E_SHAPE", -3: "AUM_E_DTYPE", -4: "AUM_E_UNSUP
         -6: "AUM_E_LAUNCH"}
 
 _i64, _i32, _u32, _vp, _fp = C.c_int64, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class _Debug:
@@ -92,6 +92,12 @@ class ConvArgs(C.Structure):
                 + [(n, _i32) for n in ("batch", "dim", "len", "width", "dtype")] + [("flags", _u32)])
 
 
+class ConvTmArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("x", "dy", "weight", "bias", "y", "dx", "dw_part", "db_part")]
+                + [(n, _i64) for n in ("x_bs", "x_ts", "y_bs", "y_ts", "dy_bs", "dy_ts", "dx_bs", "dx_ts")]
+                + [(n, _i32) for n in ("batch", "dim", "len", "width", "dtype")] + [("flags", _u32)])
+
+
 class NormArgs(C.Structure):
     _fields_ = ([(n, _vp) for n in ("x", "residual", "dy", "dresidual_out", "weight", "rstd_in", "y", "residual_out",
                                     "dx", "dresidual_in", "rstd_out", "dweight_partial")]
@@ -129,7 +135,8 @@ class ProjWArgs(C.Structure):
 EXPORTS = ["aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows",
-           "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_selftest_wave_sum32"]
+           "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_selftest_wave_sum32",
+           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts"]
 
 
 class Lib:
@@ -152,6 +159,9 @@ class Lib:
         self.c.aum_scan_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_scan_tm_bwd.argtypes = [_vp, _vp]
         self.c.aum_scan_tm_nck.argtypes = [_i32]
+        self.c.aum_conv1d_tm_fwd.argtypes = [_vp, _vp]
+        self.c.aum_conv1d_tm_bwd.argtypes = [_vp, _vp]
+        self.c.aum_conv1d_tm_nparts.argtypes = [_i32, _i32]
         self.c.aum_scan_tm_workspace_bytes.restype = _i64
         self.c.aum_scan_tm_workspace_bytes.argtypes = [_i32] * 5
         self.c.aum_fbank_fwd.argtypes = [_vp, _vp]
@@ -551,6 +561,62 @@ def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_
     a.flags = (SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0)
     _launch(lib.c.aum_scan_tm_bwd, a, u, lib, "scan_tm_bwd_bidir" if bidir else "scan_tm_bwd", (batch, dim, length, dstate, u.element_size(), True))
     return dict(du=du, ddelta=ddelta, dz=dz, dBC=dBC, dA=dA, dA_b=dA_b, dD=dD, ddelta_bias=dbias, _ws=ws)
+
+
+def conv1d_tm_supported(x, width):
+    """the token-major conv takes (batch, len, dim) views with contiguous channels, 16-byte aligned rows and width <= 4"""
+    if x.dim() != 3 or x.dtype not in _DT or width > 4 or (x.stride(2) != 1 and x.shape[2] != 1):
+        return False
+    es = x.element_size()
+    bs, ts = _tm3(x, "x", x.shape[2])
+    return x.shape[2] % (16 // es) == 0 and x.data_ptr() % 16 == 0 and (ts * es) % 16 == 0 and (bs * es) % 16 == 0
+
+
+def conv1d_tm_fwd(x, weight, bias=None, silu=True, reverse=False, lib=None):
+    """causal_conv1d_fn on a token-major (batch, len, dim) view (x may be the first half of the in_proj output rows) -> y (batch, len,
+    dim) contiguous.  weight (dim, width) / (dim, 1, width)."""
+    lib = lib or get()
+    lib.check_tensor(x)
+    batch, length, dim = x.shape
+    weight = _f32c(weight.reshape(dim, -1))
+    bias = _f32c(bias)
+    y = torch.empty((batch, length, dim), dtype=x.dtype, device=x.device)
+    a = ConvTmArgs()
+    a.x, a.weight, a.bias, a.y = _ptr(x), _ptr(weight), _ptr(bias), _ptr(y)
+    a.x_bs, a.x_ts = _tm3(x, "x", dim)
+    a.y_bs, a.y_ts = _tm3(y, "y", dim)
+    a.batch, a.dim, a.len, a.width, a.dtype = batch, dim, length, weight.shape[1], _DT[x.dtype]
+    a.flags = (CONV_SILU if silu else 0) | (CONV_REVERSE if reverse else 0)
+    _launch(lib.c.aum_conv1d_tm_fwd, a, x, lib, "conv_tm_fwd", (batch, dim, length, x.element_size()))
+    return y
+
+
+def conv1d_tm_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, lib=None):
+    """-> (dx (batch, len, dim), dweight (dim, width) fp32, dbias (dim) fp32 | None); dx_out may be a strided token-major view (the
+    first half of d(in_proj output)).  The per-wave partial sums of dweight / dbias are added in a fixed order (aum_sum_rows)."""
+    lib = lib or get()
+    lib.check_tensor(x)
+    batch, length, dim = x.shape
+    weight = _f32c(weight.reshape(dim, -1))
+    bias = _f32c(bias)
+    width = weight.shape[1]
+    dy = dy if dy.stride(2) == 1 else dy.contiguous()
+    dx = dx_out if dx_out is not None else torch.empty((batch, length, dim), dtype=x.dtype, device=x.device)
+    nparts = int(lib.c.aum_conv1d_tm_nparts(batch, length))
+    f32 = dict(dtype=torch.float32, device=x.device)
+    dw_part = torch.empty((nparts, width, dim), **f32)
+    db_part = torch.empty((nparts, dim), **f32) if bias is not None else None
+    a = ConvTmArgs()
+    a.x, a.dy, a.weight, a.bias, a.dx, a.dw_part, a.db_part = map(_ptr, (x, dy, weight, bias, dx, dw_part, db_part))
+    a.x_bs, a.x_ts = _tm3(x, "x", dim)
+    a.dy_bs, a.dy_ts = _tm3(dy, "dy", dim)
+    a.dx_bs, a.dx_ts = _tm3(dx, "dx", dim)
+    a.batch, a.dim, a.len, a.width, a.dtype = batch, dim, length, width, _DT[x.dtype]
+    a.flags = (CONV_SILU if silu else 0) | (CONV_REVERSE if reverse else 0)
+    _launch(lib.c.aum_conv1d_tm_bwd, a, x, lib, "conv_tm_bwd", (batch, dim, length, x.element_size()))
+    dweight = sum_rows(dw_part, lib=lib).t().contiguous()
+    dbias = sum_rows(db_part, lib=lib) if db_part is not None else None
+    return dx, dweight, dbias
 
 
 def conv1d_fwd(x, weight, bias=None, silu=True, reverse=False, dmajor=False, generic=False, lib=None):

@@ -1,0 +1,216 @@
+// conv_tm_kernels.h -- width <= 4 depthwise causal conv1d (+ SiLU) on TOKEN-MAJOR activations (batch, len, dim): the channel is the
+// fastest axis, so a lane owns 16 bytes of consecutive channels (8 of a 16-bit type), a wave 1 KB of a token row, and the causal
+// window is four REGISTER rows that slide along time -- no halo exchange between lanes, every global access a full 16 bytes per lane.
+// x may be the first half of the in_proj output (row stride 2 * dim), dx the first half of its gradient.
+//   forward   (MS:272 / causal_conv1d_fn):  y[t] = silu(bias + sum_k w[k] x[t - (W-1) + k])
+//   backward  (SSI:594-596 call site):      dpre = dy silu'(pre);  dx[t] = sum_k w[k] dpre[t + (W-1) - k];
+//                                           dw[k] = sum_{b,t} dpre[t] x[t - (W-1) + k];  dbias = sum_{b,t} dpre[t]
+// AUM_CONV_REVERSE: the same on the time-reversed sequence (flip(conv(flip(x))) without the copies) -- the wave walks time the other way.
+// A wave takes CONVT_TC steps of one batch entry; the backward walks them from the last to the first (dx[t] needs dpre[t .. t+3], known
+// by then) and leaves ONE partial row of dw / dbias per wave: [part][k][dim] and [part][dim] fp32, summed by aum_sum_rows in a fixed
+// order (no atomics: bitwise repeatable).
+#pragma once
+#include "wave.h"
+
+namespace aum {
+
+constexpr int CONVT_W = 4;
+constexpr int CONVT_TC = 64;       // time steps per wave
+constexpr int CONVT_UB = 8;        // steps fetched together (raw 16-byte fragments, widened when used)
+
+AUM_HOSTDEV inline int convt_chunks(int len) { return (len + CONVT_TC - 1) / CONVT_TC; }
+template <class T> AUM_HOSTDEV constexpr int convt_vec() { return 16 / (int)sizeof(T); }
+template <class T> AUM_HOSTDEV inline int convt_cblocks(int dim) { return (dim + WAVE * convt_vec<T>() - 1) / (WAVE * convt_vec<T>()); }
+AUM_HOSTDEV inline int convt_nparts(int batch, int len) { return batch * convt_chunks(len); }
+
+AUM_DEV vf convt_silu(vf a) { return a * vsigmoid(a); }
+
+template <class T> struct ConvtLane {
+    static constexpr int V = convt_vec<T>();
+    vf w[CONVT_W][V];      // w[k][v]: tap k (right-aligned: taps 4 - width .. 3 are real) of channel c0 + v
+    vf bias[V];
+    vi c0;                 // first channel of the lane (clamped into the tensor for lanes past the end)
+    vm live;
+};
+template <class T> AUM_DEV void convt_lane_setup(const AumConvTmArgs& a, int cb, ConvtLane<T>& ln) {
+    constexpr int V = convt_vec<T>();
+    const vi c = (lane_id() + cb * WAVE) * V;
+    ln.live = c < a.dim;
+    ln.c0 = vsel_i(ln.live, c, c * 0);
+    AUM_UNROLL
+    for (int v = 0; v < V; ++v) {
+        AUM_UNROLL
+        for (int k = 0; k < CONVT_W; ++k) {
+            const int kk = k - (CONVT_W - a.width);
+            ln.w[k][v] = kk >= 0 ? gload_u(a.weight, (ln.c0 + v) * a.width + kk) : splat(0.f);
+        }
+        ln.bias[v] = a.bias ? gload_u(a.bias, ln.c0 + v) : splat(0.f);
+    }
+}
+
+// unit = (batch entry, chunk of CONVT_TC steps, block of 64 * V channels), channel block fastest
+template <class T, bool SILU>
+AUM_DEV void convt_fwd_wave(const AumConvTmArgs& a, int wg) {
+    constexpr int V = convt_vec<T>(), ES = (int)sizeof(T);
+    const int ncb = convt_cblocks<T>(a.dim), nch = convt_chunks(a.len), L = a.len;
+    const int cb = wg % ncb, ch = (wg / ncb) % nch, b = wg / (ncb * nch);
+    const bool rev = (a.flags & AUM_CONV_REVERSE) != 0;
+    ConvtLane<T> ln;
+    convt_lane_setup<T>(a, cb, ln);
+    const gbuf<T> xb = make_gbuf(row_ptr<T>(a.x, (int64_t)b * a.x_bs));
+    const gbuf<T> yb = make_gbuf(row_ptr<T>(a.y, (int64_t)b * a.y_bs));
+    const vi coff = ln.c0 * ES;
+    const int x_tb = (int)a.x_ts * ES, y_tb = (int)a.y_ts * ES;
+    auto tok = [&](int it) { return rev ? L - 1 - it : it; };
+    const int it0 = ch * CONVT_TC, it1 = it0 + CONVT_TC < L ? it0 + CONVT_TC : L;
+    vf xw[CONVT_W][V];
+    // the window before the chunk: steps it0 - 3 .. it0 - 1 (zero padding before the sequence)
+    AUM_UNROLL
+    for (int k = 0; k < CONVT_W - 1; ++k) {
+        const int it = it0 - (CONVT_W - 1) + k;
+        if (it >= 0) {
+            vq_unpack<T>(gbuf_load16(xb, coff, tok(it) * x_tb), xw[k + 1]);
+        } else {
+            AUM_UNROLL
+            for (int v = 0; v < V; ++v) xw[k + 1][v] = splat(0.f);
+        }
+    }
+    for (int itb = it0; itb < it1; itb += CONVT_UB) {
+        vq raw[CONVT_UB];
+        AUM_UNROLL
+        for (int j = 0; j < CONVT_UB; ++j) {
+            const int it = itb + j < it1 ? itb + j : it1 - 1;
+            raw[j] = gbuf_load16(xb, coff, tok(it) * x_tb);
+        }
+        AUM_UNROLL
+        for (int j = 0; j < CONVT_UB; ++j) {
+            if (itb + j < it1) {
+                AUM_UNROLL
+                for (int k = 0; k < CONVT_W - 1; ++k) {
+                    AUM_UNROLL
+                    for (int v = 0; v < V; ++v) xw[k][v] = xw[k + 1][v];
+                }
+                vq_unpack<T>(raw[j], xw[CONVT_W - 1]);
+                vf y[V];
+                AUM_UNROLL
+                for (int v = 0; v < V; ++v) {
+                    vf acc = ln.bias[v];
+                    AUM_UNROLL
+                    for (int k = 0; k < CONVT_W; ++k) acc = vfma(ln.w[k][v], xw[k][v], acc);
+                    y[v] = SILU ? convt_silu(acc) : acc;
+                }
+                gbuf_store16_m(yb, coff, tok(itb + j) * y_tb, vq_pack<T>(y), ln.live);
+            }
+        }
+    }
+}
+
+// backward: steps it1 - 1 down to it0; the three steps after the chunk are recomputed first (their dpre enters dx of the chunk's
+// last steps), their dw / dbias terms belong to the next chunk
+template <class T, bool SILU>
+AUM_DEV void convt_bwd_wave(const AumConvTmArgs& a, int wg) {
+    constexpr int V = convt_vec<T>(), ES = (int)sizeof(T);
+    const int ncb = convt_cblocks<T>(a.dim), nch = convt_chunks(a.len), L = a.len;
+    const int cb = wg % ncb, ch = (wg / ncb) % nch, b = wg / (ncb * nch);
+    const bool rev = (a.flags & AUM_CONV_REVERSE) != 0;
+    ConvtLane<T> ln;
+    convt_lane_setup<T>(a, cb, ln);
+    const gbuf<T> xb = make_gbuf(row_ptr<T>(a.x, (int64_t)b * a.x_bs));
+    const gbuf<T> gb = make_gbuf(row_ptr<T>(a.dy, (int64_t)b * a.dy_bs));
+    const gbuf<T> dxb = make_gbuf(row_ptr<T>(a.dx, (int64_t)b * a.dx_bs));
+    const vi coff = ln.c0 * ES;
+    const int x_tb = (int)a.x_ts * ES, g_tb = (int)a.dy_ts * ES, dx_tb = (int)a.dx_ts * ES;
+    auto tok = [&](int it) { return rev ? L - 1 - it : it; };
+    const int it0 = ch * CONVT_TC, it1 = it0 + CONVT_TC < L ? it0 + CONVT_TC : L;
+    const int itop = it1 + (CONVT_W - 1) < L ? it1 + (CONVT_W - 1) : L;        // first step NOT recomputed
+    // xw[k] = x[it - 3 + k] of the step being processed (walking down, a new x[it - 3] enters at k = 0); dp[k] = dpre[it + k]
+    vf xw[CONVT_W][V], dp[CONVT_W][V], dw[CONVT_W][V], db[V];
+    AUM_UNROLL
+    for (int v = 0; v < V; ++v) {
+        db[v] = splat(0.f);
+        AUM_UNROLL
+        for (int k = 0; k < CONVT_W; ++k) {
+            dw[k][v] = splat(0.f);
+            dp[k][v] = splat(0.f);
+        }
+    }
+    // window of the first step processed (itop - 1): x[itop - 4 .. itop - 1]; its k = 0 row is loaded in the loop, rows 1..3 here
+    AUM_UNROLL
+    for (int k = 1; k < CONVT_W; ++k) {
+        const int it = itop - 1 - (CONVT_W - 1) + k;
+        if (it >= 0) {
+            vq_unpack<T>(gbuf_load16(xb, coff, tok(it) * x_tb), xw[k - 1]);       // stored one slot low: the loop shifts up before use
+        } else {
+            AUM_UNROLL
+            for (int v = 0; v < V; ++v) xw[k - 1][v] = splat(0.f);
+        }
+    }
+    for (int itb = itop - 1; itb >= it0; itb -= CONVT_UB) {
+        vq rx[CONVT_UB], rg[CONVT_UB];
+        AUM_UNROLL
+        for (int j = 0; j < CONVT_UB; ++j) {
+            const int it = itb - j >= it0 ? itb - j : it0;
+            const int itx = it - (CONVT_W - 1) >= 0 ? it - (CONVT_W - 1) : 0;
+            rx[j] = gbuf_load16(xb, coff, tok(itx) * x_tb);
+            rg[j] = gbuf_load16(gb, coff, tok(it) * g_tb);
+        }
+        AUM_UNROLL
+        for (int j = 0; j < CONVT_UB; ++j) {
+            const int it = itb - j;
+            if (it >= it0) {
+                AUM_UNROLL
+                for (int k = CONVT_W - 1; k > 0; --k) {
+                    AUM_UNROLL
+                    for (int v = 0; v < V; ++v) {
+                        xw[k][v] = xw[k - 1][v];
+                        dp[k][v] = dp[k - 1][v];
+                    }
+                }
+                if (it - (CONVT_W - 1) >= 0) {
+                    vq_unpack<T>(rx[j], xw[0]);
+                } else {
+                    AUM_UNROLL
+                    for (int v = 0; v < V; ++v) xw[0][v] = splat(0.f);
+                }
+                vf g[V], dxv[V];
+                vq_unpack<T>(rg[j], g);
+                const bool own = it < it1;
+                AUM_UNROLL
+                for (int v = 0; v < V; ++v) {
+                    vf d = g[v];
+                    if (SILU) {
+                        vf pre = ln.bias[v];
+                        AUM_UNROLL
+                        for (int k = 0; k < CONVT_W; ++k) pre = vfma(ln.w[k][v], xw[k][v], pre);
+                        const vf sg = vsigmoid(pre);
+                        d = d * (sg * vfma(pre, splat(1.f) - sg, splat(1.f)));
+                    }
+                    dp[0][v] = d;
+                    if (own) {
+                        db[v] = db[v] + d;
+                        AUM_UNROLL
+                        for (int k = 0; k < CONVT_W; ++k) dw[k][v] = vfma(d, xw[k][v], dw[k][v]);
+                        vf s = splat(0.f);
+                        AUM_UNROLL
+                        for (int k = 0; k < CONVT_W; ++k) s = vfma(ln.w[k][v], dp[CONVT_W - 1 - k][v], s);
+                        dxv[v] = s;
+                    }
+                }
+                if (own) gbuf_store16_m(dxb, coff, tok(it) * dx_tb, vq_pack<T>(dxv), ln.live);
+            }
+        }
+    }
+    // partial rows of this wave: dw_part[part][k][dim], db_part[part][dim]
+    const int part = b * nch + ch;
+    AUM_UNROLL
+    for (int v = 0; v < V; ++v) {
+        AUM_UNROLL
+        for (int k = 0; k < CONVT_W; ++k) {
+            const int kk = k - (CONVT_W - a.width);
+            if (kk >= 0) gstore(a.dw_part + ((int64_t)part * a.width + kk) * a.dim, ln.c0 + v, dw[k][v], ln.live);
+        }
+        if (a.db_part) gstore(a.db_part + (int64_t)part * a.dim, ln.c0 + v, db[v], ln.live);
+    }
+}
+
+}  // namespace aum

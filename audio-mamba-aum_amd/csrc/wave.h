@@ -408,6 +408,32 @@ template <class T> AUM_DEV void gbuf_store16(const gbuf<T>& b, vi voff_bytes, in
 template <class T> AUM_DEV void gbuf_store16_m(const gbuf<T>& b, vi voff_bytes, int soff_bytes, const vq& q, vm m) {
     if (m) gbuf_store16(b, voff_bytes, soff_bytes, q);
 }
+// the 16 / sizeof(T) consecutive elements of a 16-byte access as fp32, and back (round to nearest even)
+template <class T> AUM_DEV void vq_unpack(const vq& q, vf (&o)[16 / sizeof(T)]) {
+    if constexpr (sizeof(T) == 4) {
+        AUM_UNROLL
+        for (int i = 0; i < 4; ++i) o[i] = __builtin_bit_cast(float, q.w[i]);
+    } else {
+        AUM_UNROLL
+        for (int i = 0; i < 4; ++i) {
+            vpair_raw r;
+            r.w[0] = q.w[i];
+            r.w[1] = 0;
+            pair_raw_to_f32<T>(r, o[2 * i], o[2 * i + 1]);
+        }
+    }
+}
+template <class T> AUM_DEV vq vq_pack(const vf (&v)[16 / sizeof(T)]) {
+    vq q;
+    if constexpr (sizeof(T) == 4) {
+        AUM_UNROLL
+        for (int i = 0; i < 4; ++i) q.w[i] = __builtin_bit_cast(int, v[i]);
+    } else {
+        AUM_UNROLL
+        for (int i = 0; i < 4; ++i) q.w[i] = (int)f32x2_to_elem2<T>(v[2 * i], v[2 * i + 1]);
+    }
+    return q;
+}
 AUM_DEV void lds_write16(float* lds, vi byte_off, const vq& q) {
     typedef int i4 __attribute__((ext_vector_type(4)));
     *reinterpret_cast<i4*>(reinterpret_cast<char*>(lds) + byte_off) = i4{q.w[0], q.w[1], q.w[2], q.w[3]};
@@ -668,6 +694,28 @@ template <class T> inline void gbuf_store16_m(const gbuf<T>& b, const vi& voff_b
         for (int k = 0; k < 4; ++k) t[k] = q.w[k].v[l];
         std::memcpy((char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes, t, 16);
     }
+}
+template <class T> inline void vq_unpack(const vq& q, vf (&o)[16 / sizeof(T)]) {
+    constexpr int V = 16 / sizeof(T);
+    AUM_LANES {
+        int w[4];
+        for (int k = 0; k < 4; ++k) w[k] = q.w[k].v[l];
+        T e[V];
+        std::memcpy(e, w, 16);
+        for (int k = 0; k < V; ++k) o[k].v[l] = elem_to_f32(e[k]);
+    }
+}
+template <class T> inline vq vq_pack(const vf (&v)[16 / sizeof(T)]) {
+    constexpr int V = 16 / sizeof(T);
+    vq q;
+    AUM_LANES {
+        T e[V];
+        for (int k = 0; k < V; ++k) f32_to_elem(v[k].v[l], e[k]);
+        int w[4];
+        std::memcpy(w, e, 16);
+        for (int k = 0; k < 4; ++k) q.w[k].v[l] = w[k];
+    }
+    return q;
 }
 inline void lds_write16(float* lds, const vi& byte_off, const vq& q) {
     AUM_LANES {

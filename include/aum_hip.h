@@ -27,12 +27,13 @@
 extern "C" {
 #endif
 
-#define AUM_ABI_VERSION 7   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
+#define AUM_ABI_VERSION 8   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
                                3: x_lane (lane-entry state checkpoint of the L = 513 row kernels) appended after it;
                                4: aug / noise (per-clip augmentation in the log-mel kernel's epilogue) appended to AumFbankArgs;
                                5: aum_frontend_tokens_fwd (waveform -> token sequence in one launch);
                                6: aum_sum_rows (fixed-order sum of partial results);
-                               7: aum_scan_tm_fwd / _bwd (time-serial selective scan on token-major activations) */
+                               7: aum_scan_tm_fwd / _bwd (time-serial selective scan on token-major activations);
+                               8: aum_conv1d_tm_fwd / _bwd (the causal conv on token-major activations) */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 
@@ -339,6 +340,31 @@ typedef struct AumScanTmBwdArgs {
 } AumScanTmBwdArgs;
 int aum_scan_tm_bwd(const AumScanTmBwdArgs* args, void* stream);
 int64_t aum_scan_tm_workspace_bytes(int32_t batch, int32_t dim, int32_t len, int32_t dstate, int32_t bidirectional);
+
+/*
+ * Depthwise causal conv1d (+ SiLU) on TOKEN-MAJOR activations (ABI 8): the same operator as aum_causal_conv1d_fwd / _bwd
+ * (MS:272 causal_conv1d_fn; SSI:463 forward and SSI:594-596 backward call sites) for tensors laid out (batch, len, dim) with the
+ * channel contiguous -- the layout of the in_proj output rows [x | z] and of the time-serial scan's operands, so x / dx may be the
+ * first half of a (batch, len, 2 dim) tensor (strides in ELEMENTS: *_bs batch, *_ts token; channel stride 1).
+ *   x, y, dy, dx in `dtype`; weight (dim, width) fp32, width <= 4; bias (dim) fp32 or NULL; flags: AUM_CONV_SILU, AUM_CONV_REVERSE.
+ *   backward: dx written; dw_part [nparts][width][dim] and db_part [nparts][dim] (NULL without bias) fp32 are per-wave partial sums
+ *   (nparts = aum_conv1d_tm_nparts(batch, len)) that the caller adds up in a fixed order (aum_sum_rows): no atomics.
+ * Limits: dim % (16 / sizeof(dtype)) == 0, 16-byte aligned pointers and row strides.
+ */
+typedef struct AumConvTmArgs {
+    const void *x, *dy;      /* dy: backward only */
+    const float *weight, *bias;
+    void *y;                 /* forward */
+    void *dx;                /* backward */
+    float *dw_part, *db_part;
+    int64_t x_bs, x_ts, y_bs, y_ts, dy_bs, dy_ts, dx_bs, dx_ts;
+    int32_t batch, dim, len, width;
+    int32_t dtype;
+    uint32_t flags;
+} AumConvTmArgs;
+int aum_conv1d_tm_fwd(const AumConvTmArgs* args, void* stream);
+int aum_conv1d_tm_bwd(const AumConvTmArgs* args, void* stream);
+int32_t aum_conv1d_tm_nparts(int32_t batch, int32_t len);
 
 /* Self-tests and calibration (used by tests/ and bench.py; not part of the reference's surface). */
 int aum_abi_version(void);

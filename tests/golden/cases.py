@@ -73,6 +73,17 @@ CONV_CASES = [
     ("l512_b9", 9, 2, 512, 4, True),
 ]
 
+# token-major conv (batch, len, dim): dim a multiple of 8; chunks of 64 steps per wave, 512 channels (16-bit) / 256 (fp32) per wave
+CONV_TM_CASES = [
+    ("tm_l1", 2, 8, 1, 4, True),
+    ("tm_l3", 2, 16, 3, 4, True),
+    ("tm_l65", 2, 24, 65, 4, True),
+    ("tm_l130_nobias", 2, 8, 130, 4, False),
+    ("tm_l70_w3", 1, 8, 70, 3, True),
+    ("tm_l64", 1, 8, 64, 4, True),
+    ("tm_l513_d520", 1, 520, 513, 4, True),
+]
+
 # (name, rows(list shape), cols, has_residual, prenorm)
 NORM_CASES = [
     ("r130_c192_res_pre", (2, 65), 192, True, True),

@@ -104,6 +104,40 @@ def check_conv(lib, dev, case, dtype=torch.float32, reverse=False, silu=True, ge
     return errs
 
 
+def check_conv_tm(lib, dev, case, dtype=torch.float32, reverse=False, silu=True, xz_layout=False):
+    """aum_conv1d_tm_fwd / _bwd against the same oracle as the channel-major conv, on (batch, len, dim) operands; xz_layout: x and dx
+    are the first halves of (batch, len, 2 dim) tensors, as in the block."""
+    name = case[0]
+    d = cases.conv_inputs(*case)
+    tol = 1e-5 if dtype == torch.float32 else TOL_BF16
+    q = {k: rq(d[k], dtype) for k in ("x", "dout")}
+    tm = lambda a: T(np.ascontiguousarray(a.transpose(0, 2, 1)), dev, dtype)
+    x, dy = tm(d["x"]), tm(d["dout"])
+    dim = x.shape[2]
+    dx_out = None
+    if xz_layout:
+        xz = torch.zeros(x.shape[0], x.shape[1], 2 * dim, dtype=x.dtype, device=x.device)
+        xz[:, :, :dim] = x
+        x = xz[:, :, :dim]
+        dxz = torch.zeros_like(xz)
+        dx_out = dxz[:, :, :dim]
+    assert aum_hip.conv1d_tm_supported(x, d["weight"].shape[1])
+    w, b = T(d["weight"], dev), T(d["bias"], dev)
+    y = aum_hip.conv1d_tm_fwd(x, w, b, silu, reverse, lib=lib)
+    ry = O.conv1d_fwd(q["x"], d["weight"], d["bias"], silu, reverse, "f64")
+    dx, dw, db = aum_hip.conv1d_tm_bwd(x, w, b, dy, silu, reverse, dx_out=dx_out, lib=lib)
+    rg = O.conv1d_bwd(q["x"], d["weight"], d["bias"], q["dout"], silu, reverse, "f64")
+    untm = lambda t: N(t).transpose(0, 2, 1)
+    errs = {"y": rel_err(untm(y), ry), "dx": rel_err(untm(dx), rg["dx"]), "dw": rel_err(N(dw), rg["dweight"])}
+    if b is not None:
+        errs["db"] = rel_err(N(db), rg["dbias"])
+    if xz_layout:
+        assert float(dxz[:, :, dim:].abs().max()) == 0.0, (name, "dx wrote outside its half")
+    bad = {k: v for k, v in errs.items() if not v < tol * (4 if k != "y" else 1)}
+    assert not bad, (name, bad)
+    return errs
+
+
 def check_norm(lib, dev, case, dtype=torch.float32, res_dtype=torch.float32, generic=False):
     name, lead, cols, has_res, prenorm = case
     d = cases.norm_inputs(*case)

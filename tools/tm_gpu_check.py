@@ -17,6 +17,17 @@ bwd = "--bwd" in sys.argv
 bad = 0
 KC.check_wave_sum32(lib, "cuda")
 print("ok  wave_sum32 / wave_sum16")
+for case in cases.CONV_TM_CASES:
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        for rev in (False, True):
+            for silu, xz in ((True, False), (True, True), (False, False)):
+                try:
+                    e = KC.check_conv_tm(lib, "cuda", case, dt, rev, silu, xz)
+                    print("ok ", case[0], str(dt)[6:], "rev" if rev else "", "silu" if silu else "", "xz" if xz else "",
+                          " ".join(f"{k}={v:.1e}" for k, v in e.items()), flush=True)
+                except AssertionError as ex:
+                    bad += 1
+                    print("BAD", case[0], str(dt)[6:], rev, silu, xz, ex, flush=True)
 for case in cases.SCAN_TM_CASES:
     for mode in ("fwd", "rev", "bidir"):
         for dt, xz in ((torch.float32, False), (torch.bfloat16, True), (torch.bfloat16, False), (torch.float16, False)):

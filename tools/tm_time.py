@@ -26,6 +26,7 @@ A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(E, 1) * (1 +
 A_b, D, bias = A * 1.05, torch.ones(E, device=dev), torch.full((E,), -4.0, device=dev) + torch.rand(E, device=dev)
 dsp = torch.nn.functional.softplus(dl.float() + bias).to(dt)
 dout = torch.randn(Bsz, L, E, device=dev).to(dt)
+cw, cb = torch.randn(E, 4, device=dev), torch.randn(E, device=dev)
 ck2 = aum_hip.scan_tm_ckpt(Bsz, L, E, N, True, dev)
 for rep in range(6):
     # delta ready (the producer applied the softplus), training form
@@ -34,6 +35,9 @@ for rep in range(6):
     # raw delta + bias + softplus inside
     _, pre = aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, ckpt=ck2, lib=lib)
     aum_hip.scan_tm_bwd(u, dl, A, Bm, Cm, D, z, bias, dout, pre, ck2, True, A_b=A_b, lib=lib)
+    # the conv on the first half of the in_proj output rows
+    aum_hip.conv1d_tm_fwd(xz[:, :, :E], cw, cb, True, lib=lib)
+    aum_hip.conv1d_tm_bwd(xz[:, :, :E], cw, cb, dout, True, dx_out=torch.empty_like(xz)[:, :, :E], lib=lib)
     # inference form
     aum_hip.scan_tm_fwd(u, dsp, A, Bm, Cm, D, z, None, False, A_b=A_b, lib=lib)
 torch.cuda.synchronize()

@@ -11,7 +11,7 @@ acc = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         n = row["Kernel_Name"]
-        if "k_scan" in n:
+        if "k_scan" in n or "k_convt" in n or "k_sum_rows" in n:
             acc[n[:110]].append((float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) / 1e3)
 for k, v in sorted(acc.items()):
     v = sorted(v)
