@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from mamba_ssm.ops.selective_scan_interface import (InProjFn, bimamba_inner_fn, mamba_inner_fn, mamba_inner_fn_no_out_proj,
                                                     neg_exp, selective_scan_fn)
+import mamba_ssm.ops.selective_scan_interface as ssi
 from causal_conv1d import causal_conv1d_fn
 
 
@@ -91,9 +92,18 @@ class Mamba(nn.Module):
                 out, _, _ = self.step(hidden_states, conv_state, ssm_state)    # states updated in place
                 return out
         batch, seqlen, _ = hidden_states.shape
-        # matmul + transpose in one GEMM: xz is (B, 2E, L) stored channel-major, like MS:185-189
-        xz = InProjFn.apply(self.in_proj.weight, hidden_states.reshape(batch * seqlen, -1))
-        xz = xz.reshape(-1, batch, seqlen).permute(1, 0, 2)
+        tm = (ssi.TOKEN_MAJOR and hidden_states.is_cuda and self.use_fast_path and inference_params is None
+              and self.bimamba_type in ("v1", "none")
+              and ssi.token_major_ok(self.d_inner, self.d_state, self.d_conv, self.dt_rank,
+                                     torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else hidden_states.dtype))
+        if tm:
+            # token-major block: xz rows [x | z] as the GEMM writes them; (B, 2E, L) is the transposed VIEW the interface expects
+            xz = ssi.InProjTmFn.apply(self.in_proj.weight, hidden_states.reshape(batch * seqlen, -1))
+            xz = xz.view(batch, seqlen, -1).transpose(1, 2)
+        else:
+            # matmul + transpose in one GEMM: xz is (B, 2E, L) stored channel-major, like MS:185-189
+            xz = InProjFn.apply(self.in_proj.weight, hidden_states.reshape(batch * seqlen, -1))
+            xz = xz.reshape(-1, batch, seqlen).permute(1, 0, 2)
         if self.in_proj.bias is not None:
             xz = xz + self.in_proj.bias.to(xz.dtype)[None, :, None]
         A = neg_exp(self.A_log)

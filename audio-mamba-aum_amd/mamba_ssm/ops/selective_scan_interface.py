@@ -29,6 +29,9 @@ import aum_hip
 _STEP_CACHE_ON = os.environ.get("AUM_STEP_CACHE", "1") != "0"
 _WGRAD_SPLIT_ON = os.environ.get("AUM_WGRAD_SPLIT", "1") != "0"
 _REF_DZ_DROP = os.environ.get("AUM_REF_DZ_DROP", "0") == "1"
+# AUM_TOKEN_MAJOR=0: the blocks keep their activations channel-major [E][B*L] (rounds 1-2: the row kernels); default: token-major
+# [B*L][E] rows (the time-serial scan kernels, the register-window conv, plain row-major GEMMs) where the shape allows it
+TOKEN_MAJOR = os.environ.get("AUM_TOKEN_MAJOR", "1") != "0"
 
 _custom_fwd = torch.amp.custom_fwd(device_type="cuda")
 _custom_bwd = torch.amp.custom_bwd(device_type="cuda")
@@ -301,6 +304,132 @@ class InProjFn(torch.autograd.Function):
         return dw, (None if dh is None else dh.to(ctx.hdtype))
 
 
+def _mm_rows(a, b, bit):
+    """a [ntok, K] @ b [K, N] -> [ntok, N] with the tile-aligned token split of _mm_tokens_rows (tokens = rows of a)"""
+    ntok = a.shape[0]
+    n0 = _tok_n0(ntok, bit, a)
+    if not n0:
+        return torch.matmul(a, b)
+    out = torch.empty((ntok, b.shape[1]), dtype=a.dtype, device=a.device)
+    torch.matmul(a[:n0], b, out=out[:n0])
+    torch.matmul(a[n0:], b, out=out[n0:])
+    return out
+
+
+class InProjTmFn(torch.autograd.Function):
+    """xz2d [B*L, 2E] = hidden2d [B*L, D] @ W^T: the token-major form of InProjFn (MS:185-189 without the BLH -> HBL transpose: the
+    token-major kernels read the rows as they are)."""
+
+    @staticmethod
+    def forward(ctx, weight, hidden2d):
+        w = _cast(weight, _autocast_dtype())
+        h = hidden2d.to(w.dtype)
+        ctx.save_for_backward(w, h)
+        ctx.wdtype, ctx.hdtype = weight.dtype, hidden2d.dtype
+        return _mm_rows(h, w.t(), 1)
+
+    @staticmethod
+    def backward(ctx, dxz2d):
+        w, h = ctx.saved_tensors
+        dxz2d = dxz2d.to(w.dtype)
+        dh = _mm_rows(dxz2d, w, 8) if ctx.needs_input_grad[1] else None
+        dw = split_k_wgrad(dxz2d.t(), h, _pick_splits(h.shape[0], _WGRAD_SPLITS[0]), ctx.wdtype) if ctx.needs_input_grad[0] else None
+        return dw, (None if dh is None else dh.to(ctx.hdtype))
+
+
+def token_major_ok(d_inner, d_state, d_conv, dt_rank, dtype=None):
+    """shapes the token-major kernels take (include/aum_hip.h: aum_scan_tm_*, aum_conv1d_tm_*); B and C are read in place from the
+    x_proj output rows, so the dt block in front of them has to keep them 16-byte aligned"""
+    es = 2 if dtype in (torch.bfloat16, torch.float16) else 4
+    return (aum_hip.scan_tm_supported(d_inner, d_state) and d_conv <= 4 and (dt_rank * es) % 16 == 0
+            and ((dt_rank + 2 * d_state) * es) % 16 == 0)
+
+
+def _is_tm(xz):
+    """(B, 2E, L) logical tensor stored token-major: the transpose view of a (B, L, 2E) tensor with contiguous rows"""
+    return xz.dim() == 3 and xz.stride(1) == 1 and xz.shape[1] > 1 and xz.is_cuda
+
+
+def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, A_b, D,
+                      delta_bias, delta_softplus, reverse):
+    """_inner_forward on token-major activations: every tensor is (B, L, X) with X contiguous.
+      conv (SSI:463) -> x_dbl = conv_out W_x^T (SSI:467) -> delta = x_dbl[:, :R] W_dt^T (SSI:468) -> B, C = column blocks of x_dbl read in
+      place (SSI:473-493) -> one selective-scan launch, both directions (SSI:499-507) -> out_proj (SSI:517)."""
+    act = _autocast_dtype()
+    ctx.out_proj_wdtype = out_proj_weight.dtype if out_proj_weight is not None else None
+    x_proj_weight, delta_proj_weight = _cast(x_proj_weight, act), _cast(delta_proj_weight, act)
+    out_proj_weight, out_proj_bias = _cast(out_proj_weight, act), _cast(out_proj_bias, act)
+    xz_t = xz.transpose(1, 2)                                      # (B, L, 2E), rows contiguous
+    Bsz, L, two_e = xz_t.shape
+    E = two_e // 2
+    R = delta_proj_weight.shape[1]
+    N = A.shape[-1]
+    x, z = xz_t[:, :, :E], xz_t[:, :, E:]
+    conv_w = conv1d_weight.reshape(E, -1)
+    conv_out = aum_hip.conv1d_tm_fwd(x, conv_w, conv1d_bias, True, reverse)                 # SSI:463  (B, L, E)
+    conv2d = conv_out.view(Bsz * L, E)
+    x_dbl = torch.matmul(conv2d, x_proj_weight.t().to(conv2d.dtype))                        # SSI:467  (BL, R+2N)
+    delta = torch.matmul(x_dbl[:, :R], delta_proj_weight.t().to(x_dbl.dtype))               # SSI:468  (BL, E)
+    x3 = x_dbl.view(Bsz, L, R + 2 * N)
+    Bm, Cm = x3[:, :, R:R + N], x3[:, :, R + N:]                                            # SSI:479  views, no copies
+    need_bwd = any(ctx.needs_input_grad)
+    ckpt = aum_hip.scan_tm_ckpt(Bsz, L, E, N, A_b is not None, xz.device) if need_bwd else None
+    out_z, out_pre = aum_hip.scan_tm_fwd(conv_out, delta.view(Bsz, L, E), A, Bm, Cm, D, z, delta_bias, delta_softplus,
+                                         reverse if A_b is None else False, A_b=A_b, want_out_pre=need_bwd, ckpt=ckpt)
+    ctx.tm = True
+    ctx.delta_softplus, ctx.reverse = delta_softplus, reverse
+    ctx.has_out_proj = out_proj_weight is not None
+    ctx.out_proj_bias_is_None = out_proj_bias is None
+    ctx.save_for_backward(xz, conv_w, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, A_b, D,
+                          delta_bias, out_pre, out_z, ckpt)
+    if out_proj_weight is None:
+        return out_z.transpose(1, 2)                                                         # SSI:224  (B, E, L) logical
+    out = _mm_rows(out_z.view(Bsz * L, E), out_proj_weight.t(), 2)                           # SSI:517
+    if out_proj_bias is not None:
+        out = out + out_proj_bias
+    return out.reshape(Bsz, L, -1)
+
+
+def _inner_backward_tm(ctx, dout):
+    (xz, conv_w, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, A_b, D, delta_bias, out_pre,
+     out_z, ckpt) = ctx.saved_tensors
+    xz_t = xz.transpose(1, 2)
+    Bsz, L, two_e = xz_t.shape
+    E = two_e // 2
+    R = delta_proj_weight.shape[1]
+    N = A.shape[-1]
+    x, z = xz_t[:, :, :E], xz_t[:, :, E:]
+    dxz_t = torch.empty((Bsz, L, two_e), dtype=xz.dtype, device=xz.device)                   # SSI:537
+    dx, dz = dxz_t[:, :, :E], dxz_t[:, :, E:]
+    dout_proj_weight = dout_proj_bias = None
+    if ctx.has_out_proj:
+        dout2 = dout.reshape(Bsz * L, -1).to(out_proj_weight.dtype)
+        dout_z = _mm_rows(dout2, out_proj_weight, 4).view(Bsz, L, E)                          # SSI:540
+        dout_proj_weight = split_k_wgrad(dout2.t(), out_z.view(Bsz * L, E), _pick_splits(dout2.shape[0], _WGRAD_SPLITS[1]),
+                                         ctx.out_proj_wdtype)                                 # SSI:563
+        dout_proj_bias = dout2.sum(0) if not ctx.out_proj_bias_is_None else None
+    else:
+        dout_z = dout.transpose(1, 2)
+        dout_z = (dout_z if dout_z.stride(2) == 1 else dout_z.contiguous()).to(xz.dtype)
+    x3 = x_dbl.view(Bsz, L, R + 2 * N)
+    g = aum_hip.scan_tm_bwd(conv_out, delta.view(Bsz, L, E), A, x3[:, :, R:R + N], x3[:, :, R + N:], D, z, delta_bias, dout_z, out_pre,
+                            ckpt, ctx.delta_softplus, ctx.reverse if A_b is None else False, A_b=A_b, dz_out=dz)   # SSI:541-561
+    if _REF_DZ_DROP and A_b is not None:
+        raise NotImplementedError("AUM_REF_DZ_DROP reproduces SSI:560/599 on the channel-major path only (AUM_TOKEN_MAJOR=0)")
+    du2, ddelta2 = g["du"].view(Bsz * L, E), g["ddelta"].view(Bsz * L, E)
+    dx_dbl = torch.empty_like(x_dbl)
+    dx_dbl[:, R:].copy_(g["dBC"].view(Bsz * L, 2 * N))                                       # SSI:570-574
+    dx_dbl[:, :R].copy_(torch.matmul(ddelta2, delta_proj_weight.to(ddelta2.dtype)))          # SSI:587
+    splits = _pick_splits(Bsz * L, _WGRAD_SPLITS[1])
+    ddelta_proj_weight = split_k_wgrad(ddelta2.t(), x_dbl[:, :R], splits, torch.float32)     # SSI:586
+    dx_proj_weight = split_k_wgrad(dx_dbl.t(), conv_out.view(Bsz * L, E), splits, torch.float32)   # SSI:589
+    du2.addmm_(dx_dbl, x_proj_weight.to(dx_dbl.dtype))                                       # SSI:590
+    _, dconv_w, dconv_b = aum_hip.conv1d_tm_bwd(x, conv_w, conv1d_bias, g["du"], True, ctx.reverse, dx_out=dx)   # SSI:594
+    return dict(dxz=dxz_t.transpose(1, 2), dconv_w=dconv_w.reshape(E, 1, -1), dconv_b=dconv_b, dx_proj_w=dx_proj_weight,
+                ddt_proj_w=ddelta_proj_weight, dout_proj_w=dout_proj_weight, dout_proj_b=dout_proj_bias,
+                dA=g["dA"], dA_b=g.get("dA_b"), dD=g["dD"], ddelta_bias=g["ddelta_bias"], dB_proj_bias=None, dC_proj_bias=None)
+
+
 def _dm2d(t):
     """(B, E, L) channel-major tensor -> its [E, B*L] 2-D view (no copy)."""
     Bsz, E, L = t.shape
@@ -316,6 +445,12 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
                    out_proj_bias, A, A_b, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, reverse):
     if A.is_complex():
         raise NotImplementedError("real A only (SSI:502 asserts the same for the bidirectional path)")
+    ctx.tm = False
+    if (TOKEN_MAJOR and _is_tm(xz) and B_proj_bias is None and C_proj_bias is None and xz.stride(2) == xz.shape[1]
+            and token_major_ok(xz.shape[1] // 2, A.shape[-1], conv1d_weight.shape[-1], delta_proj_weight.shape[1], xz.dtype)
+            and aum_hip.conv1d_tm_supported(xz.transpose(1, 2)[:, :, :xz.shape[1] // 2], conv1d_weight.shape[-1])):
+        return _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                                 A, A_b, D, delta_bias, delta_softplus, reverse)
     act = _autocast_dtype()
     ctx.out_proj_wdtype = out_proj_weight.dtype if out_proj_weight is not None else None
     # SSI:452-457: only the projection weights are cast.  The transposes feed the data-gradient kernel (SSI:587, 590).
@@ -389,6 +524,8 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
 
 
 def _inner_backward(ctx, dout):
+    if ctx.tm:
+        return _inner_backward_tm(ctx, dout)
     (xz, conv_w, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, A_b, Bm,
      Cm, D, delta_bias, out_pre, out_pre_b, out_z, ck_f, ck_b, x_proj_wt, delta_proj_wt) = ctx.saved_tensors
     Bsz, two_e, L = xz.shape

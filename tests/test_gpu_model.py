@@ -142,15 +142,25 @@ def test_mamba_slow_path_matches_fused_path():
         assert rel_err(ps[k].grad.cpu().numpy(), pf[k].grad.cpu().numpy()) < 1e-3, k
 
 
+@pytest.mark.parametrize("layout", ["channel_major", "token_major"])
 @pytest.mark.parametrize("case", cases.INNER_CASES, ids=lambda c: c[0])
-def test_inner_fns_vs_reference(case):
+def test_inner_fns_vs_reference(case, layout):
+    """the fused inner functions (SSI:155-603) against the reference's outputs and autograd gradients (golden/inner.npz), with xz
+    stored channel-major [2E][B*L] (the row kernels) and token-major [B*L][2E] (the time-serial kernels where the shape allows them:
+    d_inner % 64 == 0 -- the d64 cases; the others take the channel-major kernels after one copy, and must still be right)"""
     g = load_golden("inner")
     name = case[0]
     import mamba_ssm.ops.selective_scan_interface as ssi
     p = cases.inner_inputs(*case)
     t = {k: torch.tensor(v, device=DEV).requires_grad_(True) for k, v in p.items() if k != "dout"}
     mode = case[1]
-    xz = t["xz"].permute(1, 0, 2).contiguous().permute(1, 0, 2)
+    if layout == "token_major":
+        xz = t["xz"].transpose(1, 2).contiguous().transpose(1, 2)
+        assert ssi._is_tm(xz)
+        if case[3] % 32 == 0:       # d_inner = 2 d_model a multiple of 64: the token-major kernels must be the ones that run
+            assert ssi.token_major_ok(2 * case[3], 16, 4, t["dt_proj_w"].shape[1], torch.float32)
+    else:
+        xz = t["xz"].permute(1, 0, 2).contiguous().permute(1, 0, 2)
     if mode == "v1":
         o = ssi.bimamba_inner_fn(xz, t["conv_w"], t["conv_b"], t["x_proj_w"], t["dt_proj_w"], t["out_proj_w"], None,
                                  t["A"], t["A_b"], None, None, t["D"], delta_bias=t["dt_bias"], delta_softplus=True)
