@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(so_path):
     lib = ctypes.CDLL(so_path)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.aum_abi_version() == aum_hip.ABI_VERSION == 6
+    assert lib.aum_abi_version() == aum_hip.ABI_VERSION == 8
     assert lib.aum_scan_max_single_pass_len() == 576
     assert lib.aum_rmsnorm_bwd_partials(32832) == 4096
 
@@ -51,6 +51,12 @@ def test_struct_layouts_match_header(tmp_path):
                                                    "dtype", "out_dtype", "flags"]),
         "AumProjArgs": (aum_hip.ProjArgs, ["act", "w_dt", "out_act", "dB", "dC_ns", "ntok", "dim", "dtype", "w_ld"]),
         "AumProjWArgs": (aum_hip.ProjWArgs, ["x", "y", "out", "ntok", "dim", "nsplit", "dtype"]),
+        "AumScanTmFwdArgs": (aum_hip.ScanTmFwdArgs, ["u", "C", "A", "delta_bias", "out", "out_pre", "ckpt", "u_bs", "C_ts", "pre_ts", "batch",
+                                                     "dstate", "dtype", "flags"]),
+        "AumScanTmBwdArgs": (aum_hip.ScanTmBwdArgs, ["u", "dout", "out_pre", "A", "ckpt", "du", "dz", "dA", "dBC", "ddelta_bias", "workspace",
+                                                     "workspace_bytes", "u_bs", "pre_ts", "du_bs", "dz_ts", "batch", "dtype", "flags"]),
+        "AumConvTmArgs": (aum_hip.ConvTmArgs, ["x", "dy", "weight", "bias", "y", "dx", "dw_part", "db_part", "x_bs", "dx_ts", "batch", "width",
+                                               "dtype", "flags"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']
     for cname, (_, fields) in probes.items():

@@ -201,3 +201,37 @@ def test_sum_rows_emu(emu):
         got = aum_hip.sum_rows(t, lib=emu)
         assert got.dtype == torch.float32 and got.shape == t.shape[1:]
         assert torch.allclose(got, t.float().sum(0), rtol=1e-5, atol=1e-5)
+
+
+# ---- time-serial token-major kernels (scan_tm_kernels.h, conv_tm_kernels.h) ---------------------------------------------------
+def test_wave_sum_butterflies(emu):
+    KC.check_wave_sum32(emu, "cpu")
+
+
+@pytest.mark.parametrize("case", cases.SCAN_TM_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+def test_scan_tm(emu, case, mode):
+    """aum_scan_tm_fwd / _bwd (lanes = channels, time serial, token-major operands, state checkpoints every 8 steps, the Fo-Bi pair
+    meeting in the middle, three pairs per workgroup in the backward) against the fp64 oracle: fp32 at 1e-3, 16-bit I/O at 1e-2;
+    ragged blocks, L < 8, z / D absent, two batch entries, the [x | z] row layout of the block"""
+    for dt, xz in ((torch.float32, False), (torch.bfloat16, True)):
+        KC.check_scan_tm(emu, "cpu", case, dt, reverse=(mode == "rev"), bidir=(mode == "bidir"), xz_layout=xz, backward=True)
+
+
+@pytest.mark.parametrize("case", cases.CONV_TM_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_conv_tm(emu, case, reverse):
+    """aum_conv1d_tm_fwd / _bwd against the conv oracle: chunk seams (64 steps), width 3, no bias, more channels than one wave
+    covers, x / dx as the first half of wider rows, all three dtypes"""
+    for dt, silu, xz in ((torch.float32, True, False), (torch.bfloat16, True, True), (torch.float16, False, False)):
+        KC.check_conv_tm(emu, "cpu", case, dt, reverse, silu, xz)
+
+
+def test_tm_limits(emu):
+    """shapes outside the token-major kernels' limits are refused (callers fall back to the channel-major kernels)"""
+    assert aum_hip.scan_tm_supported(1536, 16) and not aum_hip.scan_tm_supported(1536, 8) and not aum_hip.scan_tm_supported(96, 16)
+    x = torch.zeros(1, 4, 12)
+    assert not aum_hip.conv1d_tm_supported(x.bfloat16(), 4) and aum_hip.conv1d_tm_supported(torch.zeros(1, 4, 16).bfloat16(), 4)
+    assert not aum_hip.conv1d_tm_supported(torch.zeros(1, 4, 16), 5)
+    with pytest.raises(RuntimeError, match="UNSUPPORTED|unsupported"):
+        aum_hip.conv1d_tm_fwd(x.bfloat16(), torch.zeros(12, 4), None, lib=emu)

@@ -319,3 +319,98 @@ def test_sum_rows(lib):
         assert got.dtype == torch.float32 and got.shape == t.shape[1:]
         assert (got.double() - ref).abs().max() <= 2e-6 * max(1.0, ref.abs().max().item()) * shape[0] ** 0.5, (shape, dt)
         assert torch.equal(got, aum_hip.sum_rows(t, lib=lib))
+
+
+# ---- time-serial token-major kernels --------------------------------------------------------------------------------------------
+def test_wave_sum_butterflies(lib):
+    """the masked-DPP / permlane-swap butterflies on the real lanes (the emulator states their result, not their data movement)"""
+    KC.check_wave_sum32(lib, "cuda")
+
+
+@pytest.mark.parametrize("case", cases.SCAN_TM_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_scan_tm(lib, case, mode, dtype):
+    for xz in ((False, True) if dtype == torch.bfloat16 else (False,)):
+        KC.check_scan_tm(lib, "cuda", case, dtype, reverse=(mode == "rev"), bidir=(mode == "bidir"), xz_layout=xz, backward=True,
+                         tol=2e-3 if dtype == torch.float16 else None)
+
+
+@pytest.mark.parametrize("case", cases.CONV_TM_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_conv_tm(lib, case, reverse, dtype):
+    for silu, xz in ((True, False), (True, True), (False, False)):
+        KC.check_conv_tm(lib, "cuda", case, dtype, reverse, silu, xz)
+
+
+def test_scan_tm_headline_shape(lib):
+    """The bench's own launch -- B = 64, E = 1536, L = 513, N = 16, bf16, [x | z] rows -- checked, not only timed: (i) forward and
+    backward are bitwise repeatable (every hand-over through memory -- the Fo-Bi partials, the carries that change waves, the
+    register-free global->LDS loads -- is ordered by a barrier or a counted wait; one that names too few operations shows up as a
+    run-to-run difference); (ii) the direction pair equals the sum of two one-direction launches (which the small-shape parity
+    tests tie to the oracle) within the rounding of the bf16 partial hand-over."""
+    torch.manual_seed(0)
+    Bsz, L, E, N = 64, 513, 1536, 16
+    dev = "cuda"
+    xz = torch.randn(Bsz, L, 2 * E, device=dev).bfloat16()
+    u, z = torch.randn(Bsz, L, E, device=dev).bfloat16(), xz[:, :, E:]
+    dl = (0.5 * torch.randn(Bsz, L, E, device=dev)).bfloat16()
+    bc = torch.randn(Bsz, L, 48 + 2 * N, device=dev).bfloat16()
+    Bm, Cm = bc[:, :, 48:48 + N], bc[:, :, 48 + N:]
+    A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(E, 1) * (1 + 0.1 * torch.rand(E, N, device=dev))
+    A_b, D, bias = A * 1.05, torch.ones(E, device=dev), torch.full((E,), -4.0, device=dev)
+    dout = torch.randn(Bsz, L, E, device=dev).bfloat16()
+    ck = aum_hip.scan_tm_ckpt(Bsz, L, E, N, True, dev)
+    ref_f = ref_b = None
+    for it in range(3):
+        o, pre = aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, ckpt=ck, lib=lib)
+        g = aum_hip.scan_tm_bwd(u, dl, A, Bm, Cm, D, z, bias, dout, pre, ck, True, A_b=A_b, lib=lib)
+        cur_f = (o.clone(), pre.clone())
+        cur_b = {k: v.clone() for k, v in g.items() if v is not None and not k.startswith("_")}
+        if ref_f is None:
+            ref_f, ref_b = cur_f, cur_b
+        assert torch.equal(ref_f[0], cur_f[0]) and torch.equal(ref_f[1], cur_f[1]), it
+        for k in ref_b:
+            assert torch.equal(ref_b[k], cur_b[k]), (it, k)
+            assert torch.isfinite(cur_b[k].float()).all(), k
+    ckf, ckb = aum_hip.scan_tm_ckpt(Bsz, L, E, N, False, dev), aum_hip.scan_tm_ckpt(Bsz, L, E, N, False, dev)
+    _, pf = aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, D, z, bias, True, want_out_pre=True, ckpt=ckf, lib=lib)
+    _, pb = aum_hip.scan_tm_fwd(u, dl, A_b, Bm, Cm, D, z, bias, True, reverse=True, want_out_pre=True, ckpt=ckb, lib=lib)
+    rel = lambda a, b: ((a.float() - b.float()).abs().max() / b.float().abs().max()).item()
+    assert rel(ref_f[1], pf.float() + pb.float()) < 1e-2
+    gf = aum_hip.scan_tm_bwd(u, dl, A, Bm, Cm, D, z, bias, dout, ref_f[1], ckf, True, lib=lib)
+    gb = aum_hip.scan_tm_bwd(u, dl, A_b, Bm, Cm, D, z, bias, dout, ref_f[1], ckb, True, reverse=True, lib=lib)
+    for k in ("du", "ddelta", "dBC", "dD", "ddelta_bias"):
+        assert rel(ref_b[k], gf[k].float() + gb[k].float()) < 2e-2, k
+    assert rel(ref_b["dA"], gf["dA"]) < 2e-2 and rel(ref_b["dA_b"], gb["dA"]) < 2e-2 and rel(ref_b["dz"], gf["dz"]) < 2e-2
+
+
+def test_conv_tm_headline_shape(lib):
+    """the block's conv at B = 64, E = 1536, L = 513 on [x | z] rows: sampled channels against the oracle, dweight / dbias against an
+    fp64 torch statement of the same sums, bitwise repeatable (fixed-order partial sums, no atomics)"""
+    O = KC.O
+    torch.manual_seed(1)
+    Bsz, L, E = 64, 513, 1536
+    xz = torch.randn(Bsz, L, 2 * E, device="cuda").bfloat16()
+    x = xz[:, :, :E]
+    w, b = 0.5 * torch.randn(E, 4, device="cuda"), 0.2 * torch.randn(E, device="cuda")
+    dy = torch.randn(Bsz, L, E, device="cuda").bfloat16()
+    y = aum_hip.conv1d_tm_fwd(x, w, b, True, lib=lib)
+    dx, dw, db = aum_hip.conv1d_tm_bwd(x, w, b, dy, True, lib=lib)
+    dx2, dw2, db2 = aum_hip.conv1d_tm_bwd(x, w, b, dy, True, lib=lib)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    ch = [0, 7, 511, 512, 1000, 1535]
+    bs = [0, 31, 63]
+    xs = x[bs][:, :, ch].float().cpu().numpy().transpose(0, 2, 1)
+    dys = dy[bs][:, :, ch].float().cpu().numpy().transpose(0, 2, 1)
+    ws, bb = w[ch].cpu().numpy(), b[ch].cpu().numpy()
+    ry = O.conv1d_fwd(xs, ws, bb, True, False, "f64")
+    rg = O.conv1d_bwd(xs, ws, bb, dys, True, False, "f64")
+    assert KC.rel_err(y[bs][:, :, ch].float().cpu().numpy().transpose(0, 2, 1), ry) < KC.TOL_BF16
+    assert KC.rel_err(dx[bs][:, :, ch].float().cpu().numpy().transpose(0, 2, 1), rg["dx"]) < 4 * KC.TOL_BF16
+    # dw / db over ALL batch entries for the sampled channels: the oracle on the full batch of those channels
+    xa = x[:, :, ch].float().cpu().numpy().transpose(0, 2, 1)
+    dya = dy[:, :, ch].float().cpu().numpy().transpose(0, 2, 1)
+    ra = O.conv1d_bwd(xa, ws, bb, dya, True, False, "f64")
+    assert KC.rel_err(dw[ch].cpu().numpy(), ra["dweight"]) < 1e-3 and KC.rel_err(db[ch].cpu().numpy(), ra["dbias"]) < 1e-3
