@@ -572,14 +572,19 @@ def conv1d_tm_supported(x, width):
     return x.shape[2] % (16 // es) == 0 and x.data_ptr() % 16 == 0 and (ts * es) % 16 == 0 and (bs * es) % 16 == 0
 
 
+def _al16(t):
+    """the kernels read weights with 16-byte accesses: a parameter that is a misaligned view gets its own storage"""
+    return t if t is None or t.data_ptr() % 16 == 0 else t.clone()
+
+
 def conv1d_tm_fwd(x, weight, bias=None, silu=True, reverse=False, lib=None):
     """causal_conv1d_fn on a token-major (batch, len, dim) view (x may be the first half of the in_proj output rows) -> y (batch, len,
     dim) contiguous.  weight (dim, width) / (dim, 1, width)."""
     lib = lib or get()
     lib.check_tensor(x)
     batch, length, dim = x.shape
-    weight = _f32c(weight.reshape(dim, -1))
-    bias = _f32c(bias)
+    weight = _al16(_f32c(weight.reshape(dim, -1)))
+    bias = _al16(_f32c(bias))
     y = torch.empty((batch, length, dim), dtype=x.dtype, device=x.device)
     a = ConvTmArgs()
     a.x, a.weight, a.bias, a.y = _ptr(x), _ptr(weight), _ptr(bias), _ptr(y)
@@ -597,8 +602,8 @@ def conv1d_tm_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, li
     lib = lib or get()
     lib.check_tensor(x)
     batch, length, dim = x.shape
-    weight = _f32c(weight.reshape(dim, -1))
-    bias = _f32c(bias)
+    weight = _al16(_f32c(weight.reshape(dim, -1)))
+    bias = _al16(_f32c(bias))
     width = weight.shape[1]
     dy = dy if dy.stride(2) == 1 else dy.contiguous()
     dx = dx_out if dx_out is not None else torch.empty((batch, length, dim), dtype=x.dtype, device=x.device)

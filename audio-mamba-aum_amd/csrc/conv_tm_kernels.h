@@ -15,7 +15,10 @@
 namespace aum {
 
 constexpr int CONVT_W = 4;
-constexpr int CONVT_TC = 64;       // time steps per wave
+#ifndef AUM_CONVT_TC
+#define AUM_CONVT_TC 64
+#endif
+constexpr int CONVT_TC = AUM_CONVT_TC;       // time steps per wave
 constexpr int CONVT_UB = 8;        // steps fetched together (raw 16-byte fragments, widened when used)
 
 AUM_HOSTDEV inline int convt_chunks(int len) { return (len + CONVT_TC - 1) / CONVT_TC; }
@@ -37,14 +40,38 @@ template <class T> AUM_DEV void convt_lane_setup(const AumConvTmArgs& a, int cb,
     const vi c = (lane_id() + cb * WAVE) * V;
     ln.live = c < a.dim;
     ln.c0 = vsel_i(ln.live, c, c * 0);
-    AUM_UNROLL
-    for (int v = 0; v < V; ++v) {
+    if (a.width == CONVT_W) {
+        // the four taps of a channel are 16 contiguous bytes: one access per channel instead of four
+        const gbuf<float> wb = make_gbuf(a.weight);
         AUM_UNROLL
-        for (int k = 0; k < CONVT_W; ++k) {
-            const int kk = k - (CONVT_W - a.width);
-            ln.w[k][v] = kk >= 0 ? gload_u(a.weight, (ln.c0 + v) * a.width + kk) : splat(0.f);
+        for (int v = 0; v < V; ++v) {
+            vf t[4];
+            vq_unpack<float>(gbuf_load16(wb, (ln.c0 + v) * (CONVT_W * 4), 0), t);
+            AUM_UNROLL
+            for (int k = 0; k < CONVT_W; ++k) ln.w[k][v] = t[k];
         }
-        ln.bias[v] = a.bias ? gload_u(a.bias, ln.c0 + v) : splat(0.f);
+    } else {
+        AUM_UNROLL
+        for (int v = 0; v < V; ++v) {
+            AUM_UNROLL
+            for (int k = 0; k < CONVT_W; ++k) {
+                const int kk = k - (CONVT_W - a.width);
+                ln.w[k][v] = kk >= 0 ? gload_u(a.weight, (ln.c0 + v) * a.width + kk) : splat(0.f);
+            }
+        }
+    }
+    if (a.bias) {
+        const gbuf<float> bb = make_gbuf(a.bias);
+        AUM_UNROLL
+        for (int i = 0; i < V / 4; ++i) {
+            vf t[4];
+            vq_unpack<float>(gbuf_load16(bb, ln.c0 * 4 + 16 * i, 0), t);
+            AUM_UNROLL
+            for (int k = 0; k < 4; ++k) ln.bias[4 * i + k] = t[k];
+        }
+    } else {
+        AUM_UNROLL
+        for (int v = 0; v < V; ++v) ln.bias[v] = splat(0.f);
     }
 }
 

@@ -345,6 +345,16 @@ def token_major_ok(d_inner, d_state, d_conv, dt_rank, dtype=None):
             and ((dt_rank + 2 * d_state) * es) % 16 == 0)
 
 
+# The time-serial kernels give one wave to 64 channels of one batch entry and direction and walk the WHOLE sequence with it: they need
+# batch * (d_inner / 64) * directions waves to fill 256 CUs x 4 SIMDs x 2-3 waves.  Short of that (long-form clips at batch 8,
+# single-clip inference) the chunk-parallel channel-major kernels are the better division.  AUM_TM_MIN_WAVES overrides the threshold.
+_TM_MIN_WAVES = int(os.environ.get("AUM_TM_MIN_WAVES", "1536"))
+
+
+def token_major_preferred(batch, d_inner, bidirectional):
+    return batch * (d_inner // 64) * (2 if bidirectional else 1) >= _TM_MIN_WAVES
+
+
 def _is_tm(xz):
     """(B, 2E, L) logical tensor stored token-major: the transpose view of a (B, L, 2E) tensor with contiguous rows"""
     return xz.dim() == 3 and xz.stride(1) == 1 and xz.shape[1] > 1 and xz.is_cuda

@@ -349,7 +349,7 @@ int64_t aum_scan_tm_workspace_bytes(int32_t batch, int32_t dim, int32_t len, int
  *   x, y, dy, dx in `dtype`; weight (dim, width) fp32, width <= 4; bias (dim) fp32 or NULL; flags: AUM_CONV_SILU, AUM_CONV_REVERSE.
  *   backward: dx written; dw_part [nparts][width][dim] and db_part [nparts][dim] (NULL without bias) fp32 are per-wave partial sums
  *   (nparts = aum_conv1d_tm_nparts(batch, len)) that the caller adds up in a fixed order (aum_sum_rows): no atomics.
- * Limits: dim % (16 / sizeof(dtype)) == 0, 16-byte aligned pointers and row strides.
+ * Limits: dim % (16 / sizeof(dtype)) == 0, 16-byte aligned pointers (weight and bias included) and row strides.
  */
 typedef struct AumConvTmArgs {
     const void *x, *dy;      /* dy: backward only */
