@@ -92,7 +92,7 @@ class Mamba(nn.Module):
                 out, _, _ = self.step(hidden_states, conv_state, ssm_state)    # states updated in place
                 return out
         batch, seqlen, _ = hidden_states.shape
-        tm = (ssi.TOKEN_MAJOR and hidden_states.is_cuda and self.use_fast_path and inference_params is None
+        tm = (ssi.TOKEN_MAJOR and self.use_fast_path and inference_params is None
               and self.bimamba_type in ("v1", "none") and ssi.token_major_preferred(batch, self.d_inner, self.bimamba_type == "v1")
               and ssi.token_major_ok(self.d_inner, self.d_state, self.d_conv, self.dt_rank,
                                      torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else hidden_states.dtype))

@@ -357,7 +357,7 @@ def token_major_preferred(batch, d_inner, bidirectional):
 
 def _is_tm(xz):
     """(B, 2E, L) logical tensor stored token-major: the transpose view of a (B, L, 2E) tensor with contiguous rows"""
-    return xz.dim() == 3 and xz.stride(1) == 1 and xz.shape[1] > 1 and xz.is_cuda
+    return xz.dim() == 3 and xz.stride(1) == 1 and xz.shape[1] > 1
 
 
 def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, A_b, D,

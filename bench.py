@@ -4,6 +4,7 @@ synthetic 128-mel x 1024-frame spectrograms (BASELINE.json metric; configs[2] at
 DDP over RCCL at N>1), plus the live roofline of the dominant kernel and the CPU baseline (oracle on the host cores).
 
   python bench.py --gpus 1 --steps 10 --warmup 3
+  python bench.py --gpus N ...          (launches itself under torch.distributed.run, one rank per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one optimizer step on one per-GPU batch: fwd (bf16 autocast) -> BCE loss -> bwd (+ DDP bucketed all-reduce
@@ -132,6 +133,20 @@ def main():
     ap.add_argument("--grad-compress", default="no", choices=["no", "bf16", "fp16"], help="16-bit gradient exchange (N > 1)")
     ap.add_argument("--no-frontend", action="store_true", help="start from spectrograms instead of waveforms")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks (one process per GPU, RCCL over xGMI) the way the driver does
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("AUM_BENCH_PRINT_LAUNCH") == "1":      # tests: the command, not the run
+            print(json.dumps(cmd))
+            return
+        raise SystemExit(subprocess.call(cmd))
 
     import aum_hip
     from aum.model import build_aum

@@ -85,7 +85,10 @@ def _run_inner(case, dmajor_xz):
     t = {k: P(v) for k, v in p.items() if k != "dout"}
     xz_leaf = t["xz"]
     xz = xz_leaf
-    if dmajor_xz:       # the layout Mamba.forward produces (MS:185-189)
+    if dmajor_xz == "token":      # token-major rows [x | z]: the layout of the time-serial kernels
+        xz = xz_leaf.transpose(1, 2).contiguous().transpose(1, 2)
+        assert ssi._is_tm(xz)
+    elif dmajor_xz:     # the channel-major layout Mamba.forward produces for the row kernels (MS:185-189)
         xz = xz_leaf.permute(1, 0, 2).contiguous().permute(1, 0, 2)
     if mode == "v1":
         o = ssi.bimamba_inner_fn(xz, t["conv_w"], t["conv_b"], t["x_proj_w"], t["dt_proj_w"], t["out_proj_w"], None,
@@ -105,7 +108,7 @@ def _run_inner(case, dmajor_xz):
 
 
 @pytest.mark.parametrize("case", cases.INNER_CASES, ids=lambda c: c[0])
-@pytest.mark.parametrize("dmajor_xz", [False, True])
+@pytest.mark.parametrize("dmajor_xz", [False, True, "token"])
 def test_inner_fns_vs_reference(case, dmajor_xz):
     g = load_golden("inner")
     name = case[0]
@@ -318,3 +321,47 @@ def test_split_counts_and_token_split_rules():
     assert torch.equal(S._mm_tokens_cols(a, bt, 1), a @ bt.t())
     at, b = torch.randn(7, 9000), torch.randn(7, 3)
     assert torch.equal(S._mm_tokens_rows(at, b, 8), at.t() @ b)
+
+
+def test_token_major_module_matches_channel_major(monkeypatch):
+    """Mamba.forward in the two activation layouts (token-major rows through InProjTmFn, the register-window conv and the time-serial
+    scan; channel-major through the row kernels): same output, same parameter and input gradients; and the dispatch rules -- token-major
+    only where the kernels' limits hold and the batch fills the chip."""
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    from mamba_ssm.modules.mamba_simple import Mamba
+    assert ssi.token_major_ok(1536, 16, 4, 48, torch.bfloat16) and ssi.token_major_ok(768, 16, 4, 24, torch.bfloat16)
+    assert not ssi.token_major_ok(384, 16, 4, 12, torch.bfloat16)       # B / C rows of x_dbl not 16-byte aligned behind 12 bf16 dt columns
+    assert not ssi.token_major_ok(1536, 8, 4, 48, torch.bfloat16) and not ssi.token_major_ok(96, 16, 4, 4, torch.float32)
+    assert ssi.token_major_preferred(64, 1536, True) and not ssi.token_major_preferred(8, 1536, True)      # long-form batch 8: chunk kernels
+    torch.manual_seed(3)
+    for btype in ("v1", "none"):
+        m = Mamba(64, bimamba_type=btype)
+        x = torch.randn(2, 70, 64)
+        w = torch.randn(2, 70, 64)
+        res = []
+        for min_waves in (0, 10 ** 9):
+            monkeypatch.setattr(ssi, "_TM_MIN_WAVES", min_waves)
+            m.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            y = m(xi)
+            (y * w).sum().backward()
+            res.append((y.detach(), xi.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+        assert rel_err(res[0][0].numpy(), res[1][0].numpy()) < 1e-5 and rel_err(res[0][1].numpy(), res[1][1].numpy()) < 1e-4
+        for k in res[0][2]:
+            assert rel_err(res[0][2][k].numpy(), res[1][2][k].numpy()) < 2e-4, (btype, k)
+
+
+def test_bench_launches_itself_for_n_gpus():
+    """`python bench.py --gpus N` without a launcher starts N ranks under torch.distributed.run on 127.0.0.1 (the driver's own
+    command line); with WORLD_SIZE set it is a rank and does not launch again"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["AUM_BENCH_PRINT_LAUNCH"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
