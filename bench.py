@@ -25,6 +25,39 @@ tunable.enable(int(os.environ.get("LOCAL_RANK", "0")))     # GEMM solution selec
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+
+
+def pmc_record(kind, kernel):
+    """HBM traffic / vector-ALU occupancy of `kernel` from the counter passes committed under profiles/ (token-major kernels:
+    tools/pmc_tm_bench.sh, channel-major: tools/pmc_job.sh, tools/valu_job.sh), with the commit and date they were taken at"""
+    for f in (f"{kind}_tm.json", f"{kind}.json"):
+        path = os.path.join(ROOT, "profiles", f)
+        if os.path.exists(path):
+            d = json.load(open(path))
+            if kernel in d:
+                return d[kernel], {"file": "profiles/" + f, "commit": d.get("_commit", "round 2"), "date": d.get("_date", "round 2")}
+    return None, None
+
+
+def gemm_probe(dev, ntok, d_model, d_inner, iters=20):
+    """the largest library GEMM of the step, in_proj forward [ntok, d_model] x [d_model, 2 d_inner] in bf16, timed on the spot
+    (HIP events on the current stream) against the dense MFMA peak"""
+    a = torch.randn(ntok, d_model, device=dev).bfloat16()
+    w = torch.randn(2 * d_inner, d_model, device=dev).bfloat16()
+    for _ in range(3):
+        torch.matmul(a, w.t())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        torch.matmul(a, w.t())
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 2.0 * ntok * d_model * 2 * d_inner / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": f"in_proj forward GEMM [{ntok}x{d_model}] x [{d_model}x{2 * d_inner}] bf16 (hipBLASLt via TunableOp)",
+            "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+            "avg_launch_ms": round(ms, 4)}
 
 
 def scan_alg_bytes(meta, backward):
@@ -268,18 +301,29 @@ def main():
             roof["alg_bytes_per_launch"] = alg
             roof["achieved"] = round(alg / (rec["avg_ms"] * 1e-3) / 1e9, 1)
             roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBPS, 4)
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            roof["traffic"] = json.load(open(pmc)).get(dom)     # HBM bytes per launch from FETCH_SIZE/WRITE_SIZE passes
-        vb = os.path.join(ROOT, "profiles", "valu_busy.json")
-        if os.path.exists(vb) and dom in json.load(open(vb)):
-            roof["valu"] = json.load(open(vb))[dom]             # vector-ALU occupancy of the same kernel (SQ PMC pass)
+        roof["traffic"], roof["traffic_provenance"] = pmc_record("pmc_traffic", dom)      # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE passes
+        roof["valu"], roof["valu_provenance"] = pmc_record("valu_busy", dom)              # vector-ALU occupancy of the same kernel (SQ pass)
         if isinstance(roof.get("valu"), dict) and "valu_busy_frac" in roof["valu"]:
             roof["valu_frac"] = roof["valu"]["valu_busy_frac"]
         if dom.startswith("scan"):
-            roof["note"] = ("VALU-bound kernel (16 states x 2 directions x v_exp_f32 per element, ~6000 vector instructions per "
-                            "513-step row): SQ_ACTIVE_INST_VALU shows the vector ALU 75% (backward) / 81% (forward) busy "
-                            "(profiles/r02_valu_busy.txt), so the HBM fraction is bounded near 0.1 by arithmetic; see DESIGN.md 4.1")
+            roof["note"] = ("VALU-bound kernel (16 states x 2 directions, one v_exp_f32 per state and step at a quarter of the fp32 rate, "
+                            "packed fp32 FMAs for the rest): the vector ALU is busy for `valu_frac` of the launch (SQ_ACTIVE_INST_VALU), so the "
+                            "fraction of the HBM roofline is bounded near 0.1-0.3 by arithmetic; `traffic` above the algorithmic bytes is the "
+                            "fp32 state checkpoint (every 8 steps) and the per-wave dB/dC partial rows; see DESIGN.md 4")
+        # the forward kernel of the same scan and the largest library GEMM, against their own roofs
+        fwd_roof = None
+        fk = "scan_tm_fwd_bidir" if "scan_tm_fwd_bidir" in ktimes or (table is not None and "scan_tm_fwd_bidir" in table) else "scan_fwd_bidir"
+        frec = ktimes.get(fk) or (table or {}).get(fk)
+        if frec is not None and frec.get("meta") is not None:
+            falg = scan_alg_bytes(frec["meta"], False)
+            fwd_roof = {"bound": "hbm", "kernel": fk, "alg_bytes_per_launch": falg, "avg_launch_ms": round(frec["avg_ms"], 4),
+                        "achieved": round(falg / (frec["avg_ms"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+            fwd_roof["frac"] = round(fwd_roof["achieved"] / HBM_PEAK_GBPS, 4)
+            fwd_roof["traffic"], fwd_roof["traffic_provenance"] = pmc_record("pmc_traffic", fk)
+            fv, _ = pmc_record("valu_busy", fk)
+            if isinstance(fv, dict):
+                fwd_roof["valu_frac"] = fv.get("valu_busy_frac")
+        gemm_roof = gemm_probe(dev, args.batch * 513, model.embed_dim, 2 * model.embed_dim) if world == 1 else None
         out = {
             "metric": "clips/sec/node AuM-Base 128x1024 fwd+bwd", "value": round(clips / elapsed, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -292,6 +336,8 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}" + (" (DDP, RCCL all-reduce overlapped with backward)" if world > 1 else "")},
             "roofline": roof,
+            "roofline_forward_kernel": fwd_roof,
+            "roofline_gemm": gemm_roof,
             # whole step against the HBM roofline: SURVEY 8(d)'s algorithmic bytes of the 24 layers / measured step time
             "step_roofline": {"bound": "hbm", "alg_bytes_per_step": step_alg_bytes(args.batch, 513, model.embed_dim, args.depth),
                               "achieved": round(step_alg_bytes(args.batch, 513, model.embed_dim, args.depth) / (elapsed / args.steps) / 1e9, 1),
@@ -304,8 +350,10 @@ def main():
             "final_loss": round(final_loss, 5),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            out["cpu_baseline_torch_ref"] = cpu_baseline_torch_ref()
+            # north_star's CPU baseline is the reference's pure-PyTorch selective_scan_ref loop; the C oracle (the checker of the parity
+            # tests, all operators of a block, OpenMP on every core) is the faster CPU statement and is reported beside it
+            out["cpu_baseline"] = cpu_baseline_torch_ref()
+            out["cpu_baseline_oracle"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
