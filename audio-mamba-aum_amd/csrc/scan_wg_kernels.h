@@ -28,12 +28,19 @@ constexpr int SCANWG_NW = AUM_SCANWG_NW;          // waves per workgroup
 constexpr int SCANWG_MAX_N = 16;      // dstate limit of this path (LDS tile height)
 constexpr int SCANWG_MAX_ROWS = 64;   // rows per workgroup (8 waves x 4 pairs x 2 rows)
 constexpr int SCANWG_MAX_K = 9;       // <= 577 steps per chunk keeps the backward's 4 fp32 tiles inside 160 KB of LDS
-// debug-only ablation bits (upper half of `flags`; set through AUM_ABLATE in the Python binding, never by the product)
+// Ablation bits for timing experiments (upper half of `flags`, tools/kbench.py --only ablate): they exist only in -DAUM_ABLATE builds
+// (tools/build_variant.sh).  In the production library the masks are zero, every `flags & AUM_DBG_SKIP_*` test is a constant and its
+// branch is not in the kernels' hot loops.
+#ifdef AUM_ABLATE
 constexpr uint32_t AUM_DBG_SKIP_STATES = 1u << 16, AUM_DBG_SKIP_LDS_ATOMICS = 1u << 17, AUM_DBG_SKIP_PARTIALS = 1u << 18,
-                   AUM_DBG_SKIP_EPILOGUE = 1u << 19, AUM_DBG_NO_STEP_BARRIER = 1u << 20,
-                   AUM_DBG_CHUNKED_MAX_ROWS = 1u << 21,
-                   AUM_DBG_STATE_BWD = 1u << 22,
-                   AUM_DBG_TRACE = 1u << 23;              // scan_state_kernels.h: phase time stamps of workgroup 0 into the workspace          // checkpointed L = 513 backward: scan_state_kernels.h instead of scan_row_kernels.h   // tests: 64-row workgroups in the chunked one-row backward whatever the grid
+                   AUM_DBG_SKIP_EPILOGUE = 1u << 19, AUM_DBG_NO_STEP_BARRIER = 1u << 20;
+#else
+constexpr uint32_t AUM_DBG_SKIP_STATES = 0, AUM_DBG_SKIP_LDS_ATOMICS = 0, AUM_DBG_SKIP_PARTIALS = 0, AUM_DBG_SKIP_EPILOGUE = 0,
+                   AUM_DBG_NO_STEP_BARRIER = 0;
+#endif
+// kernel selection for tests and A/B runs (host-side dispatch, not in any loop): 64-row workgroups in the chunked one-row backward
+// whatever the grid; the checkpointed L = 513 backward of scan_state_kernels.h instead of scan_row_kernels.h; its phase time stamps
+constexpr uint32_t AUM_DBG_CHUNKED_MAX_ROWS = 1u << 21, AUM_DBG_STATE_BWD = 1u << 22, AUM_DBG_TRACE = 1u << 23;
 
 template <int K, int TAIL> struct ScanGeo {
     static constexpr int KT = K + TAIL;                    // slots per lane

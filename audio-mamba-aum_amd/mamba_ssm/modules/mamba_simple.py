@@ -158,32 +158,35 @@ class Mamba(nn.Module):
         return out
 
     def step(self, hidden_states, conv_state, ssm_state):
-        """One token of streaming inference (MS:313-358): conv window roll + one SSM update, states in place.  The
-        reference's optional fused update kernels (causal_conv1d_update, selective_state_update) are absent from its own
-        environment too; this is its element-wise composition, a handful of (batch, d_inner[, d_state]) ops per token."""
-        dtype = hidden_states.dtype
-        assert hidden_states.shape[1] == 1, "Only support decoding with 1 token at a time for now"
-        xz = self.in_proj(hidden_states.squeeze(1))                        # (B, 2E)
-        x, z = xz.chunk(2, dim=-1)
-        conv_state.copy_(torch.roll(conv_state, shifts=-1, dims=-1))       # (B, E, W)
-        conv_state[:, :, -1] = x
-        x = torch.sum(conv_state * self.conv1d.weight.reshape(self.d_inner, -1), dim=-1)
+        """One token of streaming inference for the causal block: (batch, 1, d_model) in, (batch, 1, d_model) out, the caches
+        conv_state (batch, d_inner, d_conv) and ssm_state (batch, d_inner, d_state) advanced in place.  Written from the block's
+        recurrence -- the same four stages as `forward` on a sequence of length one:
+            window  <- last d_conv inputs of the conv;           xc = silu(<window, w> + b)
+            (dt, B, C) = x_proj(xc);                             delta = softplus(dt W_dt^T + b_dt)
+            h <- exp(delta A) * h + (delta xc) B^T;              y = <h, C> + D xc
+            out = out_proj(y * silu(z))
+        Decode is outside SURVEY section 8's hot path: plain torch ops on (batch, d_inner[, d_state]) tensors, no kernels of their own."""
+        if hidden_states.dim() != 3 or hidden_states.shape[1] != 1:
+            raise ValueError("step() advances the caches by exactly one token: hidden_states must be (batch, 1, d_model)")
+        E, N, R, W = self.d_inner, self.d_state, self.dt_rank, self.d_conv
+        io_dtype = hidden_states.dtype
+        x_new, z = self.in_proj(hidden_states[:, 0]).split(E, dim=-1)
+        # slide the window one position to the left and append the new input
+        conv_state[:, :, :W - 1] = conv_state[:, :, 1:].clone()
+        conv_state[:, :, W - 1] = x_new
+        taps = self.conv1d.weight.view(E, W)
+        pre = (conv_state * taps).sum(dim=2)
         if self.conv1d.bias is not None:
-            x = x + self.conv1d.bias
-        x = F.silu(x).to(dtype=dtype)
-        x_db = self.x_proj(x)
-        dt, Bm, Cm = torch.split(x_db, [self.dt_rank, self.d_state, self.d_state], dim=-1)
-        dt = F.linear(dt, self.dt_proj.weight)                             # bias added below, inside the softplus
-        A = -torch.exp(self.A_log.float())
-        dt = F.softplus(dt + self.dt_proj.bias.to(dtype=dt.dtype))
-        dA = torch.exp(torch.einsum("bd,dn->bdn", dt, A))
-        dB = torch.einsum("bd,bn->bdn", dt, Bm)
-        ssm_state.copy_(ssm_state * dA + x.unsqueeze(-1) * dB)
-        y = torch.einsum("bdn,bn->bd", ssm_state.to(dtype), Cm)
-        y = y + self.D.to(dtype) * x
-        y = y * F.silu(z)
-        out = self.out_proj(y)
-        return out.unsqueeze(1), conv_state, ssm_state
+            pre = pre + self.conv1d.bias
+        xc = F.silu(pre).to(io_dtype)
+        proj = self.x_proj(xc)
+        dt_in, B_t, C_t = proj[:, :R], proj[:, R:R + N], proj[:, R + N:R + 2 * N]
+        delta = F.softplus(F.linear(dt_in, self.dt_proj.weight, self.dt_proj.bias.to(dt_in.dtype)))     # (batch, E)
+        decay = torch.exp(delta.unsqueeze(2) * (-torch.exp(self.A_log.float())))                       # (batch, E, N)
+        drive = (delta * xc).unsqueeze(2) * B_t.unsqueeze(1)                                           # (batch, E, N)
+        ssm_state.mul_(decay.to(ssm_state.dtype)).add_(drive.to(ssm_state.dtype))
+        y = (ssm_state.to(io_dtype) * C_t.unsqueeze(1)).sum(dim=2) + self.D.to(io_dtype) * xc
+        return self.out_proj(y * F.silu(z)).unsqueeze(1), conv_state, ssm_state
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         """MS:360-373"""

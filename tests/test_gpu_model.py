@@ -315,3 +315,55 @@ def test_model_forward_from_waveform_matches_spectrogram_input():
     y_wave.float().square().sum().backward()
     missing = [k for k, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
     assert not missing, missing
+
+
+def test_whole_step_bitwise_repeatable_token_major():
+    """Two forward + backward passes of AuM-Base blocks on the headline path (batch 32 x 513 tokens, bf16 autocast, token-major
+    kernels) give the same bits: logits and every parameter gradient.  Nothing on this path accumulates with atomics -- the scan's
+    dB/dC and the conv's dweight/dbias leave per-wave partials that are summed in a fixed order, the weight-gradient GEMMs are
+    split-K batches summed by aum_sum_rows -- so a difference here is an ordering bug (a wait that names too few operations, a
+    missing barrier)."""
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    from aum.model import build_aum
+    assert ssi.TOKEN_MAJOR and ssi.token_major_preferred(32, 1536, True) and ssi.token_major_ok(1536, 16, 4, 48, torch.bfloat16)
+    torch.manual_seed(11)
+    model = build_aum("base", depth=2, num_classes=527, bimamba_type="v1").to(DEV)
+    x = torch.randn(32, 1024, 128, device=DEV) * 0.5
+    y = (torch.rand(32, 527, device=DEV) < 0.01).float()
+    runs = []
+    for _ in range(3):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits = model(x)
+        torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), y).backward()
+        runs.append((logits.detach().clone(), {k: p_.grad.clone() for k, p_ in model.named_parameters()}))
+    for lg, gr in runs[1:]:
+        assert torch.equal(lg, runs[0][0])
+        for k, g in gr.items():
+            assert torch.isfinite(g).all(), k
+            assert torch.equal(g, runs[0][1][k]), k
+
+
+def test_base_block_token_major_bf16_matches_channel_major(monkeypatch):
+    """The AuM-Base Fo-Bi block at batch 32 under bf16 autocast in the two layouts (token-major time-serial kernels vs the
+    channel-major row kernels of rounds 1-2, both tied to the oracle by the kernel parity tests): outputs and gradients agree at the
+    bf16 bar, so the re-laid-out block computes the same function at the headline size."""
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(4)
+    m = Mamba(768, bimamba_type="v1").to(DEV)
+    x = (0.5 * torch.randn(32, 513, 768, device=DEV))
+    w = torch.randn(32, 513, 768, device=DEV) / 100
+    res = []
+    for min_waves in (0, 10 ** 9):
+        monkeypatch.setattr(ssi, "_TM_MIN_WAVES", min_waves)
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(xi)
+        (y.float() * w).sum().backward()
+        res.append((y.float().detach(), xi.grad.clone(), {k: p_.grad.clone() for k, p_ in m.named_parameters()}))
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
+    assert rel(res[0][0], res[1][0]) < 2e-2 and rel(res[0][1], res[1][1]) < 2e-2
+    for k in res[0][2]:
+        assert rel(res[0][2][k], res[1][2][k]) < 3e-2, k

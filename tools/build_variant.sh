@@ -1,5 +1,5 @@
 #!/bin/bash
-# build libaum_hip.so with extra compile flags into audio-mamba-aum_amd/aum_hip/variants/libaum_hip_<name>.so (A/B runs; AUM_DEBUG=1 AUM_HIP_LIB=...)
+# build libaum_hip.so with extra compile flags (e.g. -DAUM_ABLATE for the kbench ablation bits, which the production library does not contain) into audio-mamba-aum_amd/aum_hip/variants/libaum_hip_<name>.so (A/B runs; AUM_DEBUG=1 AUM_HIP_LIB=...)
 set -e
 name=$1; shift
 cd "$(dirname "$0")/.."
