@@ -25,7 +25,7 @@ _ERR = {-1: "AUM_E_NULL", -2: "AUM_E_SHAPE", -3: "AUM_E_DTYPE", -4: "AUM_E_UNSUP
         -6: "AUM_E_LAUNCH"}
 
 _i64, _i32, _u32, _vp, _fp = C.c_int64, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class _Debug:
@@ -132,7 +132,11 @@ class ProjWArgs(C.Structure):
                 + [(n, _i32) for n in ("dim", "nrows", "nsplit", "transpose_out", "dtype")])
 
 
-EXPORTS = ["aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
+class GemmArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("a", "b", "c")] + [(n, _i32) for n in ("m", "n", "k", "lda", "ldb", "ldc", "dtype")] + [("flags", _u32)])
+
+
+EXPORTS = ["aum_gemm_tn", "aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows",
            "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_selftest_wave_sum32",
@@ -162,6 +166,7 @@ class Lib:
         self.c.aum_conv1d_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_conv1d_tm_bwd.argtypes = [_vp, _vp]
         self.c.aum_conv1d_tm_nparts.argtypes = [_i32, _i32]
+        self.c.aum_gemm_tn.argtypes = [_vp, _vp]
         self.c.aum_scan_tm_workspace_bytes.restype = _i64
         self.c.aum_scan_tm_workspace_bytes.argtypes = [_i32] * 5
         self.c.aum_fbank_fwd.argtypes = [_vp, _vp]
@@ -561,6 +566,47 @@ def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_
     a.flags = (SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0)
     _launch(lib.c.aum_scan_tm_bwd, a, u, lib, "scan_tm_bwd_bidir" if bidir else "scan_tm_bwd", (batch, dim, length, dstate, u.element_size(), True))
     return dict(du=du, ddelta=ddelta, dz=dz, dBC=dBC, dA=dA, dA_b=dA_b, dD=dD, ddelta_bias=dbias, _ws=ws)
+
+
+GEMM_BN, GEMM_BK = 256, 64
+
+
+def gemm_tn_supported(a, b):
+    """shapes aum_gemm_tn takes (include/aum_hip.h, ABI 9): 16-bit 2-D operands with contiguous K, n % 256 == 0, k % 64 == 0"""
+    if a.dim() != 2 or b.dim() != 2 or a.dtype != b.dtype or a.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    m, k = a.shape
+    n = b.shape[0]
+    return (b.shape[1] == k and m > 0 and n % GEMM_BN == 0 and k % GEMM_BK == 0 and a.stride(1) == 1 and b.stride(1) == 1
+            and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+            and 512 * a.stride(0) < 2 ** 31 and 512 * b.stride(0) < 2 ** 31)
+
+
+GEMM_LOCKSTEP = 1
+
+
+def gemm_tn(a, b, out=None, lib=None, flags=0):
+    """out[m][n] = sum_k a[m][k] b[n][k]: the in_proj / out_proj GEMM and their data gradients on token-major activations (MS:185-189,
+    SSI:517, 540).  a (m, k), b (n, k): 16-bit, K contiguous; out (m, n) rows contiguous (may be a column block of a wider tensor)."""
+    lib = lib or get()
+    lib.check_tensor(a)
+    lib.check_tensor(b)
+    if not gemm_tn_supported(a, b):
+        raise RuntimeError(f"gemm_tn: unsupported operands {tuple(a.shape)} {a.dtype} x {tuple(b.shape)} {b.dtype} (need 16-bit, contiguous K, "
+                           "n % 256 == 0, k % 64 == 0, 16-byte aligned rows)")
+    m, k = a.shape
+    n = b.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    elif (out.shape != (m, n) or out.dtype != a.dtype or out.stride(1) != 1 or out.stride(0) % 8 or out.data_ptr() % 16
+          or out.device != a.device):
+        raise RuntimeError("gemm_tn: out must be an (m, n) tensor of the operands' dtype with contiguous, 16-byte aligned rows")
+    g = GemmArgs()
+    g.a, g.b, g.c = _ptr(a), _ptr(b), _ptr(out)
+    g.m, g.n, g.k, g.lda, g.ldb, g.ldc, g.dtype = m, n, k, a.stride(0), b.stride(0), out.stride(0), _DT[a.dtype]
+    g.flags = flags
+    _launch(lib.c.aum_gemm_tn, g, a, lib, "gemm_tn", (m, n, k))
+    return out
 
 
 def conv1d_tm_supported(x, width):

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT_DIR = os.path.join(os.path.dirname(HERE), "aum_hip")
 OBJ_DIR = os.path.join(HERE, "_obj")
 SRC = os.path.join(HERE, "aum_hip.hip")
-DEPS = ["aum_hip.hip", "aum_api.inc", "wave.h", "scan_kernels.h", "scan_wg_kernels.h", "scan_half_kernels.h", "scan_row_kernels.h", "scan_state_kernels.h", "fbank_kernels.h", "frontend_kernels.h", "proj_kernels.h", "conv_rows_kernels.h", "conv_norm_kernels.h", "scan_tm_kernels.h", "conv_tm_kernels.h", "aum_api_tm.inc",
+DEPS = ["aum_hip.hip", "aum_api.inc", "wave.h", "scan_kernels.h", "scan_wg_kernels.h", "scan_half_kernels.h", "scan_row_kernels.h", "scan_state_kernels.h", "fbank_kernels.h", "frontend_kernels.h", "proj_kernels.h", "conv_rows_kernels.h", "conv_norm_kernels.h", "scan_tm_kernels.h", "conv_tm_kernels.h", "aum_api_tm.inc", "gemm.hip", "gemm_kernels.h", "gemm_args.h",
         os.path.join("..", "..", "include", "aum_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
@@ -38,6 +38,7 @@ def parts():
     for dt in (1, 2):
         out.append((f"proj_d{dt}.o", ["-DAUM_API_PART=4", f"-DAUM_DTYPE_ONLY={dt}"]))
     out.append(("api.o", ["-DAUM_API_PART=3"]))
+    out.append(("gemm.o", ["@gemm.hip"]))          # its own translation unit (plain HIP: MFMA + LDS-DMA, no wave.h)
     return out
 
 
@@ -52,7 +53,10 @@ def build(force=False, verbose=False):
 
     def cc(item):
         name, defs = item
-        cmd = [HIPCC] + FLAGS + defs + ["-c", SRC, "-o", os.path.join(OBJ_DIR, name)]
+        src = SRC
+        if defs and defs[0].startswith("@"):
+            src, defs = os.path.join(HERE, defs[0][1:]), defs[1:]
+        cmd = [HIPCC] + FLAGS + defs + ["-c", src, "-o", os.path.join(OBJ_DIR, name)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

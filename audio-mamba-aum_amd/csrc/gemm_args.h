@@ -1,0 +1,20 @@
+// gemm_args.h -- argument rules of aum_gemm_tn (include/aum_hip.h, ABI 9), shared by the device library (gemm.hip) and the tests-only
+// host build (tests/emu/aum_emu.cpp): no HIP dependency.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/aum_hip.h"
+
+namespace aumg {
+constexpr int BM = 256, BN = 256, BK = 64;          // C tile of a workgroup, K-step
+inline int gemm_check(const AumGemmArgs* p) {
+    if (!p || !p->a || !p->b || !p->c) return AUM_E_NULL;
+    const AumGemmArgs& g = *p;
+    if (g.m <= 0 || g.n <= 0 || g.k <= 0 || g.lda < g.k || g.ldb < g.k || g.ldc < g.n) return AUM_E_SHAPE;
+    if (g.dtype != AUM_BF16 && g.dtype != AUM_F16) return AUM_E_DTYPE;
+    if (g.n % BN || g.k % BK || g.lda % 8 || g.ldb % 8 || g.ldc % 8) return AUM_E_UNSUPPORTED;
+    if (((uintptr_t)g.a | (uintptr_t)g.b | (uintptr_t)g.c) & 15u) return AUM_E_UNSUPPORTED;
+    if ((int64_t)BM * g.lda * 2 >= (1ll << 31) || (int64_t)BN * g.ldb * 2 >= (1ll << 31)) return AUM_E_UNSUPPORTED;   // 32-bit buffer offsets
+    return AUM_OK;
+}
+}  // namespace aumg

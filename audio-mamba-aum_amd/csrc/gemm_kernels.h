@@ -1,0 +1,212 @@
+// gemm_kernels.h -- the dense in_proj / out_proj GEMMs of the Mamba block as a hand-written MFMA kernel for gfx950 (round 3; ABI 9).
+//
+//   C[M][N] (16-bit) = A[M][K] . B[N][K]^T        A, B row-major with K contiguous ("TN"), fp32 accumulation, one rounding at the store
+//
+// Every operand of the forward GEMMs is K-contiguous in the token-major layout (hidden [tokens][D] . W_in[2E][D]^T, out_z [tokens][E] .
+// W_out[D][E]^T -- MS:185-189, SSI:517); the data-gradient GEMMs (SSI:540; d hidden = dxz . W_in) take the same form with the weight's
+// transpose, which the host caches once per step next to its 16-bit cast.  M = batch * len tokens (32 832 for the bench), N and K are
+// the model's widths (768 / 1536 / 3072): N % 256 == 0 and K % 64 == 0 are required, M is arbitrary.
+//
+// Division of the work
+//   * one workgroup = 8 waves = one 256 x 256 tile of C, K walked in steps of 64; wave (wr, wc) of the 2 x 4 grid owns 128 rows x 64
+//     columns = 8 x 4 accumulator fragments of v_mfma_f32_16x16x32_bf16 (128 accumulator registers).
+//   * operands go HBM -> LDS by buffer_load_dwordx4 ... lds (no registers, no ds_write pass): a wave instruction moves 8 rows x 128
+//     bytes; a K-step of A plus B is 64 such pieces, 8 per wave.  Two LDS buffers of 64 KB: the pieces of step t + 1 are in flight
+//     while step t computes; one workgroup barrier per step.  Rows of A beyond M are outside the buffer descriptor's range (the
+//     fetch never leaves the tensor; the rows they would produce are not stored).
+//   * the LDS image is lane-linear (the DMA writes lane l's 16 bytes at base + 16 l), so the bank swizzle lives in the SOURCE address:
+//     the lane that fills 16-byte slot s of row r fetches k-slot s ^ f(r), and the fragment reads apply the same XOR.
+//     ds_read_b128 serves 16 lanes per LDS cycle over a 256-byte bank row (two 128-byte tile rows): A fragments read rows r0 .. r0+15,
+//     f_A(r) = (r >> 1) & 7; B fragments read rows {16 q + 4 j + e} (below), f_B(r) = ((r >> 4) & 3) << 1 | ((r >> 1) & 1): both give
+//     16 distinct slots per lane group (checked exhaustively on the host: tests/test_gemm_layout.py).
+//   * MFMA roles are swapped -- the weight fragment is the MFMA's A operand, the activation fragment its B operand -- so a lane's four
+//     accumulator values of a fragment are four consecutive COLUMNS of C, and fragment j of a wave reads weight rows
+//     {16 q + 4 j + e : q, e = 0..3} so that the 4 fragments x 4 values of a lane are 16 consecutive columns: two 16-byte stores per
+//     lane and fragment row, the four lane groups of a wave completing a 128-byte line of C.
+//   * launch: blockIdx -> tile with the 8 XCDs each taking a contiguous range of tiles (tiles of one row block of A next to each other:
+//     A is fetched from HBM once per XCD-resident row block, B (the weight, <= 4.7 MB) stays in L2 / MALL).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_args.h"
+
+namespace aumg {
+
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+
+constexpr int NWAVES = 8, THREADS = NWAVES * 64;
+constexpr int TILE_BYTES = BM * BK * 2;                 // one operand, one K-step: 32 KB
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;             // A | B
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;              // two K-steps: 128 KB of the CU's 160 KB
+
+template <bool BF16> __device__ __forceinline__ f4v mfma(s8v a, s8v b, f4v c) {
+    if constexpr (BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+}
+template <bool BF16> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    if constexpr (BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{a, b}, bf2v));
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{a, b}, h2v));
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// the 8 pieces (4 of A, 4 of B) this wave contributes to one K-step: piece c = j * 8 + w is rows 8 c .. 8 c + 7 of the tile
+__device__ __forceinline__ void stage(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int voff_a, int voff_b, int kbyte, int rowstep_a,
+                                      int rowstep_b, char* lds_stage, int w) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds_stage + (j * 8 + w) * 1024), 16, voff_a, kbyte + j * rowstep_a, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds_stage + TILE_BYTES + (j * 8 + w) * 1024), 16, voff_b,
+                                                 kbyte + j * rowstep_b, 0, 0);
+    }
+}
+
+__device__ __forceinline__ s8v lds_frag(const char* lds, int byte_off) { return *reinterpret_cast<const s8v*>(lds + byte_off); }
+
+// blockIdx -> tile id with each XCD (blockIdx % 8) working through a contiguous range of ids (bijective for any grid size)
+__device__ __forceinline__ int xcd_tile(int orig, int nwg) {
+    const int xcd = orig & 7, idx = orig >> 3, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// SCHED 0: every wave stages, reads and multiplies K-step by K-step in lockstep, one barrier per step (the first version; kept for A/B:
+//          AUM_GEMM_LOCKSTEP).
+// SCHED 1: the two waves of a SIMD (wave w and w + 4 = the row halves wr = 0 / 1 of the tile) run half a K-step apart.  A phase = half a
+//          K-step (32 of the 64 k) = a LOAD segment (12 fragment reads, and on one phase per step the wave's 8 DMA pieces of the next
+//          step) and an MFMA segment (32 MFMAs at raised priority), a workgroup barrier after each; wr = 1 starts one barrier late, so
+//          between two barriers one wave of every SIMD feeds the matrix pipe while the other fetches.  With barriers B_0 .. B_2P
+//          (P = 2 nk phases) and segment s = the code between B_{s-1} and B_s:
+//              wr = 0:  load(p) in segment 2p,     MFMA(p) in segment 2p + 1        wr = 1:  load(p) in 2p + 1,  MFMA(p) in 2p + 2
+//          K-step t + 1 goes into the buffer step t - 1 was read from.  Its last reads (phase 2t - 1) have retired before B_{4t-1}
+//          (wr = 0: lgkmcnt(0) at the head of MFMA(2t-1), segment 4t - 1) and before B_{4t} (wr = 1, segment 4t), so pieces may be issued
+//          from segment 4t + 1 on; its first reads (phase 2t + 2) are in segment 4t + 4 (wr = 0), so the pieces must have landed before
+//          B_{4t+3}.  wr = 1 issues in segment 4t + 1 (its load(2t)) and waits at the end of segment 4t + 3 (its load(2t+1)); wr = 0 issues
+//          in segment 4t + 2 (its load(2t+1)) and waits at the end of segment 4t + 3 (its MFMA(2t+1)).
+template <bool BF16, int SCHED>
+__global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = w >> 2, wc = w & 3;
+    const int ntn = g.n / BN;
+    const int tile = xcd_tile((int)blockIdx.x, (int)gridDim.x);
+    const int tm = tile / ntn, tn = tile - tm * ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int rows_a = g.m - m0 < BM ? g.m - m0 : BM;
+
+    const char* a_base = static_cast<const char*>(g.a) + (int64_t)m0 * g.lda * 2;
+    const char* b_base = static_cast<const char*>(g.b) + (int64_t)n0 * g.ldb * 2;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a_base), 0, rows_a * g.lda * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b_base), 0, BN * g.ldb * 2, 0x00020000);
+
+    // staging: this lane fills slot (lane & 7) of row 8 c + (lane >> 3); f_A / f_B of that row do not depend on j
+    const int srow = w * 8 + (lane >> 3);
+    const int f_a = ((w & 1) * 4 + (lane >> 4)) & 7;
+    const int f_b = (((w >> 1) & 3) << 1) | ((lane >> 4) & 1);
+    const int voff_a = srow * g.lda * 2 + (((lane & 7) ^ f_a) << 4);
+    const int voff_b = srow * g.ldb * 2 + (((lane & 7) ^ f_b) << 4);
+    const int rowstep_a = 64 * g.lda * 2, rowstep_b = 64 * g.ldb * 2;
+
+    // fragment reads: lane = (operand row rho = lane & 15, k-group kg = lane >> 4)
+    const int rho = lane & 15, kg = lane >> 4;
+    const int a_rd = (wr * 128 + rho) * 128 + ((kg ^ ((lane >> 1) & 7)) << 4);                                  // + i * 2048, ^ 64 for the second half of K
+    const int b_row = wc * 64 + (rho >> 2) * 16 + (rho & 3);                                                    // + j * 4
+    const int b_rd = TILE_BYTES + b_row * 128 + ((kg ^ ((((rho >> 2) & 3) << 1) | ((rho >> 1) & 1))) << 4);     // + j * 512, ^ 64
+
+    f4v acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.k / BK;
+    stage(ra, rb, voff_a, voff_b, 0, rowstep_a, rowstep_b, lds, w);
+    if constexpr (SCHED == 0) {
+        for (int t = 0; t < nk; ++t) {
+            // step t has landed (this wave's pieces: vmcnt; everybody's: the barrier), and everybody is done reading step t - 1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < nk) stage(ra, rb, voff_a, voff_b, (t + 1) * (BK * 2), rowstep_a, rowstep_b, lds + ((t + 1) & 1) * STAGE_BYTES, w);
+            const char* st = lds + (t & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                s8v bf[4], af[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = lds_frag(st, (b_rd ^ (kk * 64)) + j * 512);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af[i] = lds_frag(st, (a_rd ^ (kk * 64)) + i * 2048);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(bf[j], af[i], acc[i][j]);
+            }
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // step 0 is in LDS
+        if (wr == 1) __builtin_amdgcn_s_barrier();                 // B_0: the second wave of every SIMD runs one segment behind
+        for (int t = 0; t < nk; ++t) {
+            const char* st = lds + (t & 1) * STAGE_BYTES;
+            const bool more = t + 1 < nk;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                // ---- load segment
+                s8v bf[4], af[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = lds_frag(st, (b_rd ^ (kk * 64)) + j * 512);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af[i] = lds_frag(st, (a_rd ^ (kk * 64)) + i * 2048);
+                if (more && kk == 1 - wr) stage(ra, rb, voff_a, voff_b, (t + 1) * (BK * 2), rowstep_a, rowstep_b, lds + ((t + 1) & 1) * STAGE_BYTES, w);
+                if (more && kk == 1 && wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- MFMA segment
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(bf[j], af[i], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                if (more && kk == 1 && wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();                 // B_2P
+    }
+
+    // store: lane holds, for fragment row i, columns wc * 64 + kg * 16 + 4 j + r (j, r = 0..3) of row wr * 128 + 16 i + rho
+    char* c_base = static_cast<char*>(g.c) + ((int64_t)m0 * g.ldc + n0 + wc * 64 + kg * 16) * 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wr * 128 + i * 16 + rho;
+        if (row < rows_a) {
+            u4v lo, hi;
+            lo.x = pack2<BF16>(acc[i][0][0], acc[i][0][1]);
+            lo.y = pack2<BF16>(acc[i][0][2], acc[i][0][3]);
+            lo.z = pack2<BF16>(acc[i][1][0], acc[i][1][1]);
+            lo.w = pack2<BF16>(acc[i][1][2], acc[i][1][3]);
+            hi.x = pack2<BF16>(acc[i][2][0], acc[i][2][1]);
+            hi.y = pack2<BF16>(acc[i][2][2], acc[i][2][3]);
+            hi.z = pack2<BF16>(acc[i][3][0], acc[i][3][1]);
+            hi.w = pack2<BF16>(acc[i][3][2], acc[i][3][3]);
+            u4v* dst = reinterpret_cast<u4v*>(c_base + (int64_t)row * g.ldc * 2);
+            dst[0] = lo;
+            dst[1] = hi;
+        }
+    }
+}
+
+}  // namespace aumg

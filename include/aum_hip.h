@@ -27,13 +27,14 @@
 extern "C" {
 #endif
 
-#define AUM_ABI_VERSION 8   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
+#define AUM_ABI_VERSION 9   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
                                3: x_lane (lane-entry state checkpoint of the L = 513 row kernels) appended after it;
                                4: aug / noise (per-clip augmentation in the log-mel kernel's epilogue) appended to AumFbankArgs;
                                5: aum_frontend_tokens_fwd (waveform -> token sequence in one launch);
                                6: aum_sum_rows (fixed-order sum of partial results);
                                7: aum_scan_tm_fwd / _bwd (time-serial selective scan on token-major activations);
-                               8: aum_conv1d_tm_fwd / _bwd (the causal conv on token-major activations) */
+                               8: aum_conv1d_tm_fwd / _bwd (the causal conv on token-major activations);
+                               9: aum_gemm_tn (the dense in_proj / out_proj GEMMs on token-major activations) */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 
@@ -61,6 +62,7 @@ enum {
 #define AUM_CONV_SILU 1u
 #define AUM_CONV_REVERSE 2u  /* anti-causal: y[l] = act(b + sum_w W[w] x[l+(W-1)-w])                            */
 #define AUM_CONV_GENERIC 4u  /* force the any-width kernel (default: the vectorised width-4 kernel when width == 4)  */
+#define AUM_GEMM_LOCKSTEP 1u /* debug / A-B: the one-barrier-per-K-step schedule (all waves in lockstep) instead of the staggered one */
 #define AUM_NORM_PRENORM 1u  /* also return residual_out                                                        */
 #define AUM_NORM_GENERIC 2u  /* force the any-cols kernel (default: register-cached vector kernel, cols <= 2048)  */
 
@@ -365,6 +367,26 @@ typedef struct AumConvTmArgs {
 int aum_conv1d_tm_fwd(const AumConvTmArgs* args, void* stream);
 int aum_conv1d_tm_bwd(const AumConvTmArgs* args, void* stream);
 int32_t aum_conv1d_tm_nparts(int32_t batch, int32_t len);
+
+/*
+ * Dense projection GEMM on token-major activations (ABI 9): the in_proj / out_proj matrix products of the Mamba block and their
+ * data gradients, which the reference leaves to cuBLAS through F.linear (vim-mamba_ssm/mamba_ssm/modules/mamba_simple.py:185-189;
+ * selective_scan_interface.py:517 out_proj forward, :540 its data gradient; the in_proj data gradient is autograd's).
+ *   c[m][n] = sum over k of a[m][k] * b[n][k]      ("TN": both operands K-contiguous; fp32 accumulation, one rounding at the store)
+ *   a: (m, k) row pitch lda;  b: (n, k) row pitch ldb;  c: (m, n) row pitch ldc -- pitches in ELEMENTS, all three tensors `dtype`
+ *   (AUM_BF16 or AUM_F16; AUM_F32: AUM_E_DTYPE).  m is arbitrary (the token count); n % 256 == 0 and k % 64 == 0 (the model widths
+ *   768 / 1536 / 3072; else AUM_E_UNSUPPORTED); pointers 16-byte aligned, pitches % 8 == 0, every tensor below 2 GiB per 256-row block
+ *   (32-bit buffer offsets).  forward: a = activations, b = the weight as nn.Linear stores it; data gradient: a = d out, b = the weight's transpose.
+ */
+typedef struct AumGemmArgs {
+    const void *a, *b;
+    void *c;
+    int32_t m, n, k;
+    int32_t lda, ldb, ldc;
+    int32_t dtype;
+    uint32_t flags;
+} AumGemmArgs;
+int aum_gemm_tn(const AumGemmArgs* args, void* stream);
 
 /* Self-tests and calibration (used by tests/ and bench.py; not part of the reference's surface). */
 int aum_abi_version(void);

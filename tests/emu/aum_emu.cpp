@@ -4,3 +4,27 @@
 // Exports the same C ABI as libaum_hip.so but takes HOST pointers.  Never loaded by the product path.
 #define AUM_EMU 1
 #include "../../audio-mamba-aum_amd/csrc/aum_api.inc"
+
+// aum_gemm_tn on host pointers: the device kernel (csrc/gemm_kernels.h) is plain HIP around MFMA and LDS-DMA instructions and has no
+// lane-array build; the host tests of the projection dispatch get the same contract -- argument rules (gemm_args.h), fp32
+// accumulation, one rounding at the store -- from this loop.  The kernel's tile layout is checked on its own in tests/test_gemm_layout.py.
+#include "../../audio-mamba-aum_amd/csrc/gemm_args.h"
+extern "C" int aum_gemm_tn(const AumGemmArgs* p, void*) {
+    const int rc = aumg::gemm_check(p);
+    if (rc != AUM_OK) return rc;
+    auto run = [&](auto tag) {
+        using T = decltype(tag);
+        const T* a = static_cast<const T*>(p->a);
+        const T* b = static_cast<const T*>(p->b);
+        T* c = static_cast<T*>(p->c);
+        for (int i = 0; i < p->m; ++i)
+            for (int j = 0; j < p->n; ++j) {
+                float acc = 0.f;
+                for (int k = 0; k < p->k; ++k) acc += aum::elem_to_f32(a[(int64_t)i * p->lda + k]) * aum::elem_to_f32(b[(int64_t)j * p->ldb + k]);
+                aum::f32_to_elem(acc, c[(int64_t)i * p->ldc + j]);
+            }
+    };
+    if (p->dtype == AUM_BF16) run(aum::bf16_t{});
+    else run(aum::f16_t{});
+    return AUM_OK;
+}

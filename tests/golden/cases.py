@@ -226,6 +226,16 @@ MODEL_CASES = [
 ]
 
 
+# BASELINE configs 3 and 2 at their full size (MM:678-685 + RUN:227-237): AuM-Base (d_model 768, 24 Fo-Bi blocks, 128 x 1024 frames ->
+# L = 513 tokens, 527 classes) forward + backward on one clip, AuM-Small (d_model 384) forward only on two clips.  The state comes
+# from model_state (seeded), so the fixture (headline.npz) holds logits, gradient norms and the small gradients only.
+# (name, bimamba_type, depth, embed_dim, spectrogram (F, T), num_classes, batch, backward)
+HEADLINE_CASES = [
+    ("base_v1_d24_l513", "v1", 24, 768, (128, 1024), 527, 1, True),
+    ("small_v1_d24_l513", "v1", 24, 384, (128, 1024), 527, 2, False),
+]
+
+
 def model_kwargs(case):
     return case[7] if len(case) > 7 else {}
 
@@ -301,3 +311,19 @@ def ckpt_inputs():
     r = _rng("ckpt_in")
     c = CKPT_CASE
     return dict(x=(0.5 * r.normal(0, 1, (c["batch"], c["dst_spec"][1], c["dst_spec"][0]))).astype(np.float32))
+
+
+# aum_gemm_tn (ABI 9): (name, m, n, k, row-pitch padding of a / c in elements).  One ragged row block (m < 256, m = 256 q + r), a single row,
+# more than one tile in both directions, every K the model has (768 / 1536 / 3072 divide by 64; 64 is one K-step: no pipelining at all),
+# operands / results that are column blocks of wider tensors.
+GEMM_CASES = [
+    ("m1_k64", 1, 256, 64, 0, 0),
+    ("m255_k128", 255, 256, 128, 0, 0),
+    ("m257_n512_k192", 257, 512, 192, 0, 0),
+    ("m513_n768_k768", 513, 768, 768, 0, 0),
+    ("m700_n256_k1536_pitch", 700, 256, 1536, 64, 256),
+    ("m300_n1536_k3072", 300, 1536, 3072, 0, 0),
+]
+# on the GPU only (the host build's triple loop would take minutes): the bench's own GEMMs, (m, n, k) of in_proj / out_proj forward and
+# data gradient at 64 x 513 tokens and at 3 x 513 tokens
+GEMM_FULL_CASES = [(64 * 513, 3072, 768), (64 * 513, 768, 1536), (64 * 513, 1536, 768), (64 * 513, 768, 3072), (3 * 513, 3072, 768)]

@@ -377,8 +377,48 @@ def wav_excerpts():
     np.savez_compressed(os.path.join(HERE, "wav_excerpts.npz"), **out)
     print("wav_excerpts.npz", {k: (v.shape, int(np.abs(v).max())) for k, v in out.items()})
 
+def headline_goldens(torch, ssi, ln):
+    """BASELINE configs 2 and 3 at full size through the reference's AudioMamba on CPU (selective_scan_ref loop; about ten minutes
+    and 10 GB for the Base backward).  Written to headline.npz; run with --headline (not part of the default regeneration)."""
+    import contextlib
+    import io
+    import time
+    mm = import_reference_model(torch, ssi, ln)
+    out = {}
+    for case in cases.HEADLINE_CASES:
+        name, btype, depth, dim, spec, ncls, batch, bwd = case
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = mm.AudioMamba(spectrogram_size=spec, depth=depth, embed_dim=dim, num_classes=ncls, bimamba_type=btype)
+        sd = model.state_dict()
+        vals = cases.model_state({k: tuple(v.shape) for k, v in sd.items()}, name)
+        model.load_state_dict({k: torch.tensor(v) for k, v in vals.items()})
+        d = cases.model_inputs(*case[:7])
+        with (contextlib.nullcontext() if bwd else torch.no_grad()):
+            logits = model(torch.tensor(d["x"]))
+        out[name + ".logits"] = npy(logits)
+        out[name + ".keys"] = np.array(sorted(sd.keys()))
+        if bwd:
+            (logits * torch.tensor(d["dlogits"])).sum().backward()
+            for k, p in model.named_parameters():
+                g = npy(p.grad)
+                out[name + ".gnorm." + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+                if p.numel() <= 1024:
+                    out[name + ".grad." + k] = g
+        out[name + ".checksum"] = cases.checksum(dict(vals, **d))
+        print(name, "done in %.0f s" % (time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(HERE, "headline.npz"), **out)
+    print("headline.npz", len(out))
+
+
 
 if __name__ == "__main__":
+    if os.path.isdir(REF) and "--headline" in sys.argv:
+        torch_, ssi_, ln_, _ = import_reference()
+        torch_.manual_seed(0)
+        torch_.set_num_threads(8)
+        headline_goldens(torch_, ssi_, ln_)
+        sys.exit(0)
     main()
     if os.path.isdir(REF) and "--wav-only" in sys.argv:
         wav_excerpts()

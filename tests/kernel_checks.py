@@ -2,6 +2,7 @@
 build on the host) against the oracle on seeded inputs.  Used by test_emu_kernels.py (CPU) and
 test_gpu_kernels.py (-m gpu)."""
 import numpy as np
+import pytest
 import torch
 
 import aum_hip
@@ -317,3 +318,34 @@ def check_scan_tm(lib, dev, case, dtype=torch.float32, reverse=False, bidir=Fals
     bad = {k: v for k, v in errs.items() if not (v < tol * (4 if k.startswith("d") else 1))}
     assert not bad, (name, str(dtype), "rev" if reverse else "fwd", "bidir" if bidir else "uni", bad, errs)
     return errs
+
+
+def check_gemm(lib, dev, case, dtype, flags=0):
+    """aum_gemm_tn (ABI 9) against an fp64 product of the same 16-bit operands: fp32 accumulation + one rounding -> within one 16-bit ulp
+    of the largest result.  MS:185-189 / SSI:517, 540 are F.linear calls in the reference (cuBLAS, same contract)."""
+    name, m, n, k, pad_a, pad_c = case
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    a_full = torch.randn(m, k + pad_a, generator=g).to(dtype).to(dev)
+    b = (torch.randn(n, k, generator=g) / k ** 0.5).to(dtype).to(dev)
+    a = a_full[:, :k]
+    c_full = torch.full((m, n + pad_c), 7.0, dtype=dtype, device=dev)
+    out = aum_hip.gemm_tn(a, b, out=c_full[:, pad_c:], lib=lib, flags=flags)
+    ref = a.double().cpu() @ b.double().cpu().t()
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = (out.double().cpu() - ref).abs().max().item()
+    assert err <= 1.01 * ulp * ref.abs().max().item() + 1e-30, (name, err, ref.abs().max().item())
+    if pad_c:
+        assert torch.all(c_full[:, :pad_c] == 7.0), "columns outside the result were written"
+
+
+def check_gemm_args(lib, dev):
+    """argument rules of aum_gemm_tn (csrc/gemm_args.h): refused shapes return an error code, nothing is launched"""
+    a = torch.zeros(8, 64, dtype=torch.bfloat16, device=dev)
+    for bad in (torch.zeros(128, 64, dtype=torch.bfloat16, device=dev),          # n % 256
+                torch.zeros(256, 32, dtype=torch.bfloat16, device=dev),          # k mismatch / k % 64
+                torch.zeros(256, 64, dtype=torch.float16, device=dev)):          # dtype mismatch
+        assert not aum_hip.gemm_tn_supported(a, bad)
+        with pytest.raises(RuntimeError):
+            aum_hip.gemm_tn(a, bad, lib=lib)
+    assert not aum_hip.gemm_tn_supported(a.float(), torch.zeros(256, 64, device=dev))

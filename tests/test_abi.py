@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(so_path):
     lib = ctypes.CDLL(so_path)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.aum_abi_version() == aum_hip.ABI_VERSION == 8
+    assert lib.aum_abi_version() == aum_hip.ABI_VERSION == 9
     assert lib.aum_scan_max_single_pass_len() == 576
     assert lib.aum_rmsnorm_bwd_partials(32832) == 4096
 
@@ -57,6 +57,7 @@ def test_struct_layouts_match_header(tmp_path):
                                                      "workspace_bytes", "u_bs", "pre_ts", "du_bs", "dz_ts", "batch", "dtype", "flags"]),
         "AumConvTmArgs": (aum_hip.ConvTmArgs, ["x", "dy", "weight", "bias", "y", "dx", "dw_part", "db_part", "x_bs", "dx_ts", "batch", "width",
                                                "dtype", "flags"]),
+        "AumGemmArgs": (aum_hip.GemmArgs, ["a", "b", "c", "m", "n", "k", "lda", "ldb", "ldc", "dtype", "flags"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']
     for cname, (_, fields) in probes.items():

@@ -235,3 +235,14 @@ def test_tm_limits(emu):
     assert not aum_hip.conv1d_tm_supported(torch.zeros(1, 4, 16), 5)
     with pytest.raises(RuntimeError, match="UNSUPPORTED|unsupported"):
         aum_hip.conv1d_tm_fwd(x.bfloat16(), torch.zeros(12, 4), None, lib=emu)
+
+
+@pytest.mark.parametrize("case", [c for c in cases.GEMM_CASES if c[1] * c[2] * c[3] < 2e8], ids=lambda c: c[0])
+def test_gemm_tn_contract(emu, case):
+    """the host build's aum_gemm_tn (a plain loop behind the same argument rules, tests/emu/aum_emu.cpp) keeps the contract the GPU
+    tests hold the MFMA kernel to; the kernel's own tile layout is checked in test_gemm_layout.py"""
+    KC.check_gemm(emu, "cpu", case, torch.bfloat16)
+
+
+def test_gemm_tn_argument_rules(emu):
+    KC.check_gemm_args(emu, "cpu")

@@ -414,3 +414,31 @@ def test_conv_tm_headline_shape(lib):
     dya = dy[:, :, ch].float().cpu().numpy().transpose(0, 2, 1)
     ra = O.conv1d_bwd(xa, ws, bb, dya, True, False, "f64")
     assert KC.rel_err(dw[ch].cpu().numpy(), ra["dweight"]) < 1e-3 and KC.rel_err(db[ch].cpu().numpy(), ra["dbias"]) < 1e-3
+
+
+@pytest.mark.parametrize("case", cases.GEMM_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("sched", ["staggered", "lockstep"])
+def test_gemm_tn(lib, case, dtype, sched):
+    KC.check_gemm(lib, "cuda", case, dtype, flags=aum_hip.GEMM_LOCKSTEP if sched == "lockstep" else 0)
+
+
+def test_gemm_tn_argument_rules(lib):
+    KC.check_gemm_args(lib, "cuda")
+
+
+@pytest.mark.parametrize("shape", cases.GEMM_FULL_CASES, ids=lambda s: "x".join(map(str, s)))
+def test_gemm_tn_full_size(lib, shape):
+    """the bench's own projection GEMMs (64 x 513 tokens: 128 full row blocks + one of 64 rows; 1548 / 387 / 774 workgroups) on sampled
+    rows against an fp64 product, bitwise repeatable from launch to launch"""
+    m, n, k = shape
+    torch.manual_seed(m + n + k)
+    a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
+    b = (torch.randn(n, k, device="cuda") / k ** 0.5).to(torch.bfloat16)
+    out = aum_hip.gemm_tn(a, b, lib=lib)
+    rows = torch.cat([torch.arange(0, 257, device="cuda"), torch.randint(0, m, (300,), device="cuda"), torch.arange(m - 257, m, device="cuda")])
+    ref = a[rows].double() @ b.double().t()
+    assert (out[rows].double() - ref).abs().max().item() <= 1.01 * 2.0 ** -8 * ref.abs().max().item()
+    for _ in range(3):
+        assert torch.equal(out, aum_hip.gemm_tn(a, b, lib=lib))
+    assert torch.equal(out, aum_hip.gemm_tn(a, b, lib=lib, flags=aum_hip.GEMM_LOCKSTEP))       # both schedules: the same sums in the same order

@@ -367,3 +367,85 @@ def test_base_block_token_major_bf16_matches_channel_major(monkeypatch):
     assert rel(res[0][0], res[1][0]) < 2e-2 and rel(res[0][1], res[1][1]) < 2e-2
     for k in res[0][2]:
         assert rel(res[0][2][k], res[1][2][k]) < 3e-2, k
+
+
+# ---- BASELINE configs 2 and 3 at full size against the reference's own AudioMamba (tests/golden/headline.npz, make_golden.py --headline:
+# MM:678-685 + RUN:227-237 on the container CPU, 19 minutes for the Base backward)
+def _headline_model(case):
+    from aum.model import AudioMamba
+    name, btype, depth, dim, spec, ncls, batch, bwd = case
+    model = AudioMamba(spectrogram_size=spec, depth=depth, embed_dim=dim, num_classes=ncls, bimamba_type=btype)
+    sd = model.state_dict()
+    g = load_golden("headline")
+    assert sorted(sd.keys()) == list(g[name + ".keys"])
+    vals = cases.model_state({k: tuple(v.shape) for k, v in sd.items()}, name)
+    d = cases.model_inputs(*case[:7])
+    assert abs(float(cases.checksum(dict(vals, **d))) - float(g[name + ".checksum"])) <= 1e-6 * abs(float(g[name + ".checksum"]))
+    model.load_state_dict({k: torch.tensor(v) for k, v in vals.items()})
+    return model.to(DEV), d, g
+
+
+def _headline_grad_errors(model, g, name, scale=1.0):
+    e_norm, e_elem = {}, {}
+    for k, p_ in model.named_parameters():
+        ref = float(g[f"{name}.gnorm.{k}"])
+        e_norm[k] = abs(float(p_.grad.double().norm().item()) / scale - ref) / max(ref, 1e-6)
+        if f"{name}.grad.{k}" in g:
+            e_elem[k] = rel_err(p_.grad.cpu().numpy() / scale, g[f"{name}.grad.{k}"])
+    return e_norm, e_elem
+
+
+def test_aum_base_headline_fp32_vs_reference():
+    """config 3's model (AuM-Base, 24 Fo-Bi blocks, 128 x 1024 frames -> 513 tokens, 527 classes) in fp32: logits at north_star's 1e-3,
+    every parameter gradient's norm (and the small gradients element-wise) against the reference's autograd"""
+    case = cases.HEADLINE_CASES[0]
+    name = case[0]
+    model, d, g = _headline_model(case)
+    logits = model(torch.tensor(d["x"], device=DEV))
+    (logits * torch.tensor(d["dlogits"], device=DEV)).sum().backward()
+    e_logits = rel_err(logits.detach().cpu().numpy(), g[name + ".logits"])
+    e_norm, e_elem = _headline_grad_errors(model, g, name)
+    wn, we = max(e_norm, key=e_norm.get), max(e_elem, key=e_elem.get)
+    _err_report(name + ".fp32", {"logits": e_logits, "gnorm_max": [wn, e_norm[wn]], "grad_elem_max": [we, e_elem[we]]})
+    assert e_logits < 1e-3, e_logits
+    assert e_norm[wn] < 2e-3, (wn, e_norm[wn])
+    assert e_elem[we] < 2e-3, (we, e_elem[we])
+
+
+def test_aum_base_headline_bench_batch_bf16_vs_reference():
+    """the bench's own launch shapes against the reference: the golden clip repeated 64 times under bf16 autocast goes through the
+    token-major kernels and the MFMA projection GEMMs exactly as bench.py's step does (B = 64, L = 513); every row of the logits is
+    the reference's logits, and the gradients are 64 times the reference's (dlogits repeated).  Bars: the depth-scaled bf16 bars above."""
+    case = cases.HEADLINE_CASES[0]
+    name, depth = case[0], case[2]
+    model, d, g = _headline_model(case)
+    reps = 64
+    x = torch.tensor(d["x"], device=DEV).repeat(reps, 1, 1)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lb = model(x)
+    (lb.float() * torch.tensor(d["dlogits"], device=DEV)).sum().backward()
+    ref = g[name + ".logits"]
+    e_rows = [rel_err(lb[i:i + 1].float().detach().cpu().numpy(), ref) for i in (0, 1, 31, 63)]
+    e_norm, e_elem = _headline_grad_errors(model, g, name, scale=float(reps))
+    wn, we = max(e_norm, key=e_norm.get), max(e_elem, key=e_elem.get)
+    _err_report(name + ".bf16_b64", {"logits": max(e_rows), "gnorm_max": [wn, e_norm[wn]], "grad_elem_max": [we, e_elem[we]]})
+    assert max(e_rows) < BF16_LOGIT_TOL * (depth / 4) ** 0.5, e_rows
+    assert e_norm[wn] < BF16_GNORM_TOL * (depth / 4) ** 0.5, (wn, e_norm[wn])
+    assert e_elem[we] < BF16_GRAD_TOL * (depth / 4) ** 0.5, (we, e_elem[we])
+
+
+def test_aum_small_headline_forward_bf16_vs_reference():
+    """config 2: AuM-Small (d_model 384, 24 blocks) forward only, two clips, fp32 at 1e-3 and bf16 autocast at the depth-scaled bar"""
+    case = cases.HEADLINE_CASES[1]
+    name, depth = case[0], case[2]
+    model, d, g = _headline_model(case)
+    x = torch.tensor(d["x"], device=DEV)
+    with torch.no_grad():
+        l32 = model(x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            l16 = model(x)
+    e32 = rel_err(l32.cpu().numpy(), g[name + ".logits"])
+    e16 = rel_err(l16.float().cpu().numpy(), g[name + ".logits"])
+    _err_report(name, {"logits_fp32": e32, "logits_bf16": e16})
+    assert e32 < 1e-3, e32
+    assert e16 < BF16_LOGIT_TOL * (depth / 4) ** 0.5, e16
