@@ -258,7 +258,9 @@ def _gather_order(n_steps, batch_size, per_rank, world):
 
 def validate(model, loader, frontend, args, D, epoch, save_pred=True):
     """TT:238-307.  NOTE the reference feeds SIGMOID outputs to the loss here (TT:266-274); kept, so valid_loss is
-    comparable with its logs."""
+    comparable with its logs.  valid_loss is the mean of the per-batch losses of ALL gathered batches, the DistributedSampler's padding
+    duplicates included -- exactly the reference's number; the mAP / AUC below are computed on the de-duplicated rows (a documented
+    divergence: the reference keeps the duplicates there too), so the two do not describe quite the same sample set under DDP."""
     from .stats import calculate_stats
     model.eval()
     loss_fn = _loss_fn(args)
@@ -326,7 +328,7 @@ def train(model, train_loader, val_loader, args, D):
     net = model
     if D.world > 1:
         net = nn.parallel.DistributedDataParallel(model, device_ids=[D.dev_index] if D.cuda else None,
-                                                  gradient_as_bucket_view=True, static_graph=True, bucket_cap_mb=100)
+                                                  gradient_as_bucket_view=True, static_graph=bool(args.if_nan2num), bucket_cap_mb=100)
         compress_gradients(net, args.grad_compress)
     scaler = torch.amp.GradScaler("cuda", enabled=(args.mixed_precision == "fp16" and D.cuda))
     scheduler = torch.optim.lr_scheduler.MultiStepLR(
@@ -375,6 +377,11 @@ def train(model, train_loader, val_loader, args, D):
                 if finite.item() == 0.0:
                     if args.if_continue_inf:
                         D.print("Loss is not finite on some rank, continuing training")
+                        # every forward of the wrapper gets its backward (a zero loss, no exchange): the reducer's per-iteration
+                        # bookkeeping stays in step on all ranks; this path is also why static_graph is off without --if_nan2num
+                        if D.world > 1:
+                            with net.no_sync():
+                                (out.float().sum() * 0.0).backward()
                         optimizer.zero_grad()
                         continue
                     D.print("Loss is not finite on some rank, stopping training")
@@ -385,7 +392,8 @@ def train(model, train_loader, val_loader, args, D):
             scaler.update()
             # running loss stays on the device: no .item() and no collective per step (the reference's per-step gather + print,
             # TT:157-174, is what SURVEY 5 flags as the scaling hazard); ranks exchange it every n_print_steps and per epoch
-            loss_acc += torch.stack([loss.detach().float() * wave.shape[0], loss_acc.new_tensor(float(wave.shape[0]))])
+            loss_acc[0].add_(loss.detach().float(), alpha=float(wave.shape[0]))       # scalars ride as kernel arguments: no host tensor, no copy
+            loss_acc[1] += float(wave.shape[0])
             global_step += 1
             HOST_SYNCS["steps"] += 1
             if global_step % args.n_print_steps == 0:

@@ -7,7 +7,31 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
     const AumGemmArgs& g = *p;
     const int tiles = (g.m + aumg::BM - 1) / aumg::BM * (g.n / aumg::BN);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool lockstep = (g.flags & AUM_GEMM_LOCKSTEP) != 0;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return AUM_E_LAUNCH;
+        ncu = prop.multiProcessorCount;
+    }
+    // Which kernel: the persistent one pays off when a CU gets several tiles (cheap ragged row block, next tile prefetched under the stores:
+    // 774 / 1548 tiles at N = 1536 / 3072: 84.6 vs 94.2 us, 158.6 vs 169.1 us); with at most two tiles per CU (N = 768: 387 tiles) one
+    // workgroup per tile is as fast or faster (84.3 vs 87.4 us, 159.4 vs 162.2 us).  profiles/r03_gemm_probe.txt
+    uint32_t flags = g.flags;
+    if (!(flags & (AUM_GEMM_LOCKSTEP | AUM_GEMM_STAGGERED | AUM_GEMM_PERSISTENT))) flags |= tiles > 2 * ncu ? AUM_GEMM_PERSISTENT : AUM_GEMM_LOCKSTEP;
+    if (flags & AUM_GEMM_PERSISTENT) {
+        aumg::GemmLaunch L;
+        L.g = g;
+        const int rem = g.m % aumg::BM;
+        L.full_rb = g.m / aumg::BM + (rem > 128 ? 1 : 0);            // a remainder above 128 rows is a full item whose last rows are out of range
+        L.half_rb = rem > 0 && rem <= 128 ? 1 : 0;
+        L.nitems = (L.full_rb + L.half_rb) * (g.n / aumg::BN);
+        const int grid = L.nitems < ncu ? L.nitems : ncu;
+        if (g.dtype == AUM_BF16) hipLaunchKernelGGL(aumg::k_gemm_tn_persistent<true>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
+        else hipLaunchKernelGGL(aumg::k_gemm_tn_persistent<false>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
+        return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
+    }
+    const bool lockstep = (flags & AUM_GEMM_LOCKSTEP) != 0;
     if (g.dtype == AUM_BF16) {
         if (lockstep) hipLaunchKernelGGL((aumg::k_gemm_tn<true, 0>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
         else hipLaunchKernelGGL((aumg::k_gemm_tn<true, 1>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);

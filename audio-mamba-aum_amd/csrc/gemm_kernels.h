@@ -17,12 +17,13 @@
 //   * the LDS image is lane-linear (the DMA writes lane l's 16 bytes at base + 16 l), so the bank swizzle lives in the SOURCE address:
 //     the lane that fills 16-byte slot s of row r fetches k-slot s ^ f(r), and the fragment reads apply the same XOR.
 //     ds_read_b128 serves 16 lanes per LDS cycle over a 256-byte bank row (two 128-byte tile rows): A fragments read rows r0 .. r0+15,
-//     f_A(r) = (r >> 1) & 7; B fragments read rows {16 q + 4 j + e} (below), f_B(r) = ((r >> 4) & 3) << 1 | ((r >> 1) & 1): both give
+//     f_A(r) = (r >> 1) & 7; B fragments read rows {8 q + e + 32 (j >> 1) + 4 (j & 1)} (below), f_B(r) = ((r >> 3) & 3) << 1 | ((r >> 1) & 1): both give
 //     16 distinct slots per lane group (checked exhaustively on the host: tests/test_gemm_layout.py).
 //   * MFMA roles are swapped -- the weight fragment is the MFMA's A operand, the activation fragment its B operand -- so a lane's four
 //     accumulator values of a fragment are four consecutive COLUMNS of C, and fragment j of a wave reads weight rows
-//     {16 q + 4 j + e : q, e = 0..3} so that the 4 fragments x 4 values of a lane are 16 consecutive columns: two 16-byte stores per
-//     lane and fragment row, the four lane groups of a wave completing a 128-byte line of C.
+//     {8 q + e + 32 (j >> 1) + 4 (j & 1) : q, e = 0..3}: fragments 0, 1 of lane group kg are columns 8 kg .. 8 kg + 7 and fragments 2, 3
+//     columns 32 + 8 kg ..: two 16-byte stores per lane and fragment row, each store instruction writing 64 contiguous bytes per row of C
+//     (the first layout -- 16 consecutive columns per lane, 16-byte pieces 32 bytes apart per instruction -- cost 7 us of a 26 us tile).
 //   * launch: blockIdx -> tile with the 8 XCDs each taking a contiguous range of tiles (tiles of one row block of A next to each other:
 //     A is fetched from HBM once per XCD-resident row block, B (the weight, <= 4.7 MB) stays in L2 / MALL).
 #pragma once
@@ -69,6 +70,8 @@ __device__ __forceinline__ void stage(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer
     }
 }
 
+// weight fragment j of a wave reads tile rows {8 q + e + 32 (j >> 1) + 4 (j & 1) : q, e = 0..3} of the wave's 64
+__device__ __forceinline__ constexpr int b_joff(int j) { return ((j >> 1) * 32 + (j & 1) * 4) * 128; }
 __device__ __forceinline__ s8v lds_frag(const char* lds, int byte_off) { return *reinterpret_cast<const s8v*>(lds + byte_off); }
 
 // blockIdx -> tile id with each XCD (blockIdx % 8) working through a contiguous range of ids (bijective for any grid size)
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
     // staging: this lane fills slot (lane & 7) of row 8 c + (lane >> 3); f_A / f_B of that row do not depend on j
     const int srow = w * 8 + (lane >> 3);
     const int f_a = ((w & 1) * 4 + (lane >> 4)) & 7;
-    const int f_b = (((w >> 1) & 3) << 1) | ((lane >> 4) & 1);
+    const int f_b = ((w & 3) << 1) | ((lane >> 4) & 1);
     const int voff_a = srow * g.lda * 2 + (((lane & 7) ^ f_a) << 4);
     const int voff_b = srow * g.ldb * 2 + (((lane & 7) ^ f_b) << 4);
     const int rowstep_a = 64 * g.lda * 2, rowstep_b = 64 * g.ldb * 2;
@@ -118,8 +121,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
     // fragment reads: lane = (operand row rho = lane & 15, k-group kg = lane >> 4)
     const int rho = lane & 15, kg = lane >> 4;
     const int a_rd = (wr * 128 + rho) * 128 + ((kg ^ ((lane >> 1) & 7)) << 4);                                  // + i * 2048, ^ 64 for the second half of K
-    const int b_row = wc * 64 + (rho >> 2) * 16 + (rho & 3);                                                    // + j * 4
-    const int b_rd = TILE_BYTES + b_row * 128 + ((kg ^ ((((rho >> 2) & 3) << 1) | ((rho >> 1) & 1))) << 4);     // + j * 512, ^ 64
+    const int b_row = wc * 64 + (rho >> 2) * 8 + (rho & 3);                                                     // + (j >> 1) * 32 + (j & 1) * 4
+    const int b_rd = TILE_BYTES + b_row * 128 + ((kg ^ ((((rho >> 2) & 3) << 1) | ((rho >> 1) & 1))) << 4);     // + b_joff(j), ^ 64
 
     f4v acc[8][4];
 #pragma unroll
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
             for (int kk = 0; kk < 2; ++kk) {
                 s8v bf[4], af[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bf[j] = lds_frag(st, (b_rd ^ (kk * 64)) + j * 512);
+                for (int j = 0; j < 4; ++j) bf[j] = lds_frag(st, (b_rd ^ (kk * 64)) + b_joff(j));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) af[i] = lds_frag(st, (a_rd ^ (kk * 64)) + i * 2048);
 #pragma unroll
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
                 // ---- load segment
                 s8v bf[4], af[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bf[j] = lds_frag(st, (b_rd ^ (kk * 64)) + j * 512);
+                for (int j = 0; j < 4; ++j) bf[j] = lds_frag(st, (b_rd ^ (kk * 64)) + b_joff(j));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) af[i] = lds_frag(st, (a_rd ^ (kk * 64)) + i * 2048);
                 if (more && kk == 1 - wr) stage(ra, rb, voff_a, voff_b, (t + 1) * (BK * 2), rowstep_a, rowstep_b, lds + ((t + 1) & 1) * STAGE_BYTES, w);
@@ -187,8 +190,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
         if (wr == 0) __builtin_amdgcn_s_barrier();                 // B_2P
     }
 
-    // store: lane holds, for fragment row i, columns wc * 64 + kg * 16 + 4 j + r (j, r = 0..3) of row wr * 128 + 16 i + rho
-    char* c_base = static_cast<char*>(g.c) + ((int64_t)m0 * g.ldc + n0 + wc * 64 + kg * 16) * 2;
+    // store: lane holds, for fragment row i, columns wc * 64 + 32 (j >> 1) + 8 kg + 4 (j & 1) + r (j, r = 0..3) of row wr * 128 + 16 i + rho
+    char* c_base = static_cast<char*>(g.c) + ((int64_t)m0 * g.ldc + n0 + wc * 64 + kg * 8) * 2;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int row = wr * 128 + i * 16 + rho;
@@ -204,8 +207,187 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
             hi.w = pack2<BF16>(acc[i][3][2], acc[i][3][3]);
             u4v* dst = reinterpret_cast<u4v*>(c_base + (int64_t)row * g.ldc * 2);
             dst[0] = lo;
-            dst[1] = hi;
+            dst[4] = hi;
         }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Persistent form (the default).  One workgroup per CU walks a list of work items round-robin (item = blockIdx + round * gridDim):
+//   * full items: 256 x 256 tiles of the row blocks that are complete; in each round the 32 workgroups of an XCD take 32 consecutive
+//     tiles (2.7 row blocks of A x the column tiles: A comes from HBM once per XCD, the weight stays in L2 / MALL);
+//   * half items: the last m % 256 rows when they are at most 128 (the bench: 64 x 513 tokens = 128 row blocks + 64 rows) as 128 x 256
+//     tiles -- the two row halves of the wave grid take 64 rows each (4 fragment rows instead of 8), a half with no rows left skips its
+//     reads and MFMAs -- instead of a round of full-price tiles for a quarter of a tile's work (7 -> 6.3 rounds at N = 3072).
+//   * the K loop is the lockstep one (SCHED 0 above); in its LAST step, where a tile has nothing left to fetch, the wave issues the
+//     pieces of the NEXT item's first step, so the next tile's HBM round trip runs under this tile's stores, and the next tile's first
+//     wait is counted so that those stores stay in flight.
+// What bounds it (measured, profiles/r03_gemm_*): a K-step takes 1.54 us (1.39 PFLOP/s across the chip) whatever the shape, and every tile
+// pays 5.7 us on top -- its 128 KB of C leave the CU at HBM's pace while every matrix pipe idles, in all 256 CUs at the same moment
+// (tiles take equal time).  Tried: rounding a finished tile to 64 packed registers and storing it two stores per K-step under the next
+// tile (exact counted waits): 256 VGPRs + spills, the compiler falls back to one fragment read per four MFMAs, 210 us instead of 159;
+// deferring half of the tile (230 VGPRs, no spills): 162 us, the basic loop loses what the stores gain.  Not kept.
+// Buffer parity: step t of a tile uses buffer (par + t) & 1; the next tile starts at par' = (par + nk) & 1, the buffer the last-but-one
+// step was read from (free since the barrier of the last step).
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct GemmLaunch {
+    AumGemmArgs g;
+    int full_rb;        // complete 256-row blocks handled as full items
+    int half_rb;        // 128-row blocks behind them (the last one may be ragged)
+    int nitems;
+};
+
+struct GemmItem {
+    int m0, n0, rows;
+    bool half;
+};
+__device__ __forceinline__ GemmItem gemm_item(const GemmLaunch& L, int id, int ntn, int grid) {
+    GemmItem it;
+    const int nfull = L.full_rb * ntn;
+    if (id < nfull) {
+        int tile = id;
+        const int r0 = id / grid * grid;
+        if ((grid & 7) == 0 && r0 + grid <= nfull) {            // a complete round: XCD x (= workgroup % 8) takes tiles r0 + x * grid/8 ...
+            const int q = id - r0;
+            tile = r0 + (q & 7) * (grid >> 3) + (q >> 3);
+        }
+        const int tm = tile / ntn;
+        it.m0 = tm * BM;
+        it.n0 = (tile - tm * ntn) * BN;
+        it.rows = BM;
+        it.half = false;
+    } else {
+        const int h = id - nfull, hb = h / ntn;
+        it.m0 = L.full_rb * BM + hb * 128;
+        it.n0 = (h - hb * ntn) * BN;
+        it.rows = L.g.m - it.m0 < 128 ? L.g.m - it.m0 : 128;
+        it.half = true;
+    }
+    return it;
+}
+
+// A tile's K-steps.  stores16: the previous item of this workgroup was a full tile, i.e. behind the pieces of this tile's first step there
+// are exactly that tile's 16 stores per wave (memory operations retire in issue order) -- the first wait leaves them in flight.
+// (The body is written out here rather than in a helper: the same statements behind a function boundary compile to a 220-register
+// schedule that runs the persistent kernel 10 % slower -- check .vgpr_count = 170 and the step A/B after touching this.)
+template <bool BF16, int NI>
+__device__ __forceinline__ void gemm_steps(f4v (&acc)[8][4], int nk, int par, bool active, char* lds, int a_rd, int b_rd, __amdgpu_buffer_rsrc_t ra,
+                                           __amdgpu_buffer_rsrc_t rb, bool has_next, __amdgpu_buffer_rsrc_t ra_n, __amdgpu_buffer_rsrc_t rb_n,
+                                           int voff_a, int voff_b, int rowstep_a, int rowstep_b, int w, bool stores16, uint32_t L_flags) {
+    for (int t = 0; t < nk; ++t) {
+        if (t == 0 && stores16 && !(L_flags & (AUM_GEMM_NO_COUNTED_WAIT | AUM_GEMM_NO_PREFETCH))) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        char* nxt = lds + ((par + t + 1) & 1) * STAGE_BYTES;
+        if (t + 1 < nk) stage(ra, rb, voff_a, voff_b, (t + 1) * (BK * 2), rowstep_a, rowstep_b, nxt, w);
+        else if (has_next && !(L_flags & AUM_GEMM_NO_PREFETCH)) stage(ra_n, rb_n, voff_a, voff_b, 0, rowstep_a, rowstep_b, nxt, w);
+        const char* st = lds + ((par + t) & 1) * STAGE_BYTES;
+        if (active) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                s8v bf[4], af[NI];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = lds_frag(st, (b_rd ^ (kk * 64)) + b_joff(j));
+#pragma unroll
+                for (int i = 0; i < NI; ++i) af[i] = lds_frag(st, (a_rd ^ (kk * 64)) + i * 2048);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(bf[j], af[i], acc[i][j]);
+            }
+        }
+    }
+}
+template <bool BF16, int NI>
+__device__ __forceinline__ void gemm_store(const f4v (&acc)[8][4], char* c_rows, int64_t ldc2, int row0, int rows) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = row0 + i * 16;
+        if (row < rows) {
+            u4v lo, hi;
+            lo.x = pack2<BF16>(acc[i][0][0], acc[i][0][1]);
+            lo.y = pack2<BF16>(acc[i][0][2], acc[i][0][3]);
+            lo.z = pack2<BF16>(acc[i][1][0], acc[i][1][1]);
+            lo.w = pack2<BF16>(acc[i][1][2], acc[i][1][3]);
+            hi.x = pack2<BF16>(acc[i][2][0], acc[i][2][1]);
+            hi.y = pack2<BF16>(acc[i][2][2], acc[i][2][3]);
+            hi.z = pack2<BF16>(acc[i][3][0], acc[i][3][1]);
+            hi.w = pack2<BF16>(acc[i][3][2], acc[i][3][3]);
+            u4v* dst = reinterpret_cast<u4v*>(c_rows + (int64_t)row * ldc2);
+            dst[0] = lo;
+            dst[4] = hi;
+        }
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_persistent(GemmLaunch L) {
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const AumGemmArgs& g = L.g;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = w >> 2, wc = w & 3;
+    const int ntn = g.n / BN, grid = (int)gridDim.x, nk = g.k / BK;
+
+    const int srow = w * 8 + (lane >> 3);
+    const int f_a = ((w & 1) * 4 + (lane >> 4)) & 7;
+    const int f_b = ((w & 3) << 1) | ((lane >> 4) & 1);
+    const int voff_a = srow * g.lda * 2 + (((lane & 7) ^ f_a) << 4);
+    const int voff_b = srow * g.ldb * 2 + (((lane & 7) ^ f_b) << 4);
+    const int rowstep_a = 64 * g.lda * 2, rowstep_b = 64 * g.ldb * 2;
+    const int rho = lane & 15, kg = lane >> 4;
+    const int a_swz = (kg ^ ((lane >> 1) & 7)) << 4;
+    const int b_row = wc * 64 + (rho >> 2) * 8 + (rho & 3);
+    const int b_rd = TILE_BYTES + b_row * 128 + ((kg ^ ((((rho >> 2) & 3) << 1) | ((rho >> 1) & 1))) << 4);
+
+    auto rsrc_a = [&](const GemmItem& it) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(g.a) + (int64_t)it.m0 * g.lda * 2), 0,
+                                                 it.rows * g.lda * 2, 0x00020000);
+    };
+    auto rsrc_b = [&](const GemmItem& it) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(g.b) + (int64_t)it.n0 * g.ldb * 2), 0,
+                                                 BN * g.ldb * 2, 0x00020000);
+    };
+
+    int id = (int)blockIdx.x;
+    if (id >= L.nitems) return;
+    GemmItem it = gemm_item(L, id, ntn, grid);
+    __amdgpu_buffer_rsrc_t ra = rsrc_a(it), rb = rsrc_b(it);
+    int par = 0;
+    bool stores16 = false;          // the previous item of this workgroup was a full tile
+    stage(ra, rb, voff_a, voff_b, 0, rowstep_a, rowstep_b, lds, w);
+    while (true) {
+        const int nid = id + grid;
+        const bool has_next = nid < L.nitems;
+        GemmItem itn = it;
+        if (has_next) itn = gemm_item(L, nid, ntn, grid);
+        const __amdgpu_buffer_rsrc_t ra_n = rsrc_a(itn), rb_n = rsrc_b(itn);
+
+        f4v acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+        const int row_base = it.half ? wr * 64 : wr * 128;                // this wave's first row of the tile
+        const int a_rd = (row_base + rho) * 128 + a_swz;
+        char* c_rows = static_cast<char*>(g.c) + ((int64_t)it.m0 * g.ldc + it.n0 + wc * 64 + kg * 8) * 2;
+        if (!it.half) {
+            gemm_steps<BF16, 8>(acc, nk, par, true, lds, a_rd, b_rd, ra, rb, has_next, ra_n, rb_n, voff_a, voff_b, rowstep_a, rowstep_b, w, stores16, g.flags);
+            gemm_store<BF16, 8>(acc, c_rows, (int64_t)g.ldc * 2, row_base + rho, it.rows);
+        } else {
+            gemm_steps<BF16, 4>(acc, nk, par, row_base < it.rows, lds, a_rd, b_rd, ra, rb, has_next, ra_n, rb_n, voff_a, voff_b, rowstep_a,
+                                rowstep_b, w, stores16, g.flags);
+            gemm_store<BF16, 4>(acc, c_rows, (int64_t)g.ldc * 2, row_base + rho, it.rows);
+        }
+        if (!has_next) break;
+        stores16 = !it.half;
+        id = nid;
+        it = itn;
+        ra = ra_n;
+        rb = rb_n;
+        par = (par + nk) & 1;
+        if (g.flags & AUM_GEMM_NO_PREFETCH) stage(ra, rb, voff_a, voff_b, 0, rowstep_a, rowstep_b, lds + par * STAGE_BYTES, w);      // A/B: fetch at the tile's head
     }
 }
 

@@ -20,6 +20,8 @@
 
 #ifdef AUM_EMU
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #define AUM_DEV inline
 #define AUM_UNROLL _Pragma("unroll")
@@ -134,6 +136,9 @@ AUM_DEV vf2 vsel2(vm m, vf2 a, vf2 b) { return m ? a : b; }
 // Element offsets are taken as UNSIGNED 32-bit values (every caller clamps them into the row): the access then is
 // `global_* v, v_offset, s[base]` -- an SGPR base plus a 32-bit VGPR offset -- instead of a sign-extended 64-bit per-lane address
 // (two VGPRs and a v_lshl_add_u64 per access, and they get hoisted out of loops and spilled).
+// CONTRACT: on every ACTIVE lane the index is >= 0 (a negative index -- an address before the row pointer -- would wrap to +4 G elements
+// here).  Callers clamp with vmax_i or mask such lanes; the lane-array build asserts it (aum_emu_idx_ok below) so the host tests catch a
+// violation the device would turn into a wild access.
 template <class T> AUM_DEV vf gload(const T* p, vi idx, vm m) { return m ? elem_to_f32(p[(uint32_t)idx]) : 0.f; }
 template <class T> AUM_DEV void gstore(T* p, vi idx, vf v, vm m) { if (m) f32_to_elem(v, p[(uint32_t)idx]); }
 // unconditional load (caller clamps idx into range): no exec-mask branch, so several can be in flight
@@ -564,18 +569,24 @@ inline vf2 vfma2(const vf2& a, const vf2& b, const vf2& c) { return vf2{vfma(a.x
 inline vf2 vexp2_2(const vf2& v) { return vf2{vexp2(v.x), vexp2(v.y)}; }
 inline vf2 vsel2(const vm& m, const vf2& a, const vf2& b) { return vf2{vsel(m, a.x, b.x), vsel(m, a.y, b.y)}; }
 
-template <class T> inline vf gload(const T* p, const vi& idx, const vm& m) {
-    vf r; AUM_LANES r.v[l] = m.v[l] ? elem_to_f32(p[idx.v[l]]) : 0.f; return r;
+// the device helpers index with (uint32_t)idx: an active lane must not carry a negative index (see the contract at the device versions)
+inline void aum_emu_idx_ok(int idx, const char* what) {
+    if (idx < 0) { std::fprintf(stderr, "aum emu: negative element index %d on an active lane in %s\n", idx, what); std::abort(); }
 }
-template <class T> inline vf gload_u(const T* p, const vi& idx) { vf r; AUM_LANES r.v[l] = elem_to_f32(p[idx.v[l]]); return r; }
+template <class T> inline vf gload(const T* p, const vi& idx, const vm& m) {
+    vf r; AUM_LANES { if (m.v[l]) aum_emu_idx_ok(idx.v[l], "gload"); r.v[l] = m.v[l] ? elem_to_f32(p[idx.v[l]]) : 0.f; } return r;
+}
+template <class T> inline vf gload_u(const T* p, const vi& idx) { vf r; AUM_LANES { aum_emu_idx_ok(idx.v[l], "gload_u"); r.v[l] = elem_to_f32(p[idx.v[l]]); } return r; }
 template <class T> inline void gstore(T* p, const vi& idx, const vf& v, const vm& m) {
-    AUM_LANES if (m.v[l]) f32_to_elem(v.v[l], p[idx.v[l]]);
+    AUM_LANES if (m.v[l]) { aum_emu_idx_ok(idx.v[l], "gstore"); f32_to_elem(v.v[l], p[idx.v[l]]); }
 }
 inline void gatomic_add(float* p, const vi& idx, const vf& v, const vm& m) { AUM_LANES if (m.v[l]) p[idx.v[l]] += v.v[l]; }
 template <class T> inline void gload8(const T* p, const vi& idx, const vm& m, vf (&o)[8]) {
+    AUM_LANES if (m.v[l]) aum_emu_idx_ok(idx.v[l], "gload8");
     for (int j = 0; j < 8; ++j) AUM_LANES o[j].v[l] = m.v[l] ? elem_to_f32(p[idx.v[l] + j]) : 0.f;
 }
 template <class T> inline void gstore8(T* p, const vi& idx, const vf (&v)[8], const vm& m) {
+    AUM_LANES if (m.v[l]) aum_emu_idx_ok(idx.v[l], "gstore8");
     for (int j = 0; j < 8; ++j) AUM_LANES if (m.v[l]) f32_to_elem(v[j].v[l], p[idx.v[l] + j]);
 }
 inline vf gload_coherent(const float* p, const vi& idx, const vm& m) { return gload(p, idx, m); }

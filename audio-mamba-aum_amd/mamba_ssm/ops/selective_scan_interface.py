@@ -25,13 +25,22 @@ import torch.nn.functional as F
 
 import aum_hip
 
-# Host-side switches (README.md "Switches"), read ONCE at import: a variable set later in a running job changes nothing.
-_STEP_CACHE_ON = os.environ.get("AUM_STEP_CACHE", "1") != "0"
-_WGRAD_SPLIT_ON = os.environ.get("AUM_WGRAD_SPLIT", "1") != "0"
-_REF_DZ_DROP = os.environ.get("AUM_REF_DZ_DROP", "0") == "1"
+# Host-side switches (README.md "Switches"), read ONCE at import: a variable set later in a running job changes nothing.  As in
+# aum_hip.debug, the ones that change WHICH kernels or GEMMs run are honoured only under AUM_DEBUG=1 (A/B runs, tools/); a production job
+# cannot be steered onto another path by a stray variable.
+_DBG = os.environ.get("AUM_DEBUG") == "1"
+
+
+def _dbg_env(name, default):
+    return os.environ.get(name, default) if _DBG else default
+
+
+_STEP_CACHE_ON = _dbg_env("AUM_STEP_CACHE", "1") != "0"
+_WGRAD_SPLIT_ON = _dbg_env("AUM_WGRAD_SPLIT", "1") != "0"
+_REF_DZ_DROP = os.environ.get("AUM_REF_DZ_DROP", "0") == "1"        # a numerics option (the reference's dz), not a kernel switch
 # AUM_TOKEN_MAJOR=0: the blocks keep their activations channel-major [E][B*L] (rounds 1-2: the row kernels); default: token-major
 # [B*L][E] rows (the time-serial scan kernels, the register-window conv, plain row-major GEMMs) where the shape allows it
-TOKEN_MAJOR = os.environ.get("AUM_TOKEN_MAJOR", "1") != "0"
+TOKEN_MAJOR = _dbg_env("AUM_TOKEN_MAJOR", "1") != "0"
 
 _custom_fwd = torch.amp.custom_fwd(device_type="cuda")
 _custom_bwd = torch.amp.custom_bwd(device_type="cuda")
@@ -49,6 +58,9 @@ def _autocast_dtype():
 # that owns many blocks can do all of it in a handful of launches at the top of its forward (`with step_cache(mixers, dtype)`); the
 # blocks then find their 16-bit weights, the transposes and A here.  Entries live for one forward (the autograd graph keeps what the
 # backward needs); a Mamba block used on its own finds nothing and casts per call, exactly as before.
+# NOT thread-safe: the dict is process-global and keyed by id(parameter); two forwards of the SAME model in two threads would pop each
+# other's entries (the result stays right -- a missing entry is a per-call cast -- but the saving is lost).  One forward per process at a
+# time is what the launcher and bench.py do.
 _STEP_CACHE = {}
 
 
@@ -61,8 +73,11 @@ def step_cache(mixers, dtype):
         for name in ("in_proj", "x_proj", "dt_proj", "out_proj", "x_proj_b", "dt_proj_b"):
             lin = getattr(m, name, None)
             if lin is not None and dtype is not None and lin.weight.dtype != dtype:
-                groups.setdefault((name in ("x_proj", "dt_proj", "x_proj_b", "dt_proj_b"), tuple(lin.weight.shape), lin.weight.device),
-                                  []).append(lin.weight)
+                # data gradient on the MFMA kernel: g [tokens, out] @ W [out, in] = gemm_tn(g, W^T [in, out]) -> (N, K) = (in, out)
+                want_t = name in ("x_proj", "dt_proj", "x_proj_b", "dt_proj_b") or (
+                    torch.is_grad_enabled() and lin.weight.is_cuda and lin.weight.dim() == 2
+                    and _hip_gemm_ok(lin.weight.new_empty(0, dtype=dtype), lin.weight.shape[1], lin.weight.shape[0]))
+                groups.setdefault((want_t, tuple(lin.weight.shape), lin.weight.device), []).append(lin.weight)
         a_logs += [p for p in (getattr(m, "A_log", None), getattr(m, "A_b_log", None)) if p is not None]
     mine = []
     with torch.no_grad():
@@ -220,7 +235,7 @@ def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
 # a bit mask for A/B runs (1 in_proj forward, 2 out_proj forward, 4 out_proj data gradient, 8 in_proj data gradient).  Same-box A/B of the
 # step: mask 0 / 1 / 2 / 4 / 8 / 15 / 13 = 80.06 / 79.67 / 80.10 / 79.53 / 79.63 / 78.97 / 78.87 ms -> default 13 (the out_proj forward
 # loses what it gains to its 17 us remainder GEMM).
-_TOKEN_SPLIT = int(os.environ.get("AUM_GEMM_TOKEN_SPLIT", "13"))
+_TOKEN_SPLIT = int(_dbg_env("AUM_GEMM_TOKEN_SPLIT", "13"))
 
 
 def _tok_n0(ntok, bit, t):
@@ -257,8 +272,10 @@ def _mm_tokens_rows(at, b, bit):
 # (4, 8): 82.42 -> 81.63 ms; cold-cache sweep of the two GEMMs incl. their partial sums in profiles/r02_sweep_wgrad_splits.txt
 # (out_proj 8 / 9 splits: 123 / 98 us).  AUM_WGRAD_SPLITS="in,out" forces a pair for sweeps.
 _WGRAD_SPLITS = ((6, 4, 8, 2), (9, 8, 4, 2))
-if os.environ.get("AUM_WGRAD_SPLITS"):
-    _WGRAD_SPLITS = tuple((int(v),) for v in os.environ["AUM_WGRAD_SPLITS"].split(","))
+if _dbg_env("AUM_WGRAD_SPLITS", ""):
+    _WGRAD_SPLITS = tuple((int(v),) for v in _dbg_env("AUM_WGRAD_SPLITS", "").split(","))
+    if len(_WGRAD_SPLITS) != 2:
+        raise ValueError("AUM_WGRAD_SPLITS takes two counts, 'in_proj,out_proj' (e.g. AUM_WGRAD_SPLITS=6,9)")
 
 
 def _pick_splits(K, prefs):
@@ -316,6 +333,49 @@ def _mm_rows(a, b, bit):
     return out
 
 
+# The K-contiguous projection GEMMs of the token-major block -- in_proj / out_proj forward, and their data gradients against the cached
+# transposed weight -- can run on the hand-written MFMA kernel (aum_hip.gemm_tn, csrc/gemm_kernels.h) whenever the operands qualify
+# (16-bit, device, widths that are multiples of 256 / 64).  Measured on MI355X at the bench shape (profiles/r03_gemm_probe.txt,
+# r03_gemm_step_ab.txt) it beats the tuned library GEMM on the out_proj data gradient (N = 1536, K = 768: 84.6 vs 91.4 us) and loses 8-20 %
+# on the other three (tile quantisation at N = 768, the synchronized store bursts of DESIGN 4.8): the default ("auto") sends a GEMM to the
+# kernel only for the (N, K) it measured faster on; AUM_DEBUG=1 AUM_GEMM=hip sends all four, AUM_GEMM=lib none (A/B runs).  The weight
+# gradients (token-contiguous operands) and everything that does not qualify stay library GEMMs.
+_GEMM_MODE = _dbg_env("AUM_GEMM", "auto")
+if _GEMM_MODE not in ("auto", "hip", "lib"):
+    raise ValueError("AUM_GEMM takes auto, hip or lib")
+_HIP_GEMM = _GEMM_MODE != "lib"
+_HIP_GEMM_FASTER = {(1536, 768)}            # (N, K) of aum_gemm_tn calls that measured faster than the library's solution
+
+
+def _hip_gemm_ok(a, n, k):
+    return (_HIP_GEMM and a.is_cuda and a.dtype in (torch.bfloat16, torch.float16) and n % aum_hip.GEMM_BN == 0 and k % aum_hip.GEMM_BK == 0
+            and (_GEMM_MODE == "hip" or (n, k) in _HIP_GEMM_FASTER))
+
+
+def _gemm_rows(a, w_nk, bit):
+    """a [ntok, K] @ w_nk [N, K]^T -> [ntok, N]"""
+    if _hip_gemm_ok(a, w_nk.shape[0], w_nk.shape[1]) and aum_hip.gemm_tn_supported(a, w_nk):
+        return aum_hip.gemm_tn(a, w_nk)
+    return _mm_rows(a, w_nk.t(), bit)
+
+
+def _weight_t_for_dgrad(w_param, w_cast, a_is_cuda):
+    """the (K, N) -> (N, K) transposed 16-bit copy of a projection weight for the data-gradient GEMM on the MFMA kernel (from the step
+    cache when a model filled it), or None when that GEMM stays with the library (which takes the weight as stored)"""
+    n, k = w_cast.shape[1], w_cast.shape[0]          # the data gradient multiplies by w (k = out features, n = in features)
+    if not (_HIP_GEMM and a_is_cuda and w_cast.dtype in (torch.bfloat16, torch.float16) and n % aum_hip.GEMM_BN == 0 and k % aum_hip.GEMM_BK == 0
+            and (_GEMM_MODE == "hip" or (n, k) in _HIP_GEMM_FASTER)):
+        return None
+    return _cast_t(w_param, w_cast.dtype)
+
+
+def _gemm_dgrad(g, w_cast, w_t, bit):
+    """g [ntok, K] @ w_cast [K, N] -> [ntok, N]; w_t = w_cast^T contiguous or None"""
+    if w_t is not None and aum_hip.gemm_tn_supported(g, w_t):
+        return aum_hip.gemm_tn(g, w_t)
+    return _mm_rows(g, w_cast, bit)
+
+
 class InProjTmFn(torch.autograd.Function):
     """xz2d [B*L, 2E] = hidden2d [B*L, D] @ W^T: the token-major form of InProjFn (MS:185-189 without the BLH -> HBL transpose: the
     token-major kernels read the rows as they are)."""
@@ -324,15 +384,16 @@ class InProjTmFn(torch.autograd.Function):
     def forward(ctx, weight, hidden2d):
         w = _cast(weight, _autocast_dtype())
         h = hidden2d.to(w.dtype)
-        ctx.save_for_backward(w, h)
+        w_t = _weight_t_for_dgrad(weight, w, h.is_cuda) if ctx.needs_input_grad[1] else None
+        ctx.save_for_backward(w, h, w_t)
         ctx.wdtype, ctx.hdtype = weight.dtype, hidden2d.dtype
-        return _mm_rows(h, w.t(), 1)
+        return _gemm_rows(h, w, 1)
 
     @staticmethod
     def backward(ctx, dxz2d):
-        w, h = ctx.saved_tensors
+        w, h, w_t = ctx.saved_tensors
         dxz2d = dxz2d.to(w.dtype)
-        dh = _mm_rows(dxz2d, w, 8) if ctx.needs_input_grad[1] else None
+        dh = _gemm_dgrad(dxz2d, w, w_t, 8) if ctx.needs_input_grad[1] else None
         dw = split_k_wgrad(dxz2d.t(), h, _pick_splits(h.shape[0], _WGRAD_SPLITS[0]), ctx.wdtype) if ctx.needs_input_grad[0] else None
         return dw, (None if dh is None else dh.to(ctx.hdtype))
 
@@ -348,7 +409,7 @@ def token_major_ok(d_inner, d_state, d_conv, dt_rank, dtype=None):
 # The time-serial kernels give one wave to 64 channels of one batch entry and direction and walk the WHOLE sequence with it: they need
 # batch * (d_inner / 64) * directions waves to fill 256 CUs x 4 SIMDs x 2-3 waves.  Short of that (long-form clips at batch 8,
 # single-clip inference) the chunk-parallel channel-major kernels are the better division.  AUM_TM_MIN_WAVES overrides the threshold.
-_TM_MIN_WAVES = int(os.environ.get("AUM_TM_MIN_WAVES", "1536"))
+_TM_MIN_WAVES = int(_dbg_env("AUM_TM_MIN_WAVES", "1536"))
 
 
 def token_major_preferred(batch, d_inner, bidirectional):
@@ -368,7 +429,11 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
     act = _autocast_dtype()
     ctx.out_proj_wdtype = out_proj_weight.dtype if out_proj_weight is not None else None
     x_proj_weight, delta_proj_weight = _cast(x_proj_weight, act), _cast(delta_proj_weight, act)
+    out_proj_param = out_proj_weight
     out_proj_weight, out_proj_bias = _cast(out_proj_weight, act), _cast(out_proj_bias, act)
+    out_proj_wt = None
+    if out_proj_weight is not None and any(ctx.needs_input_grad):
+        out_proj_wt = _weight_t_for_dgrad(out_proj_param, out_proj_weight.to(xz.dtype), xz.is_cuda)
     xz_t = xz.transpose(1, 2)                                      # (B, L, 2E), rows contiguous
     Bsz, L, two_e = xz_t.shape
     E = two_e // 2
@@ -391,10 +456,10 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
     ctx.has_out_proj = out_proj_weight is not None
     ctx.out_proj_bias_is_None = out_proj_bias is None
     ctx.save_for_backward(xz, conv_w, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, A_b, D,
-                          delta_bias, out_pre, out_z, ckpt)
+                          delta_bias, out_pre, out_z, ckpt, out_proj_wt)
     if out_proj_weight is None:
         return out_z.transpose(1, 2)                                                         # SSI:224  (B, E, L) logical
-    out = _mm_rows(out_z.view(Bsz * L, E), out_proj_weight.t(), 2)                           # SSI:517
+    out = _gemm_rows(out_z.view(Bsz * L, E), out_proj_weight.to(out_z.dtype), 2)             # SSI:517
     if out_proj_bias is not None:
         out = out + out_proj_bias
     return out.reshape(Bsz, L, -1)
@@ -402,7 +467,7 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
 
 def _inner_backward_tm(ctx, dout):
     (xz, conv_w, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, A_b, D, delta_bias, out_pre,
-     out_z, ckpt) = ctx.saved_tensors
+     out_z, ckpt, out_proj_wt) = ctx.saved_tensors
     xz_t = xz.transpose(1, 2)
     Bsz, L, two_e = xz_t.shape
     E = two_e // 2
@@ -414,7 +479,7 @@ def _inner_backward_tm(ctx, dout):
     dout_proj_weight = dout_proj_bias = None
     if ctx.has_out_proj:
         dout2 = dout.reshape(Bsz * L, -1).to(out_proj_weight.dtype)
-        dout_z = _mm_rows(dout2, out_proj_weight, 4).view(Bsz, L, E)                          # SSI:540
+        dout_z = _gemm_dgrad(dout2, out_proj_weight, out_proj_wt, 4).view(Bsz, L, E)         # SSI:540
         dout_proj_weight = split_k_wgrad(dout2.t(), out_z.view(Bsz * L, E), _pick_splits(dout2.shape[0], _WGRAD_SPLITS[1]),
                                          ctx.out_proj_wdtype)                                 # SSI:563
         dout_proj_bias = dout2.sum(0) if not ctx.out_proj_bias_is_None else None

@@ -41,23 +41,37 @@ def pmc_record(kind, kernel):
 
 
 def gemm_probe(dev, ntok, d_model, d_inner, iters=20):
-    """the largest library GEMM of the step, in_proj forward [ntok, d_model] x [d_model, 2 d_inner] in bf16, timed on the spot
-    (HIP events on the current stream) against the dense MFMA peak"""
+    """the largest GEMM of the step, in_proj forward [ntok, d_model] x [d_model, 2 d_inner] in bf16, timed on the spot (HIP events on
+    the current stream) against the dense MFMA peak: the kernel the step runs (aum_gemm_tn, hand-written MFMA; the library GEMM under
+    default dispatch for this shape) and, next to it, the library GEMM it replaced"""
+    import aum_hip
+    import mamba_ssm.ops.selective_scan_interface as ssi
     a = torch.randn(ntok, d_model, device=dev).bfloat16()
     w = torch.randn(2 * d_inner, d_model, device=dev).bfloat16()
-    for _ in range(3):
-        torch.matmul(a, w.t())
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        torch.matmul(a, w.t())
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    tf = 2.0 * ntok * d_model * 2 * d_inner / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": f"in_proj forward GEMM [{ntok}x{d_model}] x [{d_model}x{2 * d_inner}] bf16 (hipBLASLt via TunableOp)",
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    flop = 2.0 * ntok * d_model * 2 * d_inner
+    ms_lib = timed(lambda: torch.matmul(a, w.t()))
+    use_hip = ssi._hip_gemm_ok(a, w.shape[0], w.shape[1]) and aum_hip.gemm_tn_supported(a, w)
+    ms = timed(lambda: aum_hip.gemm_tn(a, w)) if use_hip else ms_lib
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"bound": "mfma",
+            "kernel": f"in_proj forward GEMM [{ntok}x{d_model}] x [{d_model}x{2 * d_inner}] bf16 ("
+                      + ("aum_gemm_tn, hand-written MFMA kernel" if use_hip else "hipBLASLt via TunableOp") + ")",
             "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-            "avg_launch_ms": round(ms, 4)}
+            "avg_launch_ms": round(ms, 4),
+            "library_gemm": {"avg_launch_ms": round(ms_lib, 4), "achieved": round(flop / (ms_lib * 1e-3) / 1e12, 1),
+                             "kernel": "hipBLASLt via TunableOp, same operands"}}
 
 
 def scan_alg_bytes(meta, backward):

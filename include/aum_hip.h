@@ -62,7 +62,12 @@ enum {
 #define AUM_CONV_SILU 1u
 #define AUM_CONV_REVERSE 2u  /* anti-causal: y[l] = act(b + sum_w W[w] x[l+(W-1)-w])                            */
 #define AUM_CONV_GENERIC 4u  /* force the any-width kernel (default: the vectorised width-4 kernel when width == 4)  */
-#define AUM_GEMM_LOCKSTEP 1u /* debug / A-B: the one-barrier-per-K-step schedule (all waves in lockstep) instead of the staggered one */
+/* aum_gemm_tn picks its kernel by tile count (persistent when a CU gets more than two tiles, else one workgroup per tile); these force one: */
+#define AUM_GEMM_LOCKSTEP 1u   /* one workgroup per 256 x 256 tile, all waves in lockstep */
+#define AUM_GEMM_STAGGERED 2u  /* debug / A-B: one workgroup per tile, the two waves of a SIMD half a K-step apart (measured slower) */
+#define AUM_GEMM_PERSISTENT 4u /* one workgroup per CU walking a tile list; a ragged last row block of <= 128 rows as half tiles */
+#define AUM_GEMM_NO_COUNTED_WAIT 8u /* debug / A-B (persistent): a tile's first wait also drains the previous tile's stores */
+#define AUM_GEMM_NO_PREFETCH 16u    /* debug / A-B (persistent): a tile's first K-step is fetched at its head, not under the previous tile's last step */
 #define AUM_NORM_PRENORM 1u  /* also return residual_out                                                        */
 #define AUM_NORM_GENERIC 2u  /* force the any-cols kernel (default: register-cached vector kernel, cols <= 2048)  */
 

@@ -323,7 +323,12 @@ GEMM_CASES = [
     ("m513_n768_k768", 513, 768, 768, 0, 0),
     ("m700_n256_k1536_pitch", 700, 256, 1536, 64, 256),
     ("m300_n1536_k3072", 300, 1536, 3072, 0, 0),
+    # the persistent kernel's item list: a 128-row remainder exactly, 129 rows (full item with rows out of range), 64 rows behind full blocks
+    ("m384_k128", 384, 256, 128, 0, 0),
+    ("m385_n512_k128", 385, 512, 128, 0, 0),
+    ("m576_n512_k192", 576, 512, 192, 0, 0),
 ]
+# (the GPU-only sizes below also cover more items than CUs: several tiles per workgroup, odd and even step counts)
 # on the GPU only (the host build's triple loop would take minutes): the bench's own GEMMs, (m, n, k) of in_proj / out_proj forward and
 # data gradient at 64 x 513 tokens and at 3 x 513 tokens
-GEMM_FULL_CASES = [(64 * 513, 3072, 768), (64 * 513, 768, 1536), (64 * 513, 1536, 768), (64 * 513, 768, 3072), (3 * 513, 3072, 768)]
+GEMM_FULL_CASES = [(70000, 512, 192), (64 * 513, 3072, 768), (64 * 513, 768, 1536), (64 * 513, 1536, 768), (64 * 513, 768, 3072), (3 * 513, 3072, 768)]

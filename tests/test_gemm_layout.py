@@ -14,7 +14,7 @@ def f_a(r):
 
 
 def f_b(r):
-    return (((r >> 4) & 3) << 1) | ((r >> 1) & 1)
+    return (((r >> 3) & 3) << 1) | ((r >> 1) & 1)
 
 
 def stage_images(A, B):
@@ -25,7 +25,7 @@ def stage_images(A, B):
             for lane in range(64):
                 r, s = (j * 8 + w) * 8 + (lane >> 3), lane & 7
                 fa = ((w & 1) * 4 + (lane >> 4)) & 7                         # the kernel's per-lane constants (independent of j)
-                fb = (((w >> 1) & 3) << 1) | ((lane >> 4) & 1)
+                fb = ((w & 3) << 1) | ((lane >> 4) & 1)
                 assert fa == f_a(r) and fb == f_b(r)
                 lds_a[r, s] = A[r, (s ^ fa) * 8:(s ^ fa) * 8 + 8]
                 lds_b[r, s] = B[r, (s ^ fb) * 8:(s ^ fb) * 8 + 8]
@@ -52,7 +52,7 @@ def test_tile_product_and_bank_slots():
                         row = wr * 128 + i * 16 + rho
                         af[i, lane], addr_a[i, lane] = lds_a[row, xa], row * 128 + xa * 16
                     for j in range(4):
-                        row = wc * 64 + (rho >> 2) * 16 + j * 4 + (rho & 3)
+                        row = wc * 64 + (rho >> 2) * 8 + (j >> 1) * 32 + (j & 1) * 4 + (rho & 3)
                         bf[j, lane], addr_b[j, lane] = lds_b[row, xb], row * 128 + xb * 16
                 for grp in GROUPS:
                     for addrs in list(addr_a) + list(addr_b):
@@ -70,7 +70,7 @@ def test_tile_product_and_bank_slots():
                 for lane in range(64):
                     m = wr * 128 + i * 16 + (lane & 15)
                     for j in range(4):
-                        n = wc * 64 + (lane >> 4) * 16 + j * 4
+                        n = wc * 64 + (j >> 1) * 32 + (lane >> 4) * 8 + (j & 1) * 4
                         C[m, n:n + 4] = acc[i, j, lane]
     assert np.array_equal(C, A @ B.T)
 

@@ -418,9 +418,9 @@ def test_conv_tm_headline_shape(lib):
 
 @pytest.mark.parametrize("case", cases.GEMM_CASES, ids=lambda c: c[0])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("sched", ["staggered", "lockstep"])
+@pytest.mark.parametrize("sched", ["auto", "persistent", "lockstep", "staggered"])
 def test_gemm_tn(lib, case, dtype, sched):
-    KC.check_gemm(lib, "cuda", case, dtype, flags=aum_hip.GEMM_LOCKSTEP if sched == "lockstep" else 0)
+    KC.check_gemm(lib, "cuda", case, dtype, flags={"auto": 0, "persistent": aum_hip.GEMM_PERSISTENT, "lockstep": aum_hip.GEMM_LOCKSTEP, "staggered": aum_hip.GEMM_STAGGERED}[sched])
 
 
 def test_gemm_tn_argument_rules(lib):
@@ -441,4 +441,33 @@ def test_gemm_tn_full_size(lib, shape):
     assert (out[rows].double() - ref).abs().max().item() <= 1.01 * 2.0 ** -8 * ref.abs().max().item()
     for _ in range(3):
         assert torch.equal(out, aum_hip.gemm_tn(a, b, lib=lib))
-    assert torch.equal(out, aum_hip.gemm_tn(a, b, lib=lib, flags=aum_hip.GEMM_LOCKSTEP))       # both schedules: the same sums in the same order
+    for fl in (aum_hip.GEMM_LOCKSTEP, aum_hip.GEMM_STAGGERED, aum_hip.GEMM_PERSISTENT):                               # every schedule: the same sums in the same order
+        assert torch.equal(out, aum_hip.gemm_tn(a, b, lib=lib, flags=fl))
+
+
+def test_norm_headline_shape(lib):
+    """the block's fused add + RMSNorm at the bench's own launch: 64 x 513 = 32 832 rows of d_model 768, 16-bit branch output on an fp32
+    residual stream (prenorm, LN:254-277): sampled rows against the oracle, dweight (the sum over ALL rows) against an fp64 torch
+    statement of the same sum, bitwise repeatable (fixed-order partial sums)"""
+    O = KC.O
+    torch.manual_seed(2)
+    rows, cols = 64 * 513, 768
+    x = torch.randn(rows, cols, device="cuda").bfloat16()
+    res = 2.0 * torch.randn(rows, cols, device="cuda")
+    w = 1.0 + 0.2 * torch.randn(cols, device="cuda")
+    dy = torch.randn(rows, cols, device="cuda").bfloat16()
+    dres = torch.randn(rows, cols, device="cuda")
+    y, rstd, res_out = aum_hip.rmsnorm_fwd(x, w, res, 1e-5, residual_dtype=torch.float32, lib=lib)
+    dx, dw, dres_in = aum_hip.rmsnorm_bwd(dy, res_out, w, rstd, dres, True, x_dtype=torch.bfloat16, lib=lib)
+    dx2, dw2, dres_in2 = aum_hip.rmsnorm_bwd(dy, res_out, w, rstd, dres, True, x_dtype=torch.bfloat16, lib=lib)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(dres_in, dres_in2)
+    pick = torch.cat([torch.arange(0, 40), torch.randint(0, rows, (200,)), torch.arange(rows - 40, rows)]).cuda()
+    n = lambda t: t[pick].float().cpu().numpy()
+    r = O.rmsnorm_fwd(n(x), w.cpu().numpy(), None, n(res), 1e-5, "f64")
+    assert KC.rel_err(n(y), r["y"]) < KC.TOL_BF16 and KC.rel_err(n(res_out), r["residual_out"]) < 1e-6
+    assert KC.rel_err(rstd[pick].cpu().numpy(), r["rstd"]) < 1e-5
+    rb = O.rmsnorm_bwd(n(dy), n(res_out), w.cpu().numpy(), rstd[pick].cpu().numpy(), n(dres), False, "f64")
+    assert KC.rel_err(n(dres_in), rb["dx"]) < 1e-5                      # the fp32 gradient of the residual stream
+    assert KC.rel_err(n(dx), rb["dx"]) < 4 * KC.TOL_BF16                # the same values rounded for the 16-bit branch
+    xhat = res_out.double() * rstd.double()[:, None]
+    assert KC.rel_err(dw.cpu().numpy(), (dy.double() * xhat).sum(0).cpu().numpy()) < 1e-4
