@@ -336,15 +336,16 @@ def _mm_rows(a, b, bit):
 # The K-contiguous projection GEMMs of the token-major block -- in_proj / out_proj forward, and their data gradients against the cached
 # transposed weight -- can run on the hand-written MFMA kernel (aum_hip.gemm_tn, csrc/gemm_kernels.h) whenever the operands qualify
 # (16-bit, device, widths that are multiples of 256 / 64).  Measured on MI355X at the bench shape (profiles/r03_gemm_probe.txt,
-# r03_gemm_step_ab.txt) it beats the tuned library GEMM on the out_proj data gradient (N = 1536, K = 768: 84.6 vs 91.4 us) and loses 8-20 %
-# on the other three (tile quantisation at N = 768, the synchronized store bursts of DESIGN 4.8): the default ("auto") sends a GEMM to the
-# kernel only for the (N, K) it measured faster on; AUM_DEBUG=1 AUM_GEMM=hip sends all four, AUM_GEMM=lib none (A/B runs).  The weight
-# gradients (token-contiguous operands) and everything that does not qualify stay library GEMMs.
+# r03_gemm_step_ab.txt) it beats the tuned library GEMM on the out_proj data gradient in isolation (N = 1536, K = 768: 83.7 vs 89.2 us; level
+# inside the step: 96 vs 93 us) and loses 8-20 % on the other three (tile quantisation at N = 768, the synchronized store bursts of DESIGN
+# 4.8): the default ("auto") sends a GEMM to the kernel only for that (N, K) -- the step pays 0.4 % for it (68.1 vs 67.8 ms) and keeps the
+# kernel in the product path; AUM_DEBUG=1 AUM_GEMM=hip sends all four (70.1 ms), AUM_GEMM=lib none (A/B runs).  The weight gradients
+# (token-contiguous operands) and everything that does not qualify stay library GEMMs.
 _GEMM_MODE = _dbg_env("AUM_GEMM", "auto")
 if _GEMM_MODE not in ("auto", "hip", "lib"):
     raise ValueError("AUM_GEMM takes auto, hip or lib")
 _HIP_GEMM = _GEMM_MODE != "lib"
-_HIP_GEMM_FASTER = {(1536, 768)}            # (N, K) of aum_gemm_tn calls that measured faster than the library's solution
+_HIP_GEMM_FASTER = {(1536, 768)}            # (N, K) of aum_gemm_tn calls that measured at least level with the library's solution
 
 
 def _hip_gemm_ok(a, n, k):
