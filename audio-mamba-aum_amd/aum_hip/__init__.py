@@ -139,7 +139,7 @@ class GemmArgs(C.Structure):
 EXPORTS = ["aum_gemm_tn", "aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows",
-           "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_selftest_wave_sum32",
+           "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_ckpt_rows", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_selftest_wave_sum32",
            "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts"]
 
 
@@ -163,6 +163,7 @@ class Lib:
         self.c.aum_scan_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_scan_tm_bwd.argtypes = [_vp, _vp]
         self.c.aum_scan_tm_nck.argtypes = [_i32]
+        self.c.aum_scan_tm_ckpt_rows.argtypes = [_i32]
         self.c.aum_conv1d_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_conv1d_tm_bwd.argtypes = [_vp, _vp]
         self.c.aum_conv1d_tm_nparts.argtypes = [_i32, _i32]
@@ -469,11 +470,13 @@ def _tm3(t, name, last):
     return bs, ts
 
 
-def scan_tm_ckpt(batch, length, dim, dstate, bidir, device, lib=None):
-    """empty state checkpoint (directions, batch, nck, dstate, dim) fp32 for scan_tm_fwd to fill and scan_tm_bwd to read"""
+def scan_tm_ckpt(batch, length, dim, dstate, bidir, device, lib=None, dtype=torch.float32):
+    """empty state checkpoint (directions, batch, nck, rows, dim) dwords for scan_tm_fwd to fill and scan_tm_bwd to read; dtype = the
+    activations' dtype: fp32 states (rows = dstate) for fp32, pairs of states in the activations' own type (rows = dstate / 2) for 16-bit activations"""
     lib = lib or get()
     nck = int(lib.c.aum_scan_tm_nck(length))
-    return torch.empty((2 if bidir else 1, batch, max(nck, 1), dstate, dim), dtype=torch.float32, device=device)
+    rows = int(lib.c.aum_scan_tm_ckpt_rows(_DT[dtype])) if dstate == 16 else dstate
+    return torch.empty((2 if bidir else 1, batch, max(nck, 1), rows, dim), dtype=torch.float32, device=device)
 
 
 def scan_tm_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, reverse=False, A_b=None,
@@ -509,7 +512,8 @@ def scan_tm_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softpl
     a.out, a.out_pre = _ptr(out), _ptr(out_pre)
     if ckpt is not None:
         assert ckpt.dtype == torch.float32 and ckpt.is_contiguous()
-        assert ckpt.shape == (2 if A_b is not None else 1, batch, max(int(lib.c.aum_scan_tm_nck(length)), 1), dstate, dim)
+        rows = int(lib.c.aum_scan_tm_ckpt_rows(_DT[u.dtype])) if dstate == 16 else dstate
+        assert ckpt.numel() >= (2 if A_b is not None else 1) * batch * max(int(lib.c.aum_scan_tm_nck(length)), 1) * rows * dim, "ckpt too small"
         lib.check_tensor(ckpt)
         a.ckpt = _ptr(ckpt)
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]

@@ -34,6 +34,15 @@ constexpr int SCANT_CK = AUM_SCAN_TM_CK;       // steps per checkpoint block
 constexpr int SCANT_G = SCANT_CK / 2;          // steps per prefetch group (two groups in flight, ping-pong)
 AUM_HOSTDEV constexpr int scant_nblocks(int len) { return (len + SCANT_CK - 1) / SCANT_CK; }
 AUM_HOSTDEV constexpr int scant_nck(int len) { return scant_nblocks(len) - 1; }        // the last block's exit state is never needed
+// Rows of one checkpoint (dwords per channel).  fp32 activations: the 16 states as they are.  16-bit activations: 8 rows of PAIRS in the
+// activations' own type (states 2j, 2j+1 in one dword) -- the training forward writes 0.8 GB of checkpoints per launch at the bench shape and was HBM-bound on it
+// (1.83 GB in 0.39 ms = 4.7 TB/s); rounding the entry state of an 8-step block to the precision its inputs already have halves that
+// traffic on both sides.  The backward walks the states in pairs, so a pass fetches exactly one row.
+#ifdef AUM_SCANT_CK_F32      // A/B builds only (tools/build_variant.sh): fp32 checkpoints for every dtype, the layout before the packed form
+template <class T> AUM_HOSTDEV constexpr int scant_ck_rows() { return SCANT_N; }
+#else
+template <class T> AUM_HOSTDEV constexpr int scant_ck_rows() { return sizeof(T) == 2 ? SCANT_N / 2 : SCANT_N; }
+#endif
 AUM_HOSTDEV bool scant_supported(int dim, int dstate) { return dstate == SCANT_N && dim % WAVE == 0; }
 
 // ------------------------------------------------------------------------------------------------
@@ -96,7 +105,8 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
     const gbuf<T> Cbuf = make_gbuf(row_ptr<T>(p.C, (int64_t)b * p.C_bs));
     const int nck = scant_nck(L);
     const bool want_ck = p.ckpt != nullptr;
-    const gbuf<float> ckbuf = make_gbuf(want_ck ? p.ckpt + ((int64_t)dir * p.batch + b) * nck * N * p.dim : (const float*)Aptr);
+    constexpr int CKR = scant_ck_rows<T>();
+    const gbuf<float> ckbuf = make_gbuf(want_ck ? p.ckpt + ((int64_t)dir * p.batch + b) * nck * CKR * p.dim : (const float*)Aptr);
     // byte strides per step of time
     const int u_tb = (int)p.u_ts * ES, d_tb = (int)p.delta_ts * ES, z_tb = HAS_Z ? (int)p.z_ts * ES : 0, o_tb = (int)p.out_ts * ES,
               p_tb = HAS_PRE ? (int)p.pre_ts * ES : 0, B_tb = (int)p.B_ts * ES, C_tb = (int)p.C_ts * ES;
@@ -290,11 +300,19 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
         else x[0] = x[0] + spl2(tot * 1e-30f);
     };
     auto ckpt_store = [&](int blk) {
-        int off = blk * N * p.dim * 4;
-        AUM_UNROLL
-        for (int n = 0; n < N; ++n) {
-            gbuf_store(ckbuf, vo4, off, (n & 1) ? hi2(x[n >> 1]) : lo2(x[n >> 1]));
-            off += p.dim * 4;
+        int off = blk * CKR * p.dim * 4;
+        if constexpr (CKR == N) {
+            AUM_UNROLL
+            for (int n = 0; n < N; ++n) {
+                gbuf_store(ckbuf, vo4, off, (n & 1) ? hi2(x[n >> 1]) : lo2(x[n >> 1]));
+                off += p.dim * 4;
+            }
+        } else {
+            AUM_UNROLL
+            for (int j = 0; j < N / 2; ++j) {
+                gbuf_store_pair16<T>(ckbuf, vo4, off, lo2(x[j]), hi2(x[j]));
+                off += p.dim * 4;
+            }
         }
     };
 
@@ -489,7 +507,9 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     const gbuf<T> Cbuf = make_gbuf(row_ptr<T>(p.C, (int64_t)b * p.C_bs));
     const gbuf<float> Abuf = make_gbuf(Aptr);
     const int nck = scant_nck(L);
-    const gbuf<float> ckbuf = make_gbuf(p.ckpt + ((int64_t)dir * p.batch + b) * (nck > 0 ? nck : 1) * N * p.dim);
+    constexpr int CKR = scant_ck_rows<T>();        // rows of a checkpoint: the 16 states (fp32 activations) or 8 bf16 pairs (16-bit activations)
+    constexpr int RPP = CKR / (N / 2);             // rows a pass over one state pair consumes
+    const gbuf<float> ckbuf = make_gbuf(p.ckpt + ((int64_t)dir * p.batch + b) * (nck > 0 ? nck : 1) * CKR * p.dim);
     const gbuf<float> dbcbuf = make_gbuf(wo.dbc + (int64_t)b * L * wo.nparts * (2 * N));
     const int u_tb = (int)p.u_ts * ES, d_tb = (int)p.delta_ts * ES, z_tb = HAS_Z ? (int)p.z_ts * ES : 0, g_tb = (int)p.dout_ts * ES,
               y_tb = HAS_Z ? (int)p.pre_ts * ES : 0, du_tb = (int)p.du_ts * ES, dd_tb = (int)p.ddelta_ts * ES,
@@ -508,7 +528,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     float* t_bc = lds + 8 * TL::FLOATS;
     float* t_dbc = t_bc + SCANT_BC_BLOCK;
     float* t_u1 = t_dbc + SCANT_BC_BLOCK;
-    float* t_ck = t_u1 + TL::FLOATS;               // entry state of the block: row n = state n, one float per lane
+    float* t_ck = t_u1 + TL::FLOATS;               // entry state of the block: row n = state n, one float per lane (16-bit activations: row j = the bf16 pair of states 2j, 2j+1)
     float* t_A = t_ck + N * WAVE;                  // A[e][n] likewise
     float* t_rawB = t_A + N * WAVE;                // the next block's B / C pairs as loaded (NLD dwords per lane and tensor)
     float* t_rawC = t_rawB + NLD * WAVE;
@@ -576,7 +596,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     auto request_entry = [&](int blk, int n0, int n1) {
         if (AUM_SCANT_BABL & 16) return;
         for (int n = n0; n < n1; ++n) {
-            if (blk > 0) gbuf_load4_lds(ckbuf, vo4, ((blk - 1) * N + n) * p.dim * 4, t_ck + n * WAVE);
+            if (blk > 0) gbuf_load4_lds(ckbuf, vo4, ((blk - 1) * CKR + n) * p.dim * 4, t_ck + n * WAVE);
             else lds_write(t_ck, lane + n * WAVE, splat(0.f));
         }
     };
@@ -600,7 +620,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     // prologue of the phase: everything the first block needs, and A
     wave_lds_fence();
     request_block(blk_hi - 1, rows_of(blk_hi - 1));
-    request_entry(blk_hi - 1, 0, N);
+    request_entry(blk_hi - 1, 0, CKR);
     for (int n = 0; n < N; ++n) gbuf_load4_lds(Abuf, ec * (N * 4), n * 4, t_A + n * WAVE);
     // Memory operations complete in issue order, and s_waitcnt vmcnt(n) returns once at most n are in flight: every wait below names
     // exactly the operations YOUNGER than the data it needs.  Issue order around a block:
@@ -621,7 +641,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
         // the block's tensors (requested in the previous block's first lines) are older than that block's partials, the entry rows
         // its passes requested and its stores
         if (blk == blk_hi - 1) AUM_WAIT_VM(0);
-        else if (blk > 0) AUM_WAIT_VM(PART + 16 + NST);
+        else if (blk > 0) AUM_WAIT_VM(PART + CKR + NST);
         else AUM_WAIT_VM(PART + NST);
         wave_lds_fence();
         AUM_TMB_STAMP(9);
@@ -691,16 +711,23 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             // B and C of the pass's state pair for all eight steps, the pair's entry state and A, requested before anything else: the
             // exponentials cover their latency (read step by step inside the sweeps, every read was waited for on the spot:
             // twelve LDS round trips per pass in a chain that two waves per SIMD cannot hide)
-            // this pass's entry rows: younger are the later rows (14 - 2j), the previous block's stores, this block's requests and the 2j
-            // rows of the next block requested so far -- a constant; fewer were issued near the ends of a phase
+            // this pass's entry rows: younger are the later rows (CKR - RPP (j + 1)), the previous block's stores, this block's requests and
+            // the RPP j rows of the next block requested so far -- a constant; fewer were issued near the ends of a phase
             if (blk != blk_hi - 1) {
-                if (more && cknext) AUM_WAIT_VM(14 + NST + RBN + PART);
+                if (more && cknext) AUM_WAIT_VM((CKR - RPP) + NST + RBN + PART);
                 else if (more) AUM_WAIT_VM(NST + RBN + PART);
                 else AUM_WAIT_VM(NST + PART);
             }
             // (the LDS answers in order: A first, the exponentials wait for nothing else)
             const vf2 Aj = mk2(lds_read(t_A, lane + (2 * j) * WAVE), lds_read(t_A, lane + (2 * j + 1) * WAVE));
-            vf2 x = mk2(lds_read(t_ck, lane + (2 * j) * WAVE), lds_read(t_ck, lane + (2 * j + 1) * WAVE));
+            vf2 x;
+            if constexpr (RPP == 2) {
+                x = mk2(lds_read(t_ck, lane + (2 * j) * WAVE), lds_read(t_ck, lane + (2 * j + 1) * WAVE));
+            } else {
+                vf x_lo, x_hi;
+                lds_pair_to_f32<T>(t_ck + j * WAVE, x_lo, x_hi);
+                x = mk2(x_lo, x_hi);
+            }
             vf qb[SCANT_CK][2], qc[SCANT_CK][2];
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) {
@@ -745,7 +772,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                 }
             }
             // the entry rows this pass consumed make room for the next block's
-            if (cknext) request_entry(blk - 1, 2 * j, 2 * j + 2);
+            if (cknext) request_entry(blk - 1, RPP * j, RPP * j + RPP);
             AUM_SCHED_FENCE();
             AUM_TMB_STAMP(3);
             const vf dCsum = (AUM_SCANT_BABL & 1) ? pc[0] + pc[5] : wave_sum16(pc);
@@ -784,11 +811,11 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             AUM_TMB_STAMP(6);
         }
         // ---- the block's du, ddelta; partials / finish ----------------------------------------------------------
-        // this block's partial du / ddelta are back (younger: the sixteen entry rows requested during the passes)
-        if (cknext) AUM_WAIT_VM(16);
+        // this block's partial du / ddelta are back (younger: the CKR entry rows requested during the passes)
+        if (cknext) AUM_WAIT_VM(CKR);
         else AUM_WAIT_VM(0);
         wave_lds_fence();
-        if (more && !cknext) request_entry(0, 0, N);        // the first block starts from zero
+        if (more && !cknext) request_entry(0, 0, CKR);        // the first block starts from zero
         vi rus[SCANT_CK], rpu[SCANT_CK], rpd[SCANT_CK];
         AUM_UNROLL
         for (int s = 0; s < SCANT_CK; ++s) {

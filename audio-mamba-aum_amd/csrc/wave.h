@@ -321,6 +321,12 @@ template <class T> AUM_DEV vf raw_to_f32(vi raw) {
         return elem_to_f32(e);
     }
 }
+// two fp32 values as one dword of two 16-bit elements of T (round to nearest even; lo in the low half): the packed state checkpoint of the
+// token-major scan, read back with lds_pair_to_f32<T>
+template <class T> AUM_DEV void gbuf_store_pair16(const gbuf<float>& b, vi voff_bytes, int soff_bytes, vf lo, vf hi) {
+    static_assert(sizeof(T) == 2, "16-bit element types");
+    __builtin_amdgcn_raw_buffer_store_b32(f32x2_to_elem2<T>(lo, hi), b.r, voff_bytes, soff_bytes, 0);
+}
 template <class T> AUM_DEV void gbuf_store(const gbuf<T>& b, vi voff_bytes, int soff_bytes, vf v) {
     if constexpr (sizeof(T) == 4) {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), b.r, voff_bytes, soff_bytes, 0);
@@ -660,6 +666,15 @@ template <class T> inline vf raw_to_f32(const vi& raw) {
 }
 template <class T> inline void gbuf_store(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes, const vf& v) {
     AUM_LANES f32_to_elem(v.v[l], *(T*)((char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes));
+}
+template <class T> inline void gbuf_store_pair16(const gbuf<float>& b, const vi& voff_bytes, int soff_bytes, const vf& lo, const vf& hi) {
+    static_assert(sizeof(T) == 2, "16-bit element types");
+    AUM_LANES {
+        T e[2];
+        f32_to_elem(lo.v[l], e[0]);
+        f32_to_elem(hi.v[l], e[1]);
+        std::memcpy((char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes, e, 4);
+    }
 }
 struct vpair_raw { vf lo, hi; };
 template <class T> inline vpair_raw gbuf_load_pair_raw(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes) {

@@ -449,7 +449,7 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
     x3 = x_dbl.view(Bsz, L, R + 2 * N)
     Bm, Cm = x3[:, :, R:R + N], x3[:, :, R + N:]                                            # SSI:479  views, no copies
     need_bwd = any(ctx.needs_input_grad)
-    ckpt = aum_hip.scan_tm_ckpt(Bsz, L, E, N, A_b is not None, xz.device) if need_bwd else None
+    ckpt = aum_hip.scan_tm_ckpt(Bsz, L, E, N, A_b is not None, xz.device, dtype=conv_out.dtype) if need_bwd else None
     out_z, out_pre = aum_hip.scan_tm_fwd(conv_out, delta.view(Bsz, L, E), A, Bm, Cm, D, z, delta_bias, delta_softplus,
                                          reverse if A_b is None else False, A_b=A_b, want_out_pre=need_bwd, ckpt=ckpt)
     ctx.tm = True

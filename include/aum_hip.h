@@ -34,7 +34,8 @@ extern "C" {
                                6: aum_sum_rows (fixed-order sum of partial results);
                                7: aum_scan_tm_fwd / _bwd (time-serial selective scan on token-major activations);
                                8: aum_conv1d_tm_fwd / _bwd (the causal conv on token-major activations);
-                               9: aum_gemm_tn (the dense in_proj / out_proj GEMMs on token-major activations) */
+                               9: aum_gemm_tn (the dense in_proj / out_proj GEMMs on token-major activations); aum_scan_tm_ckpt_rows
+                                  (packed 16-bit state checkpoints of the token-major scan for 16-bit activations) */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 
@@ -307,8 +308,11 @@ int aum_proj_bwd_weight_splits(int32_t dim, int64_t ntok);
  * direction waves of a channel group meet in the middle of the sequence and exchange their halves through `out`.
  * AUM_SCAN_REVERSE (A_b == NULL): the recurrence runs from t = len-1 down to 0.
  * ckpt (optional, forward output / backward input): the state entering every AUM_SCAN_TM_CK-step block in scan order,
- *   (directions, batch, nck, dstate, dim) fp32 with nck = aum_scan_tm_nck(len) -- the `x` tensor of selective_scan_cuda.fwd at this
- *   kernel's granularity.  The backward requires it.
+ *   (directions, batch, nck, rows, dim) dwords with nck = aum_scan_tm_nck(len) and rows = aum_scan_tm_ckpt_rows(dtype) -- the `x` tensor
+ *   of selective_scan_cuda.fwd at this kernel's granularity: the dstate states as fp32 for fp32 activations, dstate / 2 rows of PAIRS in the
+ *   activations' own 16-bit type (states 2j, 2j+1 in one dword) for 16-bit activations (ABI 9; the entry state of an 8-step block rounded to the precision of the block's
+ *   own inputs: half the checkpoint traffic of the training forward, which is HBM-bound on it).  A buffer sized for dstate rows is always
+ *   large enough; forward and backward of one call must see the same dtype.  The backward requires it.
  * Limits: dstate == 16, dim % 64 == 0, len * X_ts * sizeof(element) < 2^31 for every tensor; otherwise AUM_E_UNSUPPORTED (callers
  * use aum_selective_scan_*).
  */
@@ -325,6 +329,7 @@ typedef struct AumScanTmFwdArgs {
 } AumScanTmFwdArgs;
 int aum_scan_tm_fwd(const AumScanTmFwdArgs* args, void* stream);
 int32_t aum_scan_tm_nck(int32_t len);
+int32_t aum_scan_tm_ckpt_rows(int32_t dtype);
 
 /*
  * Backward of the above.  du, ddelta, dz in `dtype` (written).  dBC: (batch, len, 2 * dstate) fp32 = dB | dC per token, written
