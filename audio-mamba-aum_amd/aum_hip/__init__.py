@@ -136,7 +136,11 @@ class GemmArgs(C.Structure):
     _fields_ = ([(n, _vp) for n in ("a", "b", "c")] + [(n, _i32) for n in ("m", "n", "k", "lda", "ldb", "ldc", "dtype")] + [("flags", _u32)])
 
 
-EXPORTS = ["aum_gemm_tn", "aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
+class DtProjArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("x", "w", "out")] + [("ntok", _i64)] + [(n, _i32) for n in ("dim", "rank", "ldx", "ldw", "ldo", "dtype")])
+
+
+EXPORTS = ["aum_gemm_tn", "aum_dtproj_tm_fwd", "aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows",
            "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_ckpt_rows", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_selftest_wave_sum32",
@@ -168,6 +172,7 @@ class Lib:
         self.c.aum_conv1d_tm_bwd.argtypes = [_vp, _vp]
         self.c.aum_conv1d_tm_nparts.argtypes = [_i32, _i32]
         self.c.aum_gemm_tn.argtypes = [_vp, _vp]
+        self.c.aum_dtproj_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_scan_tm_workspace_bytes.restype = _i64
         self.c.aum_scan_tm_workspace_bytes.argtypes = [_i32] * 5
         self.c.aum_fbank_fwd.argtypes = [_vp, _vp]
@@ -610,6 +615,30 @@ def gemm_tn(a, b, out=None, lib=None, flags=0):
     g.m, g.n, g.k, g.lda, g.ldb, g.ldc, g.dtype = m, n, k, a.stride(0), b.stride(0), out.stride(0), _DT[a.dtype]
     g.flags = flags
     _launch(lib.c.aum_gemm_tn, g, a, lib, "gemm_tn", (m, n, k))
+    return out
+
+
+def dtproj_tm_supported(x_dbl, rank, w):
+    """shapes aum_dtproj_tm_fwd takes (include/aum_hip.h, ABI 9): 16-bit row-major x_dbl (ntok, >= rank) and dt_proj.weight (dim, rank)"""
+    return (x_dbl.dim() == 2 and w.dim() == 2 and x_dbl.dtype == w.dtype and x_dbl.dtype in (torch.bfloat16, torch.float16)
+            and w.shape[1] == rank and x_dbl.shape[1] >= rank and rank % 8 == 0 and rank <= 64 and w.shape[0] % 32 == 0
+            and x_dbl.stride(1) == 1 and w.stride(1) == 1 and x_dbl.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
+            and x_dbl.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+
+
+def dtproj_tm_fwd(x_dbl, rank, w, lib=None):
+    """delta (ntok, dim) = x_dbl[:, :rank] @ w^T (SSI:468 on token-major rows): w = dt_proj.weight (dim, rank) in x_dbl's 16-bit dtype"""
+    lib = lib or get()
+    lib.check_tensor(x_dbl)
+    lib.check_tensor(w)
+    if not dtproj_tm_supported(x_dbl, rank, w):
+        raise RuntimeError(f"dtproj_tm_fwd: unsupported operands {tuple(x_dbl.shape)} {x_dbl.dtype}, rank {rank}, weight {tuple(w.shape)} {w.dtype}")
+    ntok, dim = x_dbl.shape[0], w.shape[0]
+    out = torch.empty((ntok, dim), dtype=x_dbl.dtype, device=x_dbl.device)
+    a = DtProjArgs()
+    a.x, a.w, a.out = _ptr(x_dbl), _ptr(w), _ptr(out)
+    a.ntok, a.dim, a.rank, a.ldx, a.ldw, a.ldo, a.dtype = ntok, dim, rank, x_dbl.stride(0), w.stride(0), dim, _DT[x_dbl.dtype]
+    _launch(lib.c.aum_dtproj_tm_fwd, a, x_dbl, lib, "dtproj_tm_fwd", (ntok, dim, rank))
     return out
 
 

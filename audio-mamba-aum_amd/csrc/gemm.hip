@@ -1,5 +1,7 @@
-// gemm.hip -- translation unit of the dense projection GEMM (gemm_kernels.h) and its C-ABI entry point aum_gemm_tn (include/aum_hip.h, ABI 9).
+// gemm.hip -- translation unit of the plain-HIP MFMA kernels: the dense projection GEMM (gemm_kernels.h, aum_gemm_tn) and the dt projection of
+// the token-major block (dtproj_kernels.h, aum_dtproj_tm_fwd); include/aum_hip.h, ABI 9.
 #include "gemm_kernels.h"
+#include "dtproj_kernels.h"
 
 extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
     const int rc = aumg::gemm_check(p);
@@ -39,5 +41,20 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
         if (lockstep) hipLaunchKernelGGL((aumg::k_gemm_tn<false, 0>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
         else hipLaunchKernelGGL((aumg::k_gemm_tn<false, 1>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
     }
+    return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
+}
+
+extern "C" int aum_dtproj_tm_fwd(const AumDtProjArgs* p, void* stream) {
+    const int rc = aumd::dtproj_check(p);
+    if (rc != AUM_OK) return rc;
+    const AumDtProjArgs& g = *p;
+    const int64_t nwaves = (g.ntok + aumd::TOK_PER_WAVE - 1) / aumd::TOK_PER_WAVE;
+    const dim3 grid((unsigned)((nwaves + aumd::WAVES - 1) / aumd::WAVES)), block(aumd::WAVES * 64);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool bf = g.dtype == AUM_BF16, one = g.rank <= 32;
+    if (bf && one) hipLaunchKernelGGL((aumd::k_dtproj_tm<true, 1>), grid, block, 0, s, g);
+    else if (bf) hipLaunchKernelGGL((aumd::k_dtproj_tm<true, 2>), grid, block, 0, s, g);
+    else if (one) hipLaunchKernelGGL((aumd::k_dtproj_tm<false, 1>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((aumd::k_dtproj_tm<false, 2>), grid, block, 0, s, g);
     return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
 }

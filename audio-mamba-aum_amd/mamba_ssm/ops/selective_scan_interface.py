@@ -341,6 +341,7 @@ def _mm_rows(a, b, bit):
 # 4.8): the default ("auto") sends a GEMM to the kernel only for that (N, K) -- the step pays 0.4 % for it (68.1 vs 67.8 ms) and keeps the
 # kernel in the product path; AUM_DEBUG=1 AUM_GEMM=hip sends all four (70.1 ms), AUM_GEMM=lib none (A/B runs).  The weight gradients
 # (token-contiguous operands) and everything that does not qualify stay library GEMMs.
+_DTPROJ_HIP = _dbg_env("AUM_DTPROJ_LIB", "0") != "1"        # AUM_DEBUG=1 AUM_DTPROJ_LIB=1: the dt projection back on the library GEMM (A/B)
 _GEMM_MODE = _dbg_env("AUM_GEMM", "auto")
 if _GEMM_MODE not in ("auto", "hip", "lib"):
     raise ValueError("AUM_GEMM takes auto, hip or lib")
@@ -445,7 +446,11 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
     conv_out = aum_hip.conv1d_tm_fwd(x, conv_w, conv1d_bias, True, reverse)                 # SSI:463  (B, L, E)
     conv2d = conv_out.view(Bsz * L, E)
     x_dbl = torch.matmul(conv2d, x_proj_weight.t().to(conv2d.dtype))                        # SSI:467  (BL, R+2N)
-    delta = torch.matmul(x_dbl[:, :R], delta_proj_weight.t().to(x_dbl.dtype))               # SSI:468  (BL, E)
+    w_dt = delta_proj_weight.to(x_dbl.dtype)
+    if _DTPROJ_HIP and x_dbl.is_cuda and aum_hip.dtproj_tm_supported(x_dbl, R, w_dt):
+        delta = aum_hip.dtproj_tm_fwd(x_dbl, R, w_dt)                                        # SSI:468  (BL, E): the write-bound MFMA kernel
+    else:
+        delta = torch.matmul(x_dbl[:, :R], w_dt.t())
     x3 = x_dbl.view(Bsz, L, R + 2 * N)
     Bm, Cm = x3[:, :, R:R + N], x3[:, :, R + N:]                                            # SSI:479  views, no copies
     need_bwd = any(ctx.needs_input_grad)

@@ -34,7 +34,7 @@ extern "C" {
                                6: aum_sum_rows (fixed-order sum of partial results);
                                7: aum_scan_tm_fwd / _bwd (time-serial selective scan on token-major activations);
                                8: aum_conv1d_tm_fwd / _bwd (the causal conv on token-major activations);
-                               9: aum_gemm_tn (the dense in_proj / out_proj GEMMs on token-major activations); aum_scan_tm_ckpt_rows
+                               9: aum_gemm_tn (the dense in_proj / out_proj GEMMs on token-major activations); aum_dtproj_tm_fwd; aum_scan_tm_ckpt_rows
                                   (packed 16-bit state checkpoints of the token-major scan for 16-bit activations) */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
@@ -397,6 +397,24 @@ typedef struct AumGemmArgs {
     uint32_t flags;
 } AumGemmArgs;
 int aum_gemm_tn(const AumGemmArgs* args, void* stream);
+
+/*
+ * dt projection of the token-major block (ABI 9): delta = x_dbl[:, :dt_rank] . dt_proj.weight^T (selective_scan_interface.py:468 without
+ * its transposes; the bias and the softplus stay in the scan, as in the reference).
+ *   x: (ntok, >= rank) rows of pitch ldx, the first `rank` columns are read (x_dbl: the dt block sits in front of B and C);
+ *   w: (dim, rank) rows of pitch ldw (dt_proj.weight as nn.Linear stores it);  out: (ntok, dim) rows of pitch ldo.  Pitches in ELEMENTS, all
+ *   three tensors `dtype` (AUM_BF16 / AUM_F16; else AUM_E_DTYPE); dim % 32 == 0, rank % 8 == 0, rank <= 64, pitches % 8 == 0, 16-byte
+ *   aligned pointers (else AUM_E_UNSUPPORTED: callers use a library GEMM).  fp32 accumulation, one rounding at the store.
+ */
+typedef struct AumDtProjArgs {
+    const void *x, *w;
+    void *out;
+    int64_t ntok;
+    int32_t dim, rank;
+    int32_t ldx, ldw, ldo;
+    int32_t dtype;
+} AumDtProjArgs;
+int aum_dtproj_tm_fwd(const AumDtProjArgs* args, void* stream);
 
 /* Self-tests and calibration (used by tests/ and bench.py; not part of the reference's surface). */
 int aum_abi_version(void);

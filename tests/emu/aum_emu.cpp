@@ -28,3 +28,25 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void*) {
     else run(aum::f16_t{});
     return AUM_OK;
 }
+
+// aum_dtproj_tm_fwd on host pointers: same arrangement as aum_gemm_tn above (argument rules shared, arithmetic as a plain loop).
+#include "../../audio-mamba-aum_amd/csrc/dtproj_args.h"
+extern "C" int aum_dtproj_tm_fwd(const AumDtProjArgs* p, void*) {
+    const int rc = aumd::dtproj_check(p);
+    if (rc != AUM_OK) return rc;
+    auto run = [&](auto tag) {
+        using T = decltype(tag);
+        const T* x = static_cast<const T*>(p->x);
+        const T* w = static_cast<const T*>(p->w);
+        T* o = static_cast<T*>(p->out);
+        for (int64_t t = 0; t < p->ntok; ++t)
+            for (int e = 0; e < p->dim; ++e) {
+                float acc = 0.f;
+                for (int k = 0; k < p->rank; ++k) acc += aum::elem_to_f32(x[t * p->ldx + k]) * aum::elem_to_f32(w[(int64_t)e * p->ldw + k]);
+                aum::f32_to_elem(acc, o[t * p->ldo + e]);
+            }
+    };
+    if (p->dtype == AUM_BF16) run(aum::bf16_t{});
+    else run(aum::f16_t{});
+    return AUM_OK;
+}

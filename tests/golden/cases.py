@@ -332,3 +332,7 @@ GEMM_CASES = [
 # on the GPU only (the host build's triple loop would take minutes): the bench's own GEMMs, (m, n, k) of in_proj / out_proj forward and
 # data gradient at 64 x 513 tokens and at 3 x 513 tokens
 GEMM_FULL_CASES = [(70000, 512, 192), (64 * 513, 3072, 768), (64 * 513, 768, 1536), (64 * 513, 1536, 768), (64 * 513, 768, 3072), (3 * 513, 3072, 768)]
+
+# aum_dtproj_tm_fwd (ABI 9): (ntok, dim, dt_rank, columns of the x_dbl rows).  One K-step (rank <= 32) and two, rank not a multiple of 32,
+# ragged token tiles (32 tokens per wave, 4 waves per workgroup), AuM-Base / Small / a 64-rank row
+DTPROJ_CASES = [(1, 64, 8, 40), (33, 96, 24, 56), (129, 256, 48, 80), (513, 1536, 48, 80), (200, 768, 24, 56), (70, 128, 64, 96), (31, 32, 16, 48)]

@@ -349,3 +349,16 @@ def check_gemm_args(lib, dev):
         with pytest.raises(RuntimeError):
             aum_hip.gemm_tn(a, bad, lib=lib)
     assert not aum_hip.gemm_tn_supported(a.float(), torch.zeros(256, 64, device=dev))
+
+
+def check_dtproj(lib, dev, ntok, dim, rank, ncols, dtype):
+    """aum_dtproj_tm_fwd (ABI 9; SSI:468) against an fp64 product of the same 16-bit operands: x_dbl rows of `ncols` columns whose first
+    `rank` are the dt block (the rest -- B and C -- must not be read into the product)"""
+    g = torch.Generator().manual_seed(ntok * 131 + dim + rank)
+    x = torch.randn(ntok, ncols, generator=g).to(dtype).to(dev)
+    w = (torch.randn(dim, rank, generator=g) / rank ** 0.5).to(dtype).to(dev)
+    out = aum_hip.dtproj_tm_fwd(x, rank, w, lib=lib)
+    ref = x[:, :rank].double().cpu() @ w.double().cpu().t()
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = (out.double().cpu() - ref).abs().max().item()
+    assert out.shape == (ntok, dim) and err <= 1.01 * ulp * ref.abs().max().item() + 1e-30, (ntok, dim, rank, err)

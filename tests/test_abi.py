@@ -57,6 +57,7 @@ def test_struct_layouts_match_header(tmp_path):
                                                      "workspace_bytes", "u_bs", "pre_ts", "du_bs", "dz_ts", "batch", "dtype", "flags"]),
         "AumConvTmArgs": (aum_hip.ConvTmArgs, ["x", "dy", "weight", "bias", "y", "dx", "dw_part", "db_part", "x_bs", "dx_ts", "batch", "width",
                                                "dtype", "flags"]),
+        "AumDtProjArgs": (aum_hip.DtProjArgs, ["x", "w", "out", "ntok", "dim", "rank", "ldx", "ldw", "ldo", "dtype"]),
         "AumGemmArgs": (aum_hip.GemmArgs, ["a", "b", "c", "m", "n", "k", "lda", "ldb", "ldc", "dtype", "flags"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']

@@ -246,3 +246,10 @@ def test_gemm_tn_contract(emu, case):
 
 def test_gemm_tn_argument_rules(emu):
     KC.check_gemm_args(emu, "cpu")
+
+
+@pytest.mark.parametrize("case", [c for c in cases.DTPROJ_CASES if c[0] * c[1] < 1e5], ids=lambda c: "x".join(map(str, c)))
+def test_dtproj_tm_contract(emu, case):
+    """the host build's aum_dtproj_tm_fwd (a plain loop behind the shared argument rules) keeps the contract the GPU tests hold the MFMA
+    kernel to: only the first dt_rank columns of the x_dbl rows enter the product, fp32 accumulation, one rounding"""
+    KC.check_dtproj(emu, "cpu", *case, torch.bfloat16)

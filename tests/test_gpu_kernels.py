@@ -471,3 +471,21 @@ def test_norm_headline_shape(lib):
     assert KC.rel_err(n(dx), rb["dx"]) < 4 * KC.TOL_BF16                # the same values rounded for the 16-bit branch
     xhat = res_out.double() * rstd.double()[:, None]
     assert KC.rel_err(dw.cpu().numpy(), (dy.double() * xhat).sum(0).cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("case", cases.DTPROJ_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_dtproj_tm(lib, case, dtype):
+    KC.check_dtproj(lib, "cuda", *case, dtype)
+
+
+def test_dtproj_tm_headline_shape(lib):
+    """the bench's own launch: 64 x 513 tokens, d_inner 1536, dt_rank 48, x_dbl rows of 80 -- every element against the library's fp32
+    product of the same operands (one rounding each), bitwise repeatable"""
+    torch.manual_seed(3)
+    x = torch.randn(64 * 513, 80, device="cuda").bfloat16()
+    w = (torch.randn(1536, 48, device="cuda") / 48 ** 0.5).bfloat16()
+    out = aum_hip.dtproj_tm_fwd(x, 48, w, lib=lib)
+    ref = x[:, :48].float() @ w.float().t()
+    assert (out.float() - ref).abs().max().item() <= 1.01 * 2.0 ** -8 * ref.abs().max().item()
+    assert torch.equal(out, aum_hip.dtproj_tm_fwd(x, 48, w, lib=lib))
