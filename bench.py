@@ -67,7 +67,20 @@ def gemm_probe(dev, ntok, d_model, d_inner, iters=20):
     use_hip = ssi._hip_gemm_ok(a, w.shape[0], w.shape[1]) and aum_hip.gemm_tn_supported(a, w)
     ms = timed(lambda: aum_hip.gemm_tn(a, w)) if use_hip else ms_lib
     tf = flop / (ms * 1e-3) / 1e12
-    return {"bound": "mfma",
+    # the hand-written kernel on the GEMM the default dispatch gives it: the out_proj data gradient [ntok, d_model] x [d_model, d_inner]
+    hip_entry = None
+    g = torch.randn(ntok, d_model, device=dev).bfloat16()
+    wo_t = torch.randn(d_inner, d_model, device=dev).bfloat16()
+    if aum_hip.gemm_tn_supported(g, wo_t):
+        ms_h = timed(lambda: aum_hip.gemm_tn(g, wo_t))
+        ms_l = timed(lambda: ssi._mm_rows(g, wo_t.t(), 4))
+        fl = 2.0 * ntok * d_model * d_inner
+        hip_entry = {"kernel": f"out_proj data gradient [{ntok}x{d_model}] x [{d_model}x{d_inner}] bf16 (aum_gemm_tn, hand-written MFMA kernel"
+                               + ("; the step's default for this shape)" if ssi._hip_gemm_ok(g, d_inner, d_model) else ")"),
+                     "avg_launch_ms": round(ms_h, 4), "achieved": round(fl / (ms_h * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(fl / (ms_h * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "library_gemm_avg_launch_ms": round(ms_l, 4)}
+    return {"bound": "mfma", "hand_written": hip_entry,
             "kernel": f"in_proj forward GEMM [{ntok}x{d_model}] x [{d_model}x{2 * d_inner}] bf16 ("
                       + ("aum_gemm_tn, hand-written MFMA kernel" if use_hip else "hipBLASLt via TunableOp") + ")",
             "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
@@ -325,7 +338,7 @@ def main():
             roof["note"] = ("VALU-bound kernel (16 states x 2 directions, one v_exp_f32 per state and step at a quarter of the fp32 rate, "
                             "packed fp32 FMAs for the rest): the vector ALU is busy for `valu_frac` of the launch (SQ_ACTIVE_INST_VALU), so the "
                             "fraction of the HBM roofline is bounded near 0.1-0.3 by arithmetic; `traffic` above the algorithmic bytes is the "
-                            "fp32 state checkpoint (every 8 steps) and the per-wave dB/dC partial rows; see DESIGN.md 4")
+                            "state checkpoint (every 8 steps; pairs of states in the activations' 16-bit type) and the per-wave dB/dC partial rows; see DESIGN.md 4")
         # the forward kernel of the same scan and the largest library GEMM, against their own roofs
         fwd_roof = None
         fk = "scan_tm_fwd_bidir" if "scan_tm_fwd_bidir" in ktimes or (table is not None and "scan_tm_fwd_bidir" in table) else "scan_fwd_bidir"
