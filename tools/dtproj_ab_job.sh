@@ -1,3 +1,4 @@
+# same-box A/B of the dt-projection MFMA kernel (aum_dtproj_tm_fwd) against the library GEMM: parity tests, the kernel alone, the step
 export PYTHONPATH=$PWD/audio-mamba-aum_amd:$PYTHONPATH
 timeout 300 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -x -q -k "dtproj or headline or repeatable or inner_fns or token_major" 2>&1 | tail -3
 python - <<'PY'
