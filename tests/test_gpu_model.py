@@ -412,10 +412,16 @@ def test_aum_base_headline_fp32_vs_reference():
     assert e_elem[we] < 2e-3, (we, e_elem[we])
 
 
-def test_aum_base_headline_bench_batch_bf16_vs_reference():
-    """the bench's own launch shapes against the reference: the golden clip repeated 64 times under bf16 autocast goes through the
+@pytest.mark.parametrize("gemm_mode", ["auto", "hip", "lib"])
+def test_aum_base_headline_bench_batch_bf16_vs_reference(gemm_mode, monkeypatch):
+    """(gemm_mode: the projection-GEMM dispatch of selective_scan_interface -- `hip` runs in_proj / out_proj forward and both data
+    gradients of all 24 blocks on aum_gemm_tn, `lib` none of them, `auto` the default -- the same bars for all three.)
+    the bench's own launch shapes against the reference: the golden clip repeated 64 times under bf16 autocast goes through the
     token-major kernels and the MFMA projection GEMMs exactly as bench.py's step does (B = 64, L = 513); every row of the logits is
     the reference's logits, and the gradients are 64 times the reference's (dlogits repeated).  Bars: the depth-scaled bf16 bars above."""
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    monkeypatch.setattr(ssi, "_GEMM_MODE", gemm_mode)
+    monkeypatch.setattr(ssi, "_HIP_GEMM", gemm_mode != "lib")
     case = cases.HEADLINE_CASES[0]
     name, depth = case[0], case[2]
     model, d, g = _headline_model(case)
@@ -428,7 +434,7 @@ def test_aum_base_headline_bench_batch_bf16_vs_reference():
     e_rows = [rel_err(lb[i:i + 1].float().detach().cpu().numpy(), ref) for i in (0, 1, 31, 63)]
     e_norm, e_elem = _headline_grad_errors(model, g, name, scale=float(reps))
     wn, we = max(e_norm, key=e_norm.get), max(e_elem, key=e_elem.get)
-    _err_report(name + ".bf16_b64", {"logits": max(e_rows), "gnorm_max": [wn, e_norm[wn]], "grad_elem_max": [we, e_elem[we]]})
+    _err_report(name + ".bf16_b64." + gemm_mode, {"logits": max(e_rows), "gnorm_max": [wn, e_norm[wn]], "grad_elem_max": [we, e_elem[we]]})
     assert max(e_rows) < BF16_LOGIT_TOL * (depth / 4) ** 0.5, e_rows
     assert e_norm[wn] < BF16_GNORM_TOL * (depth / 4) ** 0.5, (wn, e_norm[wn])
     assert e_elem[we] < BF16_GRAD_TOL * (depth / 4) ** 0.5, (we, e_elem[we])
