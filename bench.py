@@ -70,10 +70,11 @@ def gemm_probe(dev, ntok, d_model, d_inner, iters=20):
     # the hand-written kernel on the GEMM the default dispatch gives it: the out_proj data gradient [ntok, d_model] x [d_model, d_inner]
     hip_entry = None
     g = torch.randn(ntok, d_model, device=dev).bfloat16()
-    wo_t = torch.randn(d_inner, d_model, device=dev).bfloat16()
+    wo = torch.randn(d_model, d_inner, device=dev).bfloat16()           # out_proj.weight as nn.Linear stores it: the library's operand
+    wo_t = wo.t().contiguous()                                         # its transposed copy (per-forward weight cache): aum_gemm_tn's
     if aum_hip.gemm_tn_supported(g, wo_t):
         ms_h = timed(lambda: aum_hip.gemm_tn(g, wo_t))
-        ms_l = timed(lambda: ssi._mm_rows(g, wo_t.t(), 4))
+        ms_l = timed(lambda: ssi._mm_rows(g, wo, 4))                   # the recorded shapes of the step (no online tuning here)
         fl = 2.0 * ntok * d_model * d_inner
         hip_entry = {"kernel": f"out_proj data gradient [{ntok}x{d_model}] x [{d_model}x{d_inner}] bf16 (aum_gemm_tn, hand-written MFMA kernel"
                                + ("; the step's default for this shape)" if ssi._hip_gemm_ok(g, d_inner, d_model) else ")"),
