@@ -64,7 +64,7 @@ if __name__ == "__main__":
         out, name = [long_form()], "variants_bench_long.json"
     else:
         out = [run("base", "v1", True), run("base", "v1", False), run("base", "v2", True), run("base", "none", True),
-               run("small", "v1", True), run("tiny", "v1", True), run("base", "v1", True, batch=256, steps=3, warm=2), long_form()]
+               run("small", "v1", True), run("small", "v1", False), run("tiny", "v1", True), run("base", "v1", True, batch=256, steps=3, warm=2), long_form()]
         name = "variants_bench.json"
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", name), "w"), indent=1)
