@@ -409,13 +409,18 @@ def token_major_ok(d_inner, d_state, d_conv, dt_rank, dtype=None):
 
 
 # The time-serial kernels give one wave to 64 channels of one batch entry and direction and walk the WHOLE sequence with it: they need
-# batch * (d_inner / 64) * directions waves to fill 256 CUs x 4 SIMDs x 2-3 waves.  Short of that (long-form clips at batch 8,
-# single-clip inference) the chunk-parallel channel-major kernels are the better division.  AUM_TM_MIN_WAVES overrides the threshold.
+# batch * (d_inner / 64) * directions waves to fill 256 CUs x 4 SIMDs -- 1.5 per SIMD for the forward (three resident), 2 per SIMD when a
+# backward follows (two resident at 256 VGPRs).  Short of that (long-form clips at batch 8, single-clip inference, AuM-Small training at
+# batch 64) the chunk-parallel channel-major kernels are the better division: AuM-Small, B = 64 (1536 waves), same box: training 41.2 ms
+# token-major vs 39.7 ms channel-major, forward only 11.3 vs 11.9 ms (profiles/r03_variants_bench.json).  AUM_TM_MIN_WAVES overrides
+# the forward threshold (the training one is 4/3 of it).
 _TM_MIN_WAVES = int(_dbg_env("AUM_TM_MIN_WAVES", "1536"))
 
 
-def token_major_preferred(batch, d_inner, bidirectional):
-    return batch * (d_inner // 64) * (2 if bidirectional else 1) >= _TM_MIN_WAVES
+def token_major_preferred(batch, d_inner, bidirectional, training=None):
+    training = torch.is_grad_enabled() if training is None else training
+    need = -(-_TM_MIN_WAVES * 4 // 3) if training else _TM_MIN_WAVES
+    return batch * (d_inner // 64) * (2 if bidirectional else 1) >= need
 
 
 def _is_tm(xz):

@@ -318,18 +318,18 @@ def test_model_forward_from_waveform_matches_spectrogram_input():
 
 
 def test_whole_step_bitwise_repeatable_token_major():
-    """Two forward + backward passes of AuM-Base blocks on the headline path (batch 32 x 513 tokens, bf16 autocast, token-major
+    """Two forward + backward passes of AuM-Base blocks on the headline path (batch 48 x 513 tokens, bf16 autocast, token-major
     kernels) give the same bits: logits and every parameter gradient.  Nothing on this path accumulates with atomics -- the scan's
     dB/dC and the conv's dweight/dbias leave per-wave partials that are summed in a fixed order, the weight-gradient GEMMs are
     split-K batches summed by aum_sum_rows -- so a difference here is an ordering bug (a wait that names too few operations, a
     missing barrier)."""
     import mamba_ssm.ops.selective_scan_interface as ssi
     from aum.model import build_aum
-    assert ssi.TOKEN_MAJOR and ssi.token_major_preferred(32, 1536, True) and ssi.token_major_ok(1536, 16, 4, 48, torch.bfloat16)
+    assert ssi.TOKEN_MAJOR and ssi.token_major_preferred(48, 1536, True) and ssi.token_major_ok(1536, 16, 4, 48, torch.bfloat16)
     torch.manual_seed(11)
     model = build_aum("base", depth=2, num_classes=527, bimamba_type="v1").to(DEV)
-    x = torch.randn(32, 1024, 128, device=DEV) * 0.5
-    y = (torch.rand(32, 527, device=DEV) < 0.01).float()
+    x = torch.randn(48, 1024, 128, device=DEV) * 0.5
+    y = (torch.rand(48, 527, device=DEV) < 0.01).float()
     runs = []
     for _ in range(3):
         model.zero_grad(set_to_none=True)

@@ -333,6 +333,8 @@ def test_token_major_module_matches_channel_major(monkeypatch):
     assert not ssi.token_major_ok(384, 16, 4, 12, torch.bfloat16)       # B / C rows of x_dbl not 16-byte aligned behind 12 bf16 dt columns
     assert not ssi.token_major_ok(1536, 8, 4, 48, torch.bfloat16) and not ssi.token_major_ok(96, 16, 4, 4, torch.float32)
     assert ssi.token_major_preferred(64, 1536, True) and not ssi.token_major_preferred(8, 1536, True)      # long-form batch 8: chunk kernels
+    # AuM-Small at batch 64 is 1536 waves: enough for the forward alone, not when a backward follows
+    assert ssi.token_major_preferred(64, 768, True, training=False) and not ssi.token_major_preferred(64, 768, True, training=True)
     torch.manual_seed(3)
     for btype in ("v1", "none"):
         m = Mamba(64, bimamba_type=btype)
