@@ -335,18 +335,21 @@ def _mm_rows(a, b, bit):
 
 # The K-contiguous projection GEMMs of the token-major block -- in_proj / out_proj forward, and their data gradients against the cached
 # transposed weight -- can run on the hand-written MFMA kernel (aum_hip.gemm_tn, csrc/gemm_kernels.h) whenever the operands qualify
-# (16-bit, device, widths that are multiples of 256 / 64).  Measured on MI355X at the bench shape (profiles/r03_gemm_probe.txt,
-# r03_gemm_step_ab.txt) it beats the tuned library GEMM on the out_proj data gradient in isolation (N = 1536, K = 768: 83.7 vs 89.2 us; level
-# inside the step: 96 vs 93 us) and loses 8-20 % on the other three (tile quantisation at N = 768, the synchronized store bursts of DESIGN
-# 4.8): the default ("auto") sends a GEMM to the kernel only for that (N, K) -- the step pays 0.4 % for it (68.1 vs 67.8 ms) and keeps the
-# kernel in the product path; AUM_DEBUG=1 AUM_GEMM=hip sends all four (70.1 ms), AUM_GEMM=lib none (A/B runs).  The weight gradients
-# (token-contiguous operands) and everything that does not qualify stay library GEMMs.
+# (16-bit, device, widths that are multiples of 256 / 64).  Which of them do is decided by the step, not by the kernel alone
+# (profiles/r03_gemm_step_ab.txt, same box, ms per step): library only 67.49; + out_proj data gradient (N = 1536, K = 768) 66.77;
+# + in_proj forward (3072, 768) 66.20 -- alone the kernel is 10 % behind the library on that one, but it takes the 64 ragged rows of
+# 64 x 513 tokens in its stride where the library needs a second launch (152.6 + 19 us); + out_proj forward (768, 1536) 66.93; all four
+# 67.0-70.1 (N = 768 is two tiles per CU: tile quantisation).  The default ("auto") therefore sends the two N >= 1536 shapes
+# to the kernel; AUM_DEBUG=1 AUM_GEMM=hip sends all four, AUM_GEMM=lib none, AUM_GEMM_SHAPES="NxK,..." another set (A/B runs).  The weight
+# gradients (token-contiguous operands) and everything that does not qualify stay library GEMMs.
 _DTPROJ_HIP = _dbg_env("AUM_DTPROJ_LIB", "0") != "1"        # AUM_DEBUG=1 AUM_DTPROJ_LIB=1: the dt projection back on the library GEMM (A/B)
 _GEMM_MODE = _dbg_env("AUM_GEMM", "auto")
 if _GEMM_MODE not in ("auto", "hip", "lib"):
     raise ValueError("AUM_GEMM takes auto, hip or lib")
 _HIP_GEMM = _GEMM_MODE != "lib"
-_HIP_GEMM_FASTER = {(1536, 768)}            # (N, K) of aum_gemm_tn calls that measured at least level with the library's solution
+_HIP_GEMM_FASTER = {(1536, 768), (3072, 768)}     # (N, K) of aum_gemm_tn calls that make the STEP faster than the library's solutions do
+if _dbg_env("AUM_GEMM_SHAPES", ""):         # A/B runs: another set, "NxK,NxK"
+    _HIP_GEMM_FASTER = {tuple(int(v) for v in sh.split("x")) for sh in _dbg_env("AUM_GEMM_SHAPES", "").split(",")}
 
 
 def _hip_gemm_ok(a, n, k):
