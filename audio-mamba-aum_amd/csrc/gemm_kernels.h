@@ -255,7 +255,7 @@ __device__ __forceinline__ GemmItem gemm_item(const GemmLaunch& L, int id, int n
         const int tm = tile / ntn;
         it.m0 = tm * BM;
         it.n0 = (tile - tm * ntn) * BN;
-        it.rows = BM;
+        it.rows = L.g.m - it.m0 < BM ? L.g.m - it.m0 : BM;       // < BM only for a last row block of 129 .. 255 rows (taken as a full item)
         it.half = false;
     } else {
         const int h = id - nfull, hb = h / ntn;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_persistent(GemmLaunch L)
             gemm_store<BF16, 4>(acc, c_rows, (int64_t)g.ldc * 2, row_base + rho, it.rows);
         }
         if (!has_next) break;
-        stores16 = !it.half;
+        stores16 = !it.half && it.rows == BM;         // every wave of a complete full tile issued its 16 stores
         id = nid;
         it = itn;
         ra = ra_n;

@@ -329,8 +329,11 @@ def check_gemm(lib, dev, case, dtype, flags=0):
     a_full = torch.randn(m, k + pad_a, generator=g).to(dtype).to(dev)
     b = (torch.randn(n, k, generator=g) / k ** 0.5).to(dtype).to(dev)
     a = a_full[:, :k]
-    c_full = torch.full((m, n + pad_c), 7.0, dtype=dtype, device=dev)
+    # the result is a block of a larger buffer: pad_c columns in front of it and 260 rows behind it must come back untouched
+    c_buf = torch.full((m + 260, n + pad_c), 7.0, dtype=dtype, device=dev)
+    c_full = c_buf[:m]
     out = aum_hip.gemm_tn(a, b, out=c_full[:, pad_c:], lib=lib, flags=flags)
+    assert torch.all(c_buf[m:] == 7.0), "rows behind the result were written"
     ref = a.double().cpu() @ b.double().cpu().t()
     ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     err = (out.double().cpu() - ref).abs().max().item()
