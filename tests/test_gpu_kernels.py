@@ -489,3 +489,16 @@ def test_dtproj_tm_headline_shape(lib):
     ref = x[:, :48].float() @ w.float().t()
     assert (out.float() - ref).abs().max().item() <= 1.01 * 2.0 ** -8 * ref.abs().max().item()
     assert torch.equal(out, aum_hip.dtproj_tm_fwd(x, 48, w, lib=lib))
+
+
+def test_gemm_tn_random_shapes(lib):
+    """40 seeded shapes (m 1 .. 1500 incl. every kind of last row block, n 256 .. 1024, k 64 .. 512), every kernel of aum_gemm_tn: the
+    product against fp64, and nothing written outside the result (rows behind it, columns beside it)"""
+    import random
+    rnd = random.Random(20260928)
+    for it in range(40):
+        m = rnd.choice([rnd.randint(1, 1500), 256 * rnd.randint(1, 5) + rnd.choice([0, 1, 64, 127, 128, 129, 255])])
+        n, k = 256 * rnd.randint(1, 4), 64 * rnd.randint(1, 8)
+        pad_a, pad_c = 8 * rnd.randint(0, 3), 8 * rnd.randint(0, 3)
+        flags = rnd.choice([0, aum_hip.GEMM_PERSISTENT, aum_hip.GEMM_LOCKSTEP, aum_hip.GEMM_STAGGERED])
+        KC.check_gemm(lib, "cuda", (f"rnd{it}_{m}_{n}_{k}", m, n, k, pad_a, pad_c), torch.bfloat16, flags=flags)
