@@ -149,3 +149,28 @@ def test_inner_vs_reference(case):
     for k in keys:
         assert k in res, k
         assert rel_err(res[k], g[name + "." + k]) < 2e-4, k   # reference autograd runs in fp32
+
+
+def test_headline_fixture_is_self_consistent():
+    """tests/golden/headline.npz (the reference's AudioMamba at BASELINE configs 3 and 2, make_golden.py --headline) stores outputs only;
+    its inputs -- 92 M seeded parameter values and the clip -- are regenerated from cases.py.  The stored checksum pins that generator: if
+    it drifts, the GPU tests would compare the product with goldens of different weights."""
+    import cases
+    g = load_golden("headline")
+    case = cases.HEADLINE_CASES[1]                      # AuM-Small: 24 M parameters, a few seconds
+    name = case[0]
+    keys = [str(k) for k in g[name + ".keys"]]
+    assert len(keys) > 200 and g[name + ".logits"].shape == (case[6], case[5])
+    # shapes of the state dict follow from the architecture (MM:678-685): rebuild them from the package's own model
+    import torch
+    from aum.model import AudioMamba
+    with torch.device("meta"):
+        model = AudioMamba(spectrogram_size=case[4], depth=case[2], embed_dim=case[3], num_classes=case[5], bimamba_type=case[1])
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert sorted(shapes) == keys
+    vals = cases.model_state(shapes, name)
+    d = cases.model_inputs(*case[:7])
+    ref = float(g[name + ".checksum"])
+    assert abs(float(cases.checksum(dict(vals, **d))) - ref) <= 1e-9 * abs(ref)
+    base = cases.HEADLINE_CASES[0][0]
+    assert sum(k.startswith(base + ".gnorm.") for k in g) == 271 and g[base + ".logits"].shape == (1, 527)
