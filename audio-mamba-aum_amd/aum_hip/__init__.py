@@ -140,7 +140,12 @@ class DtProjArgs(C.Structure):
     _fields_ = ([(n, _vp) for n in ("x", "w", "out")] + [("ntok", _i64)] + [(n, _i32) for n in ("dim", "rank", "ldx", "ldw", "ldo", "dtype")])
 
 
-EXPORTS = ["aum_gemm_tn", "aum_dtproj_tm_fwd", "aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
+class XdtArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("u", "wx", "wdt", "x_dbl", "delta")] + [("ntok", _i64)]
+                + [(n, _i32) for n in ("dim", "rank", "ncols", "ldu", "ldwx", "ldwdt", "ldx", "ldd", "dtype")])
+
+
+EXPORTS = ["aum_gemm_tn", "aum_dtproj_tm_fwd", "aum_xdt_tm_fwd", "aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows",
            "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_ckpt_rows", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_selftest_wave_sum32",
@@ -173,6 +178,7 @@ class Lib:
         self.c.aum_conv1d_tm_nparts.argtypes = [_i32, _i32]
         self.c.aum_gemm_tn.argtypes = [_vp, _vp]
         self.c.aum_dtproj_tm_fwd.argtypes = [_vp, _vp]
+        self.c.aum_xdt_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_scan_tm_workspace_bytes.restype = _i64
         self.c.aum_scan_tm_workspace_bytes.argtypes = [_i32] * 5
         self.c.aum_fbank_fwd.argtypes = [_vp, _vp]
@@ -640,6 +646,39 @@ def dtproj_tm_fwd(x_dbl, rank, w, lib=None):
     a.ntok, a.dim, a.rank, a.ldx, a.ldw, a.ldo, a.dtype = ntok, dim, rank, x_dbl.stride(0), w.stride(0), dim, _DT[x_dbl.dtype]
     _launch(lib.c.aum_dtproj_tm_fwd, a, x_dbl, lib, "dtproj_tm_fwd", (ntok, dim, rank))
     return out
+
+
+XDT_COLS, XDT_MAX_DIM = 80, 1536
+
+
+def xdt_tm_supported(u, wx, wdt):
+    """shapes aum_xdt_tm_fwd takes (include/aum_hip.h, ABI 9): 16-bit row-major conv_out (ntok, dim), x_proj.weight (80, dim),
+    dt_proj.weight (dim, rank)"""
+    if not (u.dim() == 2 and wx.dim() == 2 and wdt.dim() == 2 and u.dtype == wx.dtype == wdt.dtype and u.dtype in (torch.bfloat16, torch.float16)):
+        return False
+    dim, rank = u.shape[1], wdt.shape[1]
+    ok_t = lambda t: t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+    return (wx.shape == (XDT_COLS, dim) and wdt.shape[0] == dim and dim % 128 == 0 and dim <= XDT_MAX_DIM and rank % 8 == 0 and rank <= 64
+            and ok_t(u) and ok_t(wx) and ok_t(wdt))
+
+
+def xdt_tm_fwd(u, wx, wdt, lib=None):
+    """(x_dbl (ntok, 80), delta (ntok, dim)) = (u @ wx^T, x_dbl[:, :rank] @ wdt^T) in one pass over u (SSI:467-468 on token-major rows)"""
+    lib = lib or get()
+    for t in (u, wx, wdt):
+        lib.check_tensor(t)
+    if not xdt_tm_supported(u, wx, wdt):
+        raise RuntimeError(f"xdt_tm_fwd: unsupported operands {tuple(u.shape)} {u.dtype}, {tuple(wx.shape)}, {tuple(wdt.shape)}")
+    ntok, dim = u.shape
+    rank = wdt.shape[1]
+    x_dbl = torch.empty((ntok, XDT_COLS), dtype=u.dtype, device=u.device)
+    delta = torch.empty((ntok, dim), dtype=u.dtype, device=u.device)
+    a = XdtArgs()
+    a.u, a.wx, a.wdt, a.x_dbl, a.delta = _ptr(u), _ptr(wx), _ptr(wdt), _ptr(x_dbl), _ptr(delta)
+    a.ntok, a.dim, a.rank, a.ncols = ntok, dim, rank, XDT_COLS
+    a.ldu, a.ldwx, a.ldwdt, a.ldx, a.ldd, a.dtype = u.stride(0), wx.stride(0), wdt.stride(0), XDT_COLS, dim, _DT[u.dtype]
+    _launch(lib.c.aum_xdt_tm_fwd, a, u, lib, "xdt_tm_fwd", (ntok, dim, rank))
+    return x_dbl, delta
 
 
 def conv1d_tm_supported(x, width):

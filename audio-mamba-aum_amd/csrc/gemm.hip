@@ -2,6 +2,7 @@
 // the token-major block (dtproj_kernels.h, aum_dtproj_tm_fwd); include/aum_hip.h, ABI 9.
 #include "gemm_kernels.h"
 #include "dtproj_kernels.h"
+#include "xdt_kernels.h"
 
 extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
     const int rc = aumg::gemm_check(p);
@@ -56,5 +57,19 @@ extern "C" int aum_dtproj_tm_fwd(const AumDtProjArgs* p, void* stream) {
     else if (bf) hipLaunchKernelGGL((aumd::k_dtproj_tm<true, 2>), grid, block, 0, s, g);
     else if (one) hipLaunchKernelGGL((aumd::k_dtproj_tm<false, 1>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((aumd::k_dtproj_tm<false, 2>), grid, block, 0, s, g);
+    return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
+}
+
+extern "C" int aum_xdt_tm_fwd(const AumXdtArgs* p, void* stream) {
+    const int rc = aumx::xdt_check(p);
+    if (rc != AUM_OK) return rc;
+    const AumXdtArgs& g = *p;
+    const dim3 grid((unsigned)((g.ntok + XDT_TOK_WG - 1) / XDT_TOK_WG)), block(XDT_WAVES * 64);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool bf = g.dtype == AUM_BF16, one = g.rank <= 32;
+    if (bf && one) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<true, 1>), grid, block, 0, s, g);
+    else if (bf) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<true, 2>), grid, block, 0, s, g);
+    else if (one) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<false, 1>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<false, 2>), grid, block, 0, s, g);
     return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
 }

@@ -1,0 +1,213 @@
+// xdt_kernels.h -- x_proj and dt_proj of the token-major block in ONE pass over conv_out (round 3; ABI 9 aum_xdt_tm_fwd).
+//
+//   x_dbl[M][C] = u[M][E] . W_x[C][E]^T            SSI:467        (C = dt_rank + 2 d_state = 80 for AuM-Base)
+//   delta[M][E] = x_dbl[M][0:R] . W_dt[E][R]^T     SSI:468        (R = dt_rank)
+//
+// Both are bound by one stream each -- the first reads an activation tensor (100 MB at the bench shape) to produce 5 MB, the second
+// turns those 5 MB into an activation tensor -- and as two launches the small tensor makes a round trip through memory in between.
+// Here a workgroup of 4 waves takes 128 tokens through both: W_x (245 KB) passes through LDS in two K-halves shared by the four waves
+// (rows padded by 16 bytes: fragment reads spread over the banks), a wave accumulates its 32 tokens x 80 columns on the matrix pipe
+// (v_mfma_f32_16x16x32: rows = x_dbl columns, columns = tokens), rounds them into an LDS tile of its own -- from which x_dbl leaves in
+// 16-byte pieces and the dt block comes back as the MFMA B operand -- and then streams W_dt through the same LDS space in two channel
+// halves, storing delta 64 contiguous bytes per token row and instruction (the store layout of dtproj_kernels.h).
+// u is fetched 32 contiguous bytes per lane (a full 128-byte line per token row and K-step of 64) two steps ahead of its use; the k
+// order inside a step is permuted the same way on both operands (lane group kg holds k0 + 16 kg .. + 15), which the product does not see.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "xdt_args.h"
+
+namespace aumx {
+
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+
+template <bool BF16> __device__ __forceinline__ f4v mfma(s8v a, s8v b, f4v c) {
+    if constexpr (BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+}
+template <bool BF16> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    if constexpr (BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{a, b}, bf2v));
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{a, b}, h2v));
+}
+
+constexpr int NCF = XDT_COLS / 16;                        // 5 column fragments of x_dbl
+constexpr int NTF = XDT_TOK_W / 16;                       // token fragments per wave
+constexpr int XP = XDT_COLS * 2 + 16;                     // bytes per row of a wave's x_dbl tile (176: 11 x 16, odd -> conflict-free reads)
+constexpr int XT_BYTES = XDT_TOK_W * XP;                  // one wave's tile
+constexpr int WDP = 144;                                  // bytes per W_dt row in LDS (rank <= 64: 128 + 16)
+__host__ __device__ constexpr int slab_pitch(int kh) { return kh * 2 + 16; }          // bytes per W_x row of a K-half
+__host__ __device__ constexpr int slab_bytes(int dim) {
+    const int a = XDT_COLS * slab_pitch(dim / 2), b = (dim / 2) * WDP;
+    return a > b ? a : b;
+}
+__host__ __device__ constexpr int lds_bytes(int dim) { return slab_bytes(dim) + XDT_WAVES * XT_BYTES; }
+
+// rows x chunks 16-byte pieces of a row-major matrix (row pitch src_pitch bytes) -> LDS rows of dst_pitch bytes, by all 256 threads: eight
+// loads in flight per thread before the first LDS write (written as one load-store pair per iteration, each iteration was a round trip to
+// L2 on the critical path: 30 of them per W_x half -- 119 us for the kernel instead of 60)
+__device__ __forceinline__ void stage_rows(char* dst, int dst_pitch, const char* src, int64_t src_pitch, int rows, int chunks, int tid) {
+    const int total = rows * chunks;
+    for (int base = tid; base < total; base += XDT_WAVES * 64 * 8) {
+        u4v r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = base + j * XDT_WAVES * 64;
+            if (idx < total) {
+                const int row = idx / chunks, ch = idx - row * chunks;
+                r[j] = *reinterpret_cast<const u4v*>(src + row * src_pitch + ch * 16);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = base + j * XDT_WAVES * 64;
+            if (idx < total) {
+                const int row = idx / chunks, ch = idx - row * chunks;
+                *reinterpret_cast<u4v*>(dst + row * dst_pitch + ch * 16) = r[j];
+            }
+        }
+    }
+}
+
+template <bool BF16, int KS>
+__global__ __launch_bounds__(XDT_WAVES * 64, 1) void k_xdt_tm_fwd(AumXdtArgs g) {
+    __shared__ __attribute__((aligned(16))) char lds[lds_bytes(XDT_MAX_DIM)];           // 143 KB: one workgroup per CU
+    const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int rho = lane & 15, kg = lane >> 4;
+    const int E = g.dim, KH = E / 2, SP = slab_pitch(KH);
+    char* slab = lds;
+    char* xt = lds + slab_bytes(E) + w * XT_BYTES;
+    const int64_t t0 = (int64_t)blockIdx.x * XDT_TOK_WG + w * XDT_TOK_W;
+    const s8v zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const char* ub = static_cast<const char*>(g.u);
+    bool tok_ok[NTF];
+    const char* urow[NTF];
+    for (int tf = 0; tf < NTF; ++tf) {
+        tok_ok[tf] = t0 + tf * 16 + rho < g.ntok;
+        urow[tf] = ub + ((t0 + tf * 16 + rho) * g.ldu + kg * 16) * 2;
+    }
+
+    f4v acc[NTF][NCF];
+#pragma unroll
+    for (int tf = 0; tf < NTF; ++tf)
+#pragma unroll
+        for (int f = 0; f < NCF; ++f) acc[tf][f] = f4v{0.f, 0.f, 0.f, 0.f};
+
+    // ---- stage A: x_dbl = u . W_x^T, K in two halves of W_x through LDS -------------------------------------------------------
+    auto load_u = [&](int k0, s8v (&uf)[NTF][2]) {
+#pragma unroll
+        for (int tf = 0; tf < NTF; ++tf) {
+            uf[tf][0] = tok_ok[tf] ? *reinterpret_cast<const s8v*>(urow[tf] + (int64_t)k0 * 2) : zero;
+            uf[tf][1] = tok_ok[tf] ? *reinterpret_cast<const s8v*>(urow[tf] + (int64_t)k0 * 2 + 16) : zero;
+        }
+    };
+    const int nsteps = KH / 64;
+    s8v uf[NTF][2], u1[NTF][2], un[NTF][2];          // this step's u, the next step's, the one after that (requested two steps ahead)
+    load_u(0, uf);
+    if (64 < E) load_u(64, u1);
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                                             // everybody is done with the previous contents of the slab
+        stage_rows(slab, SP, static_cast<const char*>(g.wx) + (int64_t)half * KH * 2, (int64_t)g.ldwx * 2, XDT_COLS, KH / 8, tid);
+        __syncthreads();
+        const char* wrd = slab + rho * SP + kg * 32;                 // + f * 16 rows, + step * 128 bytes
+        for (int s = 0; s < nsteps; ++s) {
+            const int kn = half * KH + (s + 2) * 64;                 // two steps ahead (also across the half boundary)
+            if (kn < E) load_u(kn, un);
+#pragma unroll
+            for (int f = 0; f < NCF; ++f) {
+                const s8v w0 = *reinterpret_cast<const s8v*>(wrd + f * 16 * SP + s * 128);
+                const s8v w1 = *reinterpret_cast<const s8v*>(wrd + f * 16 * SP + s * 128 + 16);
+#pragma unroll
+                for (int tf = 0; tf < NTF; ++tf) {
+                    acc[tf][f] = mfma<BF16>(w0, uf[tf][0], acc[tf][f]);
+                    acc[tf][f] = mfma<BF16>(w1, uf[tf][1], acc[tf][f]);
+                }
+            }
+#pragma unroll
+            for (int tf = 0; tf < NTF; ++tf)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    uf[tf][h2] = u1[tf][h2];
+                    u1[tf][h2] = un[tf][h2];
+                }
+        }
+    }
+    // ---- the wave's x_dbl tile: rounded once, [token][column] in LDS; x_dbl leaves from there in 16-byte pieces --------------------
+    // lane (kg, token rho) holds columns 16 f + 4 kg + r of token fragment tf
+#pragma unroll
+    for (int tf = 0; tf < NTF; ++tf)
+#pragma unroll
+        for (int f = 0; f < NCF; ++f) {
+            u2v v;
+            v.x = pack2<BF16>(acc[tf][f][0], acc[tf][f][1]);
+            v.y = pack2<BF16>(acc[tf][f][2], acc[tf][f][3]);
+            *reinterpret_cast<u2v*>(xt + (tf * 16 + rho) * XP + (f * 16 + kg * 4) * 2) = v;
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0): the wave's own LDS writes have landed (nobody else reads this tile)
+    {
+        char* xo = static_cast<char*>(g.x_dbl);
+        constexpr int PIECES = XDT_COLS * 2 / 16;                    // 10 per token row
+        for (int idx = lane; idx < XDT_TOK_W * PIECES; idx += 64) {
+            const int tk = idx / PIECES, pc = idx - tk * PIECES;
+            if (t0 + tk < g.ntok)
+                *reinterpret_cast<u4v*>(xo + ((t0 + tk) * g.ldx) * 2 + pc * 16) = *reinterpret_cast<const u4v*>(xt + tk * XP + pc * 16);
+        }
+    }
+    // ---- stage B: delta = x_dbl[:, :R] . W_dt^T, the channels in two halves of W_dt through the same LDS space -------------------
+    s8v xf[NTF][KS];
+#pragma unroll
+    for (int tf = 0; tf < NTF; ++tf)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = ks * 32 + kg * 8;
+            xf[tf][ks] = k < g.rank ? *reinterpret_cast<const s8v*>(xt + (tf * 16 + rho) * XP + k * 2) : zero;
+        }
+    const bool k_ok[2] = {kg * 8 < g.rank, 32 + kg * 8 < g.rank};
+    const int CH = E / 2, wchunks = g.rank / 8;
+    char* ob = static_cast<char*>(g.delta) + ((t0 + rho) * g.ldd + kg * 8) * 2;
+    const int64_t otf = (int64_t)16 * g.ldd * 2;
+    // fragment j of a channel pair reads weight rows c0 + 8 (rho >> 2) + 4 j + (rho & 3): accumulator rows 4 kg + r of fragments 0, 1 are
+    // channels c0 + 8 kg + 0..7
+    const char* wdr = slab + ((rho >> 2) * 8 + (rho & 3)) * WDP + kg * 16;
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        stage_rows(slab, WDP, static_cast<const char*>(g.wdt) + (int64_t)half * CH * g.ldwdt * 2, (int64_t)g.ldwdt * 2, CH, wchunks, tid);
+        __syncthreads();
+        const int npairs = CH / 32;
+#pragma unroll 2
+        for (int p = 0; p < npairs; ++p) {
+            s8v wf[2][KS];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    wf[j][ks] = k_ok[ks] ? *reinterpret_cast<const s8v*>(wdr + (p * 32 + j * 4) * WDP + ks * 64) : zero;
+#pragma unroll
+            for (int tf = 0; tf < NTF; ++tf) {
+                f4v a2[2] = {f4v{0.f, 0.f, 0.f, 0.f}, f4v{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) a2[j] = mfma<BF16>(wf[j][ks], xf[tf][ks], a2[j]);
+                if (tok_ok[tf]) {
+                    u4v o;
+                    o.x = pack2<BF16>(a2[0][0], a2[0][1]);
+                    o.y = pack2<BF16>(a2[0][2], a2[0][3]);
+                    o.z = pack2<BF16>(a2[1][0], a2[1][1]);
+                    o.w = pack2<BF16>(a2[1][2], a2[1][3]);
+                    *reinterpret_cast<u4v*>(ob + tf * otf + ((int64_t)half * CH + p * 32) * 2) = o;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace aumx

@@ -342,6 +342,7 @@ def _mm_rows(a, b, bit):
 # 67.0-70.1 (N = 768 is two tiles per CU: tile quantisation).  The default ("auto") therefore sends the two N >= 1536 shapes
 # to the kernel; AUM_DEBUG=1 AUM_GEMM=hip sends all four, AUM_GEMM=lib none, AUM_GEMM_SHAPES="NxK,..." another set (A/B runs).  The weight
 # gradients (token-contiguous operands) and everything that does not qualify stay library GEMMs.
+_XDT_HIP = _dbg_env("AUM_XDT_LIB", "0") != "1"              # AUM_DEBUG=1 AUM_XDT_LIB=1: x_proj as a library GEMM + the dt projection kernel (A/B)
 _DTPROJ_HIP = _dbg_env("AUM_DTPROJ_LIB", "0") != "1"        # AUM_DEBUG=1 AUM_DTPROJ_LIB=1: the dt projection back on the library GEMM (A/B)
 _GEMM_MODE = _dbg_env("AUM_GEMM", "auto")
 if _GEMM_MODE not in ("auto", "hip", "lib"):
@@ -453,9 +454,15 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
     conv_w = conv1d_weight.reshape(E, -1)
     conv_out = aum_hip.conv1d_tm_fwd(x, conv_w, conv1d_bias, True, reverse)                 # SSI:463  (B, L, E)
     conv2d = conv_out.view(Bsz * L, E)
-    x_dbl = torch.matmul(conv2d, x_proj_weight.t().to(conv2d.dtype))                        # SSI:467  (BL, R+2N)
-    w_dt = delta_proj_weight.to(x_dbl.dtype)
-    if _DTPROJ_HIP and x_dbl.is_cuda and aum_hip.dtproj_tm_supported(x_dbl, R, w_dt):
+    w_x, w_dt = x_proj_weight.to(conv2d.dtype), delta_proj_weight.to(conv2d.dtype)
+    if _XDT_HIP and conv2d.is_cuda and aum_hip.xdt_tm_supported(conv2d, w_x, w_dt):
+        x_dbl, delta = aum_hip.xdt_tm_fwd(conv2d, w_x, w_dt)                                 # SSI:467-468 in one pass over conv_out
+    else:
+        x_dbl = torch.matmul(conv2d, w_x.t())                                                # SSI:467  (BL, R+2N)
+        delta = None
+    if delta is not None:
+        pass
+    elif _DTPROJ_HIP and x_dbl.is_cuda and aum_hip.dtproj_tm_supported(x_dbl, R, w_dt):
         delta = aum_hip.dtproj_tm_fwd(x_dbl, R, w_dt)                                        # SSI:468  (BL, E): the write-bound MFMA kernel
     else:
         delta = torch.matmul(x_dbl[:, :R], w_dt.t())

@@ -34,7 +34,7 @@ extern "C" {
                                6: aum_sum_rows (fixed-order sum of partial results);
                                7: aum_scan_tm_fwd / _bwd (time-serial selective scan on token-major activations);
                                8: aum_conv1d_tm_fwd / _bwd (the causal conv on token-major activations);
-                               9: aum_gemm_tn (the dense in_proj / out_proj GEMMs on token-major activations); aum_dtproj_tm_fwd; aum_scan_tm_ckpt_rows
+                               9: aum_gemm_tn (the dense in_proj / out_proj GEMMs on token-major activations); aum_dtproj_tm_fwd, aum_xdt_tm_fwd; aum_scan_tm_ckpt_rows
                                   (packed 16-bit state checkpoints of the token-major scan for 16-bit activations) */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
@@ -415,6 +415,25 @@ typedef struct AumDtProjArgs {
     int32_t dtype;
 } AumDtProjArgs;
 int aum_dtproj_tm_fwd(const AumDtProjArgs* args, void* stream);
+
+/*
+ * x_proj and dt_proj of the token-major block in one pass over conv_out (ABI 9; selective_scan_interface.py:467-468 without their
+ * transposes): x_dbl = u . x_proj.weight^T, delta = x_dbl[:, :rank] . dt_proj.weight^T (bias and softplus stay in the scan).
+ *   u: (ntok, dim) rows of pitch ldu (conv_out);  wx: (ncols, dim) pitch ldwx;  wdt: (dim, rank) pitch ldwdt;
+ *   x_dbl (out): (ntok, ncols) pitch ldx;  delta (out): (ntok, dim) pitch ldd.  Pitches in ELEMENTS, all tensors `dtype` (AUM_BF16 / AUM_F16).
+ *   Built for ncols == 80 (dt_rank + 2 d_state of AuM-Base), dim % 128 == 0, dim <= 1536, rank % 8 == 0, rank <= 64, pitches % 8 == 0,
+ *   16-byte aligned pointers; anything else AUM_E_UNSUPPORTED (callers use a GEMM for x_dbl and aum_dtproj_tm_fwd).  delta is computed from
+ *   the ROUNDED x_dbl, as the two separate products do.
+ */
+typedef struct AumXdtArgs {
+    const void *u, *wx, *wdt;
+    void *x_dbl, *delta;
+    int64_t ntok;
+    int32_t dim, rank, ncols;
+    int32_t ldu, ldwx, ldwdt, ldx, ldd;
+    int32_t dtype;
+} AumXdtArgs;
+int aum_xdt_tm_fwd(const AumXdtArgs* args, void* stream);
 
 /* Self-tests and calibration (used by tests/ and bench.py; not part of the reference's surface). */
 int aum_abi_version(void);

@@ -50,3 +50,33 @@ extern "C" int aum_dtproj_tm_fwd(const AumDtProjArgs* p, void*) {
     else run(aum::f16_t{});
     return AUM_OK;
 }
+
+// aum_xdt_tm_fwd on host pointers: same arrangement (shared argument rules; x_dbl rounded once, delta from the rounded x_dbl).
+#include "../../audio-mamba-aum_amd/csrc/xdt_args.h"
+extern "C" int aum_xdt_tm_fwd(const AumXdtArgs* p, void*) {
+    const int rc = aumx::xdt_check(p);
+    if (rc != AUM_OK) return rc;
+    auto run = [&](auto tag) {
+        using T = decltype(tag);
+        const T* u = static_cast<const T*>(p->u);
+        const T* wx = static_cast<const T*>(p->wx);
+        const T* wd = static_cast<const T*>(p->wdt);
+        T* x = static_cast<T*>(p->x_dbl);
+        T* d = static_cast<T*>(p->delta);
+        for (int64_t t = 0; t < p->ntok; ++t) {
+            for (int c = 0; c < p->ncols; ++c) {
+                float acc = 0.f;
+                for (int k = 0; k < p->dim; ++k) acc += aum::elem_to_f32(u[t * p->ldu + k]) * aum::elem_to_f32(wx[(int64_t)c * p->ldwx + k]);
+                aum::f32_to_elem(acc, x[t * p->ldx + c]);
+            }
+            for (int e = 0; e < p->dim; ++e) {
+                float acc = 0.f;
+                for (int k = 0; k < p->rank; ++k) acc += aum::elem_to_f32(x[t * p->ldx + k]) * aum::elem_to_f32(wd[(int64_t)e * p->ldwdt + k]);
+                aum::f32_to_elem(acc, d[t * p->ldd + e]);
+            }
+        }
+    };
+    if (p->dtype == AUM_BF16) run(aum::bf16_t{});
+    else run(aum::f16_t{});
+    return AUM_OK;
+}

@@ -58,6 +58,7 @@ def test_struct_layouts_match_header(tmp_path):
         "AumConvTmArgs": (aum_hip.ConvTmArgs, ["x", "dy", "weight", "bias", "y", "dx", "dw_part", "db_part", "x_bs", "dx_ts", "batch", "width",
                                                "dtype", "flags"]),
         "AumDtProjArgs": (aum_hip.DtProjArgs, ["x", "w", "out", "ntok", "dim", "rank", "ldx", "ldw", "ldo", "dtype"]),
+        "AumXdtArgs": (aum_hip.XdtArgs, ["u", "wx", "wdt", "x_dbl", "delta", "ntok", "dim", "rank", "ncols", "ldu", "ldwx", "ldwdt", "ldx", "ldd", "dtype"]),
         "AumGemmArgs": (aum_hip.GemmArgs, ["a", "b", "c", "m", "n", "k", "lda", "ldb", "ldc", "dtype", "flags"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']

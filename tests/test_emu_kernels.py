@@ -253,3 +253,8 @@ def test_dtproj_tm_contract(emu, case):
     """the host build's aum_dtproj_tm_fwd (a plain loop behind the shared argument rules) keeps the contract the GPU tests hold the MFMA
     kernel to: only the first dt_rank columns of the x_dbl rows enter the product, fp32 accumulation, one rounding"""
     KC.check_dtproj(emu, "cpu", *case, torch.bfloat16)
+
+
+def test_xdt_tm_contract(emu):
+    """the host build's aum_xdt_tm_fwd (plain loops behind the shared argument rules): x_dbl rounded once, delta from the rounded x_dbl"""
+    KC.check_xdt(emu, "cpu", 33, 128, 24, torch.bfloat16)

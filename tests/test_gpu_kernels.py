@@ -502,3 +502,25 @@ def test_gemm_tn_random_shapes(lib):
         pad_a, pad_c = 8 * rnd.randint(0, 3), 8 * rnd.randint(0, 3)
         flags = rnd.choice([0, aum_hip.GEMM_PERSISTENT, aum_hip.GEMM_LOCKSTEP, aum_hip.GEMM_STAGGERED])
         KC.check_gemm(lib, "cuda", (f"rnd{it}_{m}_{n}_{k}", m, n, k, pad_a, pad_c), torch.bfloat16, flags=flags)
+
+
+@pytest.mark.parametrize("case", cases.XDT_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_xdt_tm(lib, case, dtype):
+    KC.check_xdt(lib, "cuda", *case, dtype)
+
+
+def test_xdt_tm_headline_shape(lib):
+    """the bench's own launch (64 x 513 tokens, d_inner 1536, dt_rank 48): x_dbl and delta of every token against the library's fp32
+    products of the same operands, bitwise repeatable"""
+    torch.manual_seed(4)
+    u = torch.randn(64 * 513, 1536, device="cuda").bfloat16()
+    wx = (torch.randn(80, 1536, device="cuda") / 1536 ** 0.5).bfloat16()
+    wdt = (torch.randn(1536, 48, device="cuda") / 48 ** 0.5).bfloat16()
+    x_dbl, delta = aum_hip.xdt_tm_fwd(u, wx, wdt, lib=lib)
+    rx = u.float() @ wx.float().t()
+    assert (x_dbl.float() - rx).abs().max().item() <= 1.01 * 2.0 ** -8 * rx.abs().max().item()
+    rd = x_dbl[:, :48].float() @ wdt.float().t()
+    assert (delta.float() - rd).abs().max().item() <= 1.01 * 2.0 ** -8 * rd.abs().max().item()
+    x2, d2 = aum_hip.xdt_tm_fwd(u, wx, wdt, lib=lib)
+    assert torch.equal(x_dbl, x2) and torch.equal(delta, d2)
