@@ -658,7 +658,7 @@ def xdt_tm_supported(u, wx, wdt):
         return False
     dim, rank = u.shape[1], wdt.shape[1]
     ok_t = lambda t: t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
-    return (wx.shape == (XDT_COLS, dim) and wdt.shape[0] == dim and dim % 128 == 0 and dim <= XDT_MAX_DIM and rank % 8 == 0 and rank <= 64
+    return (wx.shape == (XDT_COLS, dim) and wdt.shape[0] == dim and dim % 256 == 0 and dim <= XDT_MAX_DIM and rank % 8 == 0 and rank <= 64
             and ok_t(u) and ok_t(wx) and ok_t(wdt))
 
 

@@ -10,7 +10,7 @@
 // (v_mfma_f32_16x16x32: rows = x_dbl columns, columns = tokens), rounds them into an LDS tile of its own -- from which x_dbl leaves in
 // 16-byte pieces and the dt block comes back as the MFMA B operand -- and then streams W_dt through the same LDS space in two channel
 // halves, storing delta 64 contiguous bytes per token row and instruction (the store layout of dtproj_kernels.h).
-// u is fetched 32 contiguous bytes per lane (a full 128-byte line per token row and K-step of 64) two steps ahead of its use; the k
+// u is fetched 32 contiguous bytes per lane (a full 128-byte line per token row and K-step of 64) four K-steps ahead of its use; the k
 // order inside a step is permuted the same way on both operands (lane group kg holds k0 + 16 kg .. + 15), which the product does not see.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -109,35 +109,36 @@ __global__ __launch_bounds__(XDT_WAVES * 64, 1) void k_xdt_tm_fwd(AumXdtArgs g) 
             uf[tf][1] = tok_ok[tf] ? *reinterpret_cast<const s8v*>(urow[tf] + (int64_t)k0 * 2 + 16) : zero;
         }
     };
-    const int nsteps = KH / 64;
-    s8v uf[NTF][2], u1[NTF][2], un[NTF][2];          // this step's u, the next step's, the one after that (requested two steps ahead)
-    load_u(0, uf);
-    if (64 < E) load_u(64, u1);
-    for (int half = 0; half < 2; ++half) {
-        __syncthreads();                                             // everybody is done with the previous contents of the slab
-        stage_rows(slab, SP, static_cast<const char*>(g.wx) + (int64_t)half * KH * 2, (int64_t)g.ldwx * 2, XDT_COLS, KH / 8, tid);
-        __syncthreads();
-        const char* wrd = slab + rho * SP + kg * 32;                 // + f * 16 rows, + step * 128 bytes
-        for (int s = 0; s < nsteps; ++s) {
-            const int kn = half * KH + (s + 2) * 64;                 // two steps ahead (also across the half boundary)
-            if (kn < E) load_u(kn, un);
+    // conv_out rows arrive through a ring of four register sets indexed by the (unrolled) step: a set is refilled, four steps ahead, right
+    // after the MFMAs that read it were issued.  (Rotating three sets through register copies -- the first version -- made every copy wait
+    // for its load: the prefetch distance collapsed to one step.)
+    const int nsteps = KH / 64, total = E / 64;               // steps per K-half; dim % 256 == 0 -> total % 4 == 0
+    s8v ur[4][NTF][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < total) load_u(j * 64, ur[j]);
+    const char* wrd = slab + rho * SP + kg * 32;              // + f * 16 rows, + step-in-half * 128 bytes
+    for (int s0 = 0; s0 < total; s0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int s = s0 + j;
+            if (s == 0 || s == nsteps) {                      // a K-half of W_x through LDS
+                __syncthreads();                              // everybody is done with the previous contents of the slab
+                stage_rows(slab, SP, static_cast<const char*>(g.wx) + (int64_t)(s / nsteps) * KH * 2, (int64_t)g.ldwx * 2, XDT_COLS, KH / 8, tid);
+                __syncthreads();
+            }
+            const int sl = s >= nsteps ? s - nsteps : s;
 #pragma unroll
             for (int f = 0; f < NCF; ++f) {
-                const s8v w0 = *reinterpret_cast<const s8v*>(wrd + f * 16 * SP + s * 128);
-                const s8v w1 = *reinterpret_cast<const s8v*>(wrd + f * 16 * SP + s * 128 + 16);
+                const s8v w0 = *reinterpret_cast<const s8v*>(wrd + f * 16 * SP + sl * 128);
+                const s8v w1 = *reinterpret_cast<const s8v*>(wrd + f * 16 * SP + sl * 128 + 16);
 #pragma unroll
                 for (int tf = 0; tf < NTF; ++tf) {
-                    acc[tf][f] = mfma<BF16>(w0, uf[tf][0], acc[tf][f]);
-                    acc[tf][f] = mfma<BF16>(w1, uf[tf][1], acc[tf][f]);
+                    acc[tf][f] = mfma<BF16>(w0, ur[j][tf][0], acc[tf][f]);
+                    acc[tf][f] = mfma<BF16>(w1, ur[j][tf][1], acc[tf][f]);
                 }
             }
-#pragma unroll
-            for (int tf = 0; tf < NTF; ++tf)
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    uf[tf][h2] = u1[tf][h2];
-                    u1[tf][h2] = un[tf][h2];
-                }
+            if (s + 4 < total) load_u((s + 4) * 64, ur[j]);
         }
     }
     // ---- the wave's x_dbl tile: rounded once, [token][column] in LDS; x_dbl leaves from there in 16-byte pieces --------------------

@@ -338,4 +338,4 @@ GEMM_FULL_CASES = [(70000, 512, 192), (64 * 513, 3072, 768), (64 * 513, 768, 153
 DTPROJ_CASES = [(1, 64, 8, 40), (33, 96, 24, 56), (129, 256, 48, 80), (513, 1536, 48, 80), (200, 768, 24, 56), (70, 128, 64, 96), (31, 32, 16, 48)]
 
 # aum_xdt_tm_fwd (ABI 9): (ntok, dim, dt_rank) -- ragged token tiles (128 per workgroup, 32 per wave), one and two dt K-steps, every dim class
-XDT_CASES = [(1, 128, 8), (33, 256, 24), (127, 384, 48), (129, 768, 32), (513, 1536, 48), (300, 1024, 64)]
+XDT_CASES = [(1, 256, 8), (33, 256, 24), (127, 512, 48), (129, 768, 32), (513, 1536, 48), (300, 1024, 64)]
