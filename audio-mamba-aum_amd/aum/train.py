@@ -377,11 +377,9 @@ def train(model, train_loader, val_loader, args, D):
                 if finite.item() == 0.0:
                     if args.if_continue_inf:
                         D.print("Loss is not finite on some rank, continuing training")
-                        # every forward of the wrapper gets its backward (a zero loss, no exchange): the reducer's per-iteration
-                        # bookkeeping stays in step on all ranks; this path is also why static_graph is off without --if_nan2num
-                        if D.world > 1:
-                            with net.no_sync():
-                                (out.float().sum() * 0.0).backward()
+                        # the step is skipped on EVERY rank (the flag was MIN-reduced): no backward, so no gradient exchange is started
+                        # -- a DDP forward without a backward is legal while static_graph is off, which is why it is off without
+                        # --if_nan2num -- and nothing non-finite reaches the buckets
                         optimizer.zero_grad()
                         continue
                     D.print("Loss is not finite on some rank, stopping training")

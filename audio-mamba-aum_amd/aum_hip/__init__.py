@@ -544,8 +544,24 @@ def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_
     dev = u.device
     for t in (u, delta, z, B, C, dout, out_pre, ckpt):
         lib.check_tensor(t)
+    # the kernel is told ONE element type: a tensor of another one would be read past its end (e.g. a 16-bit dout under fp32 rows)
+    if u.dtype not in _DT:
+        raise RuntimeError("u must be fp32, bf16 or fp16")
+    for name, t in (("delta", delta), ("z", z), ("B", B), ("C", C), ("dout", dout), ("out_pre", out_pre), ("dz_out", dz_out)):
+        if t is not None and t.dtype != u.dtype:
+            raise RuntimeError(f"{name} must have u's dtype ({u.dtype}), got {t.dtype}")
+    for name, t in (("delta", delta), ("z", z), ("dout", dout), ("out_pre", out_pre), ("dz_out", dz_out)):
+        if t is not None and tuple(t.shape) != (batch, length, dim):
+            raise RuntimeError(f"{name}: expected shape {(batch, length, dim)}, got {tuple(t.shape)}")
+    if z is not None and out_pre is None:
+        raise RuntimeError("out_pre (the forward's pre-gate sum) is required when z is given")
     A, A_b, D, delta_bias = _f32c(A), _f32c(A_b), _f32c(D), _f32c(delta_bias)
     bidir = A_b is not None
+    if ckpt is None or ckpt.dtype != torch.float32 or not ckpt.is_contiguous():
+        raise RuntimeError("ckpt: the contiguous fp32 tensor scan_tm_fwd filled")
+    rows_ = int(lib.c.aum_scan_tm_ckpt_rows(_DT[u.dtype])) if dstate == 16 else dstate
+    if ckpt.numel() < (2 if bidir else 1) * batch * max(int(lib.c.aum_scan_tm_nck(length)), 1) * rows_ * dim:
+        raise RuntimeError("ckpt too small for this launch")
     du = torch.empty((batch, length, dim), dtype=u.dtype, device=dev)
     ddelta = torch.empty((batch, length, dim), dtype=u.dtype, device=dev)
     dz = None
@@ -576,7 +592,6 @@ def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_
         a.z_bs, a.z_ts = _tm3(z, "z", dim)
         a.pre_bs, a.pre_ts = _tm3(out_pre, "out_pre", dim)
         a.dz_bs, a.dz_ts = _tm3(dz, "dz", dim)
-    assert ckpt.dtype == torch.float32 and ckpt.is_contiguous()
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
     a.flags = (SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0)
     _launch(lib.c.aum_scan_tm_bwd, a, u, lib, "scan_tm_bwd_bidir" if bidir else "scan_tm_bwd", (batch, dim, length, dstate, u.element_size(), True))

@@ -1,5 +1,6 @@
 // gemm.hip -- translation unit of the plain-HIP MFMA kernels: the dense projection GEMM (gemm_kernels.h, aum_gemm_tn) and the dt projection of
 // the token-major block (dtproj_kernels.h, aum_dtproj_tm_fwd); include/aum_hip.h, ABI 9.
+#include <atomic>
 #include "gemm_kernels.h"
 #include "dtproj_kernels.h"
 #include "xdt_kernels.h"
@@ -10,13 +11,17 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
     const AumGemmArgs& g = *p;
     const int tiles = (g.m + aumg::BM - 1) / aumg::BM * (g.n / aumg::BN);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static int ncu = 0;
+    // CU count of the CURRENT device (one process may drive several devices from several threads): a small per-device cache, filled
+    // with relaxed atomics -- racing fillers write the same value
+    static std::atomic<int> ncu_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return AUM_E_LAUNCH;
+    int ncu = ncu_of[dev].load(std::memory_order_relaxed);
     if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return AUM_E_LAUNCH;
-        ncu = prop.multiProcessorCount;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) return AUM_E_LAUNCH;
+        ncu_of[dev].store(ncu, std::memory_order_relaxed);
     }
+    (void)hipGetLastError();        // a stale error of an earlier, unrelated launch must not be reported as this one's
     // Which kernel: the persistent one pays off when a CU gets several tiles (cheap ragged row block, next tile prefetched under the stores:
     // 774 / 1548 tiles at N = 1536 / 3072: 84.6 vs 94.2 us, 158.6 vs 169.1 us); with at most two tiles per CU (N = 768: 387 tiles) one
     // workgroup per tile is as fast or faster (84.3 vs 87.4 us, 159.4 vs 162.2 us).  profiles/r03_gemm_probe.txt

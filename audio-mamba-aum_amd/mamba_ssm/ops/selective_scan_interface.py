@@ -500,7 +500,7 @@ def _inner_backward_tm(ctx, dout):
     dout_proj_weight = dout_proj_bias = None
     if ctx.has_out_proj:
         dout2 = dout.reshape(Bsz * L, -1).to(out_proj_weight.dtype)
-        dout_z = _gemm_dgrad(dout2, out_proj_weight, out_proj_wt, 4).view(Bsz, L, E)         # SSI:540
+        dout_z = _gemm_dgrad(dout2, out_proj_weight, out_proj_wt, 4).view(Bsz, L, E).to(conv_out.dtype)     # SSI:540
         dout_proj_weight = split_k_wgrad(dout2.t(), out_z.view(Bsz * L, E), _pick_splits(dout2.shape[0], _WGRAD_SPLITS[1]),
                                          ctx.out_proj_wdtype)                                 # SSI:563
         dout_proj_bias = dout2.sum(0) if not ctx.out_proj_bias_is_None else None
@@ -510,8 +510,6 @@ def _inner_backward_tm(ctx, dout):
     x3 = x_dbl.view(Bsz, L, R + 2 * N)
     g = aum_hip.scan_tm_bwd(conv_out, delta.view(Bsz, L, E), A, x3[:, :, R:R + N], x3[:, :, R + N:], D, z, delta_bias, dout_z, out_pre,
                             ckpt, ctx.delta_softplus, ctx.reverse if A_b is None else False, A_b=A_b, dz_out=dz)   # SSI:541-561
-    if _REF_DZ_DROP and A_b is not None:
-        raise NotImplementedError("AUM_REF_DZ_DROP reproduces SSI:560/599 on the channel-major path only (AUM_TOKEN_MAJOR=0)")
     du2, ddelta2 = g["du"].view(Bsz * L, E), g["ddelta"].view(Bsz * L, E)
     dx_dbl = torch.empty_like(x_dbl)
     dx_dbl[:, R:].copy_(g["dBC"].view(Bsz * L, 2 * N))                                       # SSI:570-574
@@ -542,7 +540,9 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     if A.is_complex():
         raise NotImplementedError("real A only (SSI:502 asserts the same for the bidirectional path)")
     ctx.tm = False
-    if (TOKEN_MAJOR and _is_tm(xz) and B_proj_bias is None and C_proj_bias is None and xz.stride(2) == xz.shape[1]
+    # (AUM_REF_DZ_DROP needs the two directions' gate inputs separately: only the channel-major block keeps them, so the option selects it)
+    if (TOKEN_MAJOR and not (_REF_DZ_DROP and A_b is not None) and _is_tm(xz) and B_proj_bias is None and C_proj_bias is None
+            and xz.stride(2) == xz.shape[1]
             and token_major_ok(xz.shape[1] // 2, A.shape[-1], conv1d_weight.shape[-1], delta_proj_weight.shape[1], xz.dtype)
             and aum_hip.conv1d_tm_supported(xz.transpose(1, 2)[:, :, :xz.shape[1] // 2], conv1d_weight.shape[-1])):
         return _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,

@@ -412,7 +412,60 @@ def headline_goldens(torch, ssi, ln):
 
 
 
+def headline_bf16_goldens(torch, ssi, ln):
+    """The SAME-PRECISION pin of the headline configuration: the reference's AudioMamba at BASELINE configs 3 and 2
+    run under torch.autocast(bfloat16) on CPU -- the projections (F.linear / matmul) and the conv round to bf16 exactly where the
+    reference's autocast run does (SSI:452-457 casts the projection weights, the activations between the ops are 16-bit), while the
+    selective scan keeps its fp32 interior: on the GPU `selective_scan_cuda` computes in fp32 whatever the I/O type and
+    MambaInnerFn.forward is `custom_fwd` (autocast disabled inside), so `selective_scan_ref` (which upcasts at SSI:101-107) is called
+    with autocast switched off around it -- otherwise its contracting einsums would be autocast to bf16 bmm, which no GPU run of the
+    reference does.  Written to headline_bf16.npz next to the fp32 pin (headline.npz) of the same seeded parameters and inputs."""
+    import contextlib
+    import io
+    import time
+    ref_scan = ssi.selective_scan_ref
+
+    def scan_fp32_interior(*a, **k):
+        with torch.autocast("cpu", enabled=False):
+            return ref_scan(*a, **k)
+
+    ssi.selective_scan_fn = scan_fp32_interior
+    mm = import_reference_model(torch, ssi, ln)
+    out = {}
+    for case in cases.HEADLINE_CASES:
+        name, btype, depth, dim, spec, ncls, batch, bwd = case
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = mm.AudioMamba(spectrogram_size=spec, depth=depth, embed_dim=dim, num_classes=ncls, bimamba_type=btype)
+        sd = model.state_dict()
+        vals = cases.model_state({k: tuple(v.shape) for k, v in sd.items()}, name)
+        model.load_state_dict({k: torch.tensor(v) for k, v in vals.items()})
+        d = cases.model_inputs(*case[:7])
+        with (contextlib.nullcontext() if bwd else torch.no_grad()):
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                logits = model(torch.tensor(d["x"]))
+        out[name + ".logits"] = npy(logits)
+        out[name + ".logits_dtype"] = np.array(str(logits.dtype))
+        if bwd:
+            (logits.float() * torch.tensor(d["dlogits"])).sum().backward()
+            for k, p in model.named_parameters():
+                g = npy(p.grad)
+                out[name + ".gnorm." + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+                if p.numel() <= 1024:
+                    out[name + ".grad." + k] = g
+        out[name + ".checksum"] = cases.checksum(dict(vals, **d))
+        print(name, "bf16 autocast done in %.0f s" % (time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(HERE, "headline_bf16.npz"), **out)
+    print("headline_bf16.npz", len(out))
+
+
 if __name__ == "__main__":
+    if os.path.isdir(REF) and "--headline-bf16" in sys.argv:
+        torch_, ssi_, ln_, _ = import_reference()
+        torch_.manual_seed(0)
+        torch_.set_num_threads(8)
+        headline_bf16_goldens(torch_, ssi_, ln_)
+        sys.exit(0)
     if os.path.isdir(REF) and "--headline" in sys.argv:
         torch_, ssi_, ln_, _ = import_reference()
         torch_.manual_seed(0)

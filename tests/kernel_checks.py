@@ -7,7 +7,7 @@ import torch
 
 import aum_hip
 import cases
-from conftest import rel_err
+from conftest import rel_err, rel_err_by, rms_err
 from oracle import oracle as O
 
 TOL_F32 = 1e-4      # north_star bar for fp32 is 1e-3; the kernels are held to 1e-4 of the fp64 oracle
@@ -25,6 +25,20 @@ def N(t):
 def rq(a, dtype):
     """round-trip through the activation dtype (what the kernel will see)."""
     return None if a is None else torch.tensor(np.asarray(a)).to(dtype).float().numpy()
+
+
+def _scan_errors(pairs):
+    """{name: (got, reference)} -> three errors per tensor: `name` max error over the largest reference element (rel_err), `rms:name`
+    rms error over the rms of the reference (the typical element), and for the per-state tensors `state:name` rel_err taken state by
+    state (dA column n, dB / dC row n against that state's own largest element: the late states of dA are orders of magnitude below
+    the first ones and invisible to the other two)."""
+    errs = {}
+    for k, (got, ref) in pairs.items():
+        errs[k] = rel_err(got, ref)
+        errs["rms:" + k] = rms_err(got, ref)
+        if k in ("dA", "dA_b", "dB", "dC"):
+            errs["state:" + k] = rel_err_by(got, ref, 1)
+    return errs
 
 
 def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, tol=None, strided=False, generic=False,
@@ -60,9 +74,9 @@ def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, 
     if bidir:
         rb = O.scan_fwd(q["u"], q["delta"], A_b, q["B"], q["C"], d["D"], q["z"], d["delta_bias"], softplus, True, "f64")
         ref_out, ref_pre = ref_out + rb["out"], ref_pre + rb["y_pre"]
-    errs = {"out": rel_err(N(out), ref_out), "out_pre": rel_err(N(out_pre), ref_pre)}
+    pairs = {"out": (N(out), ref_out), "out_pre": (N(out_pre), ref_pre)}
     if not bidir:
-        errs["last_state"] = rel_err(N(last), ref["last_state"])
+        pairs["last_state"] = (N(last), ref["last_state"])
     # backward
     dout = act(d["dout"])
     g = aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, out_pre if has_z else None, softplus, reverse,
@@ -80,8 +94,9 @@ def check_scan(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, 
         if gr.get(k) is None:
             assert g.get(k) is None, k
             continue
-        errs[k] = rel_err(N(g[k]), gr[k])
-    bad = {k: v for k, v in errs.items() if not (v < tol * (4 if k.startswith("d") else 1))}
+        pairs[k] = (N(g[k]), gr[k])
+    errs = _scan_errors(pairs)
+    bad = {k: v for k, v in errs.items() if not (v < tol * (4 if k.split(":")[-1].startswith("d") else 1))}
     assert not bad, (name, str(dtype), "rev" if reverse else "fwd", "bidir" if bidir else "uni", bad, errs)
     return errs
 
@@ -294,10 +309,10 @@ def check_scan_tm(lib, dev, case, dtype=torch.float32, reverse=False, bidir=Fals
         rb = O.scan_fwd(q["u"], q["delta"], A_b, q["B"], q["C"], d["D"], q["z"], d["delta_bias"], softplus, True, "f64")
         ref_out, ref_pre = ref_out + rb["out"], ref_pre + rb["y_pre"]
     cm = lambda t: N(t).transpose(0, 2, 1)
-    errs = {"out": rel_err(cm(out), ref_out), "out_pre": rel_err(cm(out_pre), ref_pre)}
+    pairs = {"out": (cm(out), ref_out), "out_pre": (cm(out_pre), ref_pre)}
     out2, none = aum_hip.scan_tm_fwd(u, delta, A, Bm, Cm, D, z, bias, softplus, reverse, T(A_b, dev), lib=lib)    # inference form
     assert none is None
-    errs["out_nopre"] = rel_err(cm(out2), ref_out)
+    pairs["out_nopre"] = (cm(out2), ref_out)
     if backward:
         g = aum_hip.scan_tm_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, out_pre if has_z else None, ck, softplus, reverse, T(A_b, dev), lib=lib)
         gr = O.scan_bwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus, reverse, "f64")
@@ -314,10 +329,118 @@ def check_scan_tm(lib, dev, case, dtype=torch.float32, reverse=False, bidir=Fals
             if gr.get(k) is None:
                 assert got.get(k) is None, k
                 continue
-            errs[k] = rel_err(got[k], gr[k])
-    bad = {k: v for k, v in errs.items() if not (v < tol * (4 if k.startswith("d") else 1))}
+            pairs[k] = (got[k], gr[k])
+    errs = _scan_errors(pairs)
+    bad = {k: v for k, v in errs.items() if not (v < tol * (4 if k.split(":")[-1].startswith("d") else 1))}
     assert not bad, (name, str(dtype), "rev" if reverse else "fwd", "bidir" if bidir else "uni", bad, errs)
     return errs
+
+
+def _tm_rows_vs_oracle(O, b, es, u, dl, z, Bm, Cm, A, A_b, D, bias, dout, softplus=True):
+    """fp64 oracle on channels `es` of batch entry `b` of token-major tensors: both directions summed (A_b None: forward only)"""
+    f = lambda t: t.float().cpu().numpy()
+    rows = lambda t: np.ascontiguousarray(f(t[b][:, es]).T[None])            # (1, rows, L)
+    bc = lambda t: np.ascontiguousarray(f(t[b]).T[None])                     # (1, N, L)
+    args = (rows(u), rows(dl))
+    Aq, Dq, bq = f(A[es]), f(D[es]), f(bias[es])
+    zq = rows(z)
+    fw = O.scan_fwd(*args, Aq, bc(Bm), bc(Cm), Dq, zq, bq, softplus, False, "f64")
+    out, pre = fw["out"], fw["y_pre"]
+    gr = None
+    if dout is not None:
+        gr = O.scan_bwd(*args, Aq, bc(Bm), bc(Cm), Dq, zq, bq, rows(dout), softplus, False, "f64")
+    if A_b is not None:
+        rb = O.scan_fwd(*args, f(A_b[es]), bc(Bm), bc(Cm), Dq, zq, bq, softplus, True, "f64")
+        out, pre = out + rb["out"], pre + rb["y_pre"]
+        if dout is not None:
+            gb = O.scan_bwd(*args, f(A_b[es]), bc(Bm), bc(Cm), Dq, zq, bq, rows(dout), softplus, True, "f64")
+            for k in ("du", "ddelta", "dz", "dB", "dC", "dD", "ddelta_bias"):
+                gr[k] = gr[k] + gb[k]
+            gr["dA_b"] = gb["dA"]
+    return out, pre, gr
+
+
+def check_scan_tm_grid(lib, dev, Bsz, L, E, rows, entries, chans, split):
+    """The token-major Fo-Bi scan pair (k_scant_fwd / k_scant_bwd) at a whole launch of (Bsz, L, E), N = 16, bf16, the block's row layouts (z = second half of [x | z] rows, B / C = column blocks of 80-column x_dbl rows), batch-
+    distinct random data -- against the ORACLE, not against themselves (the pattern of test_scan_headline_grid_b64):
+    (i) sampled (batch entry, channel) rows of out, out_pre, du, ddelta, dz vs the fp64 oracle on exactly those rows, both
+    directions summed (lanes 0 / 63, wave and workgroup boundaries, the carries that change waves in the backward's three-stage
+    workgroups, the last unit); (ii) dB | dC of sampled batch entries vs the oracle summed over ALL 1 536 channels of the entry;
+    (iii) dA, dA_b, dD, ddelta_bias of sampled channels vs the oracle over all 64 batch entries of those channels, and the whole
+    tensors vs the sum of eight B = 8 launches (a batch-index error in a checkpoint row, a partial row or a b * stride shows up in
+    every one of the three)."""
+    torch.manual_seed(5)
+    N, R = 16, 48
+    bf = lambda t: t.bfloat16()
+    xz = bf(torch.randn(Bsz, L, 2 * E, device=dev))
+    u, z = bf(torch.randn(Bsz, L, E, device=dev)), xz[:, :, E:]
+    dl = bf(0.5 * torch.randn(Bsz, L, E, device=dev))
+    x_dbl = bf(torch.randn(Bsz, L, R + 2 * N, device=dev))
+    Bm, Cm = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:]
+    A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(E, 1) * (1 + 0.1 * torch.rand(E, N, device=dev))
+    A_b = A * (1 + 0.1 * torch.rand(E, N, device=dev))
+    D, bias = torch.rand(E, device=dev) + 0.5, torch.full((E,), -4.0, device=dev) + torch.rand(E, device=dev)
+    dout = bf(torch.randn(Bsz, L, E, device=dev))
+    ck = aum_hip.scan_tm_ckpt(Bsz, L, E, N, True, dev, dtype=torch.bfloat16)
+    ck.fill_(float("nan"))
+    out, pre = aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, ckpt=ck, lib=lib)
+    g = aum_hip.scan_tm_bwd(u, dl, A, Bm, Cm, D, z, bias, dout, pre, ck, True, A_b=A_b, lib=lib)
+    f = lambda t: t.float().cpu().numpy()
+    worst = {}
+
+    def note(k, e, bar):
+        worst[k] = max(worst.get(k, 0.0), e)
+        assert e < bar, (k, e, bar)
+    # (i) units are (batch entry, 64-channel group) numbered batch-major, 24 groups per entry; forward workgroups take 2 units, backward
+    # workgroups 3 pairs (X, Y, Z: Y's carries cross waves): sample every residue of the unit number mod 2 and mod 3, lane 0 / 63 of a
+    # group, the first and the last unit
+    for b, es in rows.items():
+        ro, rp, gr = _tm_rows_vs_oracle(O, b, es, u, dl, z, Bm, Cm, A, A_b, D, bias, dout)
+        sl = lambda t: f(t[b][:, es]).T[None]
+        note("out", rel_err(sl(out), ro), TOL_BF16)
+        note("out_pre", rel_err(sl(pre), rp), TOL_BF16)
+        note("rms:out", rms_err(sl(out), ro), TOL_BF16)
+        for k in ("du", "ddelta", "dz"):
+            note(k, rel_err(sl(g[k]), gr[k]), 4 * TOL_BF16)
+            note("rms:" + k, rms_err(sl(g[k]), gr[k]), 4 * TOL_BF16)
+    # (ii) dB | dC: the sum over all channels and both directions of one batch entry
+    allch = list(range(E))
+    for b in entries:
+        _, _, gr = _tm_rows_vs_oracle(O, b, allch, u, dl, z, Bm, Cm, A, A_b, D, bias, dout)
+        got = f(g["dBC"][b])                                   # (L, 2N)
+        for k, blk in (("dB", got[:, :N]), ("dC", got[:, N:])):
+            ref = gr[k][0].T                                   # (L, N)
+            note(k, rel_err(blk, ref), 4 * TOL_BF16)
+            note("rms:" + k, rms_err(blk, ref), 4 * TOL_BF16)
+            note("state:" + k, rel_err_by(blk, ref, 1), 4 * TOL_BF16)
+    # (iii) batch-summed parameter gradients of sampled channels: the oracle over all 64 entries
+    es = list(chans)
+    acc = None
+    for b in range(Bsz):
+        _, _, gr = _tm_rows_vs_oracle(O, b, es, u, dl, z, Bm, Cm, A, A_b, D, bias, dout)
+        cur = {k: gr[k] for k in ("dA", "dA_b", "dD", "ddelta_bias")}
+        acc = cur if acc is None else {k: acc[k] + cur[k] for k in acc}
+    for k in acc:
+        note(k, rel_err(f(g[k][es]), acc[k]), 4 * TOL_BF16)
+        if k in ("dA", "dA_b"):
+            note("state:" + k, rel_err_by(f(g[k][es]), acc[k], 1), 4 * TOL_BF16)
+    # ... and the whole tensors against eight B = 8 launches (fp32 reassociation only)
+    acc8 = {k: torch.zeros_like(g[k]) for k in ("dA", "dA_b", "dD", "ddelta_bias")}
+    for b0 in range(0, Bsz, split):
+        s8 = lambda t: t[b0:b0 + split]
+        ck8 = aum_hip.scan_tm_ckpt(split, L, E, N, True, dev, dtype=torch.bfloat16)
+        o8, p8 = aum_hip.scan_tm_fwd(s8(u), s8(dl), A, s8(Bm), s8(Cm), D, s8(z), bias, True, A_b=A_b, want_out_pre=True, ckpt=ck8, lib=lib)
+        assert torch.equal(o8, out[b0:b0 + split]) and torch.equal(p8, pre[b0:b0 + split]), b0
+        g8 = aum_hip.scan_tm_bwd(s8(u), s8(dl), A, s8(Bm), s8(Cm), D, s8(z), bias, s8(dout), p8, ck8, True, A_b=A_b, lib=lib)
+        for k in ("du", "ddelta", "dz", "dBC"):
+            assert torch.equal(g8[k], g[k][b0:b0 + split]), (b0, k)
+        for k in acc8:
+            acc8[k] += g8[k]
+    for k in acc8:
+        assert (acc8[k] - g[k]).abs().max() <= 1e-4 * g[k].abs().max(), k
+    return worst
+
+
 
 
 def check_gemm(lib, dev, case, dtype, flags=0):

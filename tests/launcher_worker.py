@@ -13,6 +13,20 @@ if __name__ == "__main__":
     aum_hip._product = aum_hip.Lib(build_emu.build(), host=True)
     import json
     from aum import train
+    # tests only: make the loss of rank AUM_TEST_NAN_RANK non-finite at the listed training steps (test_launcher_two_ranks_gloo_nan_steps)
+    nan_steps = {int(x) for x in os.environ.get("AUM_TEST_NAN_STEPS", "").split(",") if x}
+    if nan_steps and os.environ.get("RANK", "0") == os.environ.get("AUM_TEST_NAN_RANK", "1"):
+        real_loss, calls = train._loss, {"n": 0}
+
+        def poisoned(loss_fn, out, labels):
+            import torch
+            loss = real_loss(loss_fn, out, labels)
+            if torch.is_grad_enabled():                      # training steps only (validation runs under no_grad)
+                if calls["n"] in nan_steps:
+                    loss = loss * float("nan")
+                calls["n"] += 1
+            return loss
+        train._loss = poisoned
     train.main(sys.argv[1:])
     exp = sys.argv[sys.argv.index("--exp-dir") + 1]
     with open(os.path.join(exp, f"host_syncs_rank{os.environ.get('RANK', '0')}.json"), "w") as f:

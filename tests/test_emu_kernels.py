@@ -258,3 +258,11 @@ def test_dtproj_tm_contract(emu, case):
 def test_xdt_tm_contract(emu):
     """the host build's aum_xdt_tm_fwd (plain loops behind the shared argument rules): x_dbl rounded once, delta from the rounded x_dbl"""
     KC.check_xdt(emu, "cpu", 33, 256, 24, torch.bfloat16)
+
+
+def test_scan_tm_grid_small(emu):
+    """the whole-launch oracle check of test_gpu_kernels.py::test_scan_tm_headline_grid_b64 (sampled rows, whole-entry dB | dC, batch-
+    summed parameter gradients, batch splits) on a launch small enough for the lane-array build: 5 entries x 3 channel groups = 15
+    units -> forward workgroups of 2 and backward workgroups of 3 pairs, both with a ragged last workgroup"""
+    rows = {0: [0, 63, 64, 191], 1: [5, 100], 2: [128, 127], 4: [0, 191, 77]}
+    KC.check_scan_tm_grid(emu, "cpu", 5, 41, 192, rows, (0, 4), [0, 63, 64, 191], 1)

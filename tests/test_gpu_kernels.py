@@ -1,5 +1,6 @@
 """GPU parity tests proper: the product library libaum_hip.so (hand-written gfx950 kernels, called through the
 C ABI) against the oracle on the same seeded inputs.  Run with -m gpu on an MI355X."""
+import numpy as np
 import pytest
 import torch
 
@@ -384,6 +385,57 @@ def test_scan_tm_headline_shape(lib):
     for k in ("du", "ddelta", "dBC", "dD", "ddelta_bias"):
         assert rel(ref_b[k], gf[k].float() + gb[k].float()) < 2e-2, k
     assert rel(ref_b["dA"], gf["dA"]) < 2e-2 and rel(ref_b["dA_b"], gb["dA"]) < 2e-2 and rel(ref_b["dz"], gf["dz"]) < 2e-2
+
+
+def test_scan_tm_headline_grid_b64(lib):
+    """the dominant kernels (k_scant_fwd / k_scant_bwd) at the bench's own launch -- B = 64, E = 1536, L = 513,
+    N = 16, bf16, the block's row layouts, batch-distinct random data -- against the fp64 ORACLE (KC.check_scan_tm_grid: sampled rows
+    of out / out_pre / du / ddelta / dz, dB | dC of whole batch entries, dA / dA_b / dD / ddelta_bias of sampled channels over all 64
+    entries, the whole parameter gradients against eight B = 8 launches).  Units are (batch entry, 64-channel group) numbered
+    batch-major, 24 groups per entry; forward workgroups take 2 units, backward workgroups 3 pairs (X, Y, Z: Y's carries cross
+    waves): the sample holds every residue of the unit number mod 2 and mod 3, lanes 0 / 63 of a group, the first and the last unit."""
+    rows = {0: [0, 63, 64, 127, 128, 700], 1: [5, 64 * 7 + 1, 1535], 17: [64 * 3 + 63, 64 * 4, 64 * 5 + 17], 31: [64 * 11, 1472],
+            40: [1000, 1001], 62: [64 * 23 + 62, 3], 63: [0, 777, 1535]}
+    worst = KC.check_scan_tm_grid(lib, "cuda", 64, 513, 1536, rows, (0, 29, 63), [0, 63, 64, 500, 1023, 1535], 8)
+    print("scan_tm headline grid, worst errors:", {k: float("%.3g" % v) for k, v in sorted(worst.items())})
+
+
+def test_scan_tm_small_inference_grid_b64(lib):
+    """BASELINE config 2 at its bench batch on the dispatch the bench takes: AuM-Small, B = 64, E = 768, bf16,
+    forward only -- token-major, 56-column x_dbl rows (dt rank 24 | B | C), which xdt_tm_supported refuses, so delta comes from
+    aum_dtproj_tm_fwd and the scan runs without out_pre / checkpoints.  dt projection vs an fp64 product at that shape; sampled rows
+    of the Fo-Bi scan output vs the fp64 oracle."""
+    O = KC.O
+    torch.manual_seed(6)
+    Bsz, L, E, N, R = 64, 513, 768, 16, 24
+    dev = "cuda"
+    bf = lambda t: t.bfloat16()
+    xz = bf(torch.randn(Bsz, L, 2 * E, device=dev))
+    u, z = bf(torch.randn(Bsz, L, E, device=dev)), xz[:, :, E:]
+    x_dbl = bf(torch.randn(Bsz, L, R + 2 * N, device=dev))
+    w_dt = bf(torch.randn(E, R, device=dev) / R ** 0.5 * 0.5)
+    w_x = bf(torch.randn(R + 2 * N, E, device=dev) / E ** 0.5)
+    assert not aum_hip.xdt_tm_supported(u.reshape(-1, E), w_x, w_dt), "the fused x/dt kernel is not expected to take AuM-Small's shape"
+    x2 = x_dbl.reshape(-1, R + 2 * N)
+    assert aum_hip.dtproj_tm_supported(x2, R, w_dt)
+    dl = aum_hip.dtproj_tm_fwd(x2, R, w_dt, lib=lib).reshape(Bsz, L, E)
+    ref = x2[:, :R].double() @ w_dt.double().t()
+    err = (dl.reshape(-1, E).double() - ref).abs().max().item()
+    assert err <= 1.01 * 2.0 ** -8 * ref.abs().max().item(), err
+    Bm, Cm = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:]
+    A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(E, 1) * (1 + 0.1 * torch.rand(E, N, device=dev))
+    A_b = A * (1 + 0.1 * torch.rand(E, N, device=dev))
+    D, bias = torch.rand(E, device=dev) + 0.5, torch.full((E,), -4.0, device=dev) + torch.rand(E, device=dev)
+    out, none = aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, D, z, bias, True, A_b=A_b, lib=lib)
+    assert none is None
+    out2, _ = aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, D, z, bias, True, A_b=A_b, lib=lib)
+    assert torch.equal(out, out2)
+    f = lambda t: t.float().cpu().numpy()
+    rows = {0: [0, 63, 64, 767], 1: [1, 700], 33: [64 * 5, 64 * 5 + 63, 400], 63: [0, 383, 767]}
+    for b, es in rows.items():
+        ro, _, _ = KC._tm_rows_vs_oracle(O, b, es, u, dl, z, Bm, Cm, A, A_b, D, bias, None)
+        got = f(out[b][:, es]).T[None]
+        assert KC.rel_err(got, ro) < KC.TOL_BF16 and KC.rms_err(got, ro) < KC.TOL_BF16, (b, KC.rel_err(got, ro), KC.rms_err(got, ro))
 
 
 def test_conv_tm_headline_shape(lib):

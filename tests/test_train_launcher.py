@@ -297,6 +297,37 @@ def test_launcher_two_ranks_gloo(toy_dataset, tmp_path):
         assert hs == {"steps": 3, "loss_syncs": 1}, hs
 
 
+def test_launcher_two_ranks_gloo_nan_steps(toy_dataset, tmp_path):
+    """world_size 2 with --if_nan2num False --if_continue_inf True (TT:153-164) and ONE rank's loss non-finite at steps 0 and 2: the
+    finite flag is MIN-reduced, so both ranks skip the same steps (no rank is left waiting in the gradient all-reduce), nothing
+    non-finite reaches the parameters, the skipped steps are not counted and the run finishes with finite metrics."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp = str(tmp_path / "exp_nan")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "launcher_worker.py"),
+           "--model_type", "tiny", "--depth", "1", "--n_class", "4", "--label-csv", str(toy_dataset / "labels.csv"),
+           "--data-train", str(toy_dataset / "train.json"), "--data-val", str(toy_dataset / "val.json"),
+           "--audio_length", "64", "--num-workers", "0", "-b", "2", "--mixed_precision", "no", "--exp-dir", exp,
+           "--n-epochs", "1", "--metrics", "acc", "--loss", "CE", "--if_nan2num", "False", "--if_continue_inf", "True"]
+    env = dict(os.environ, OMP_NUM_THREADS="2", AUM_TEST_NAN_STEPS="0,2", AUM_TEST_NAN_RANK="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("Loss is not finite on some rank, continuing training") == 2, r.stdout[-2000:]
+    res = np.loadtxt(exp + "/result.csv", delimiter=",").reshape(1, 8)
+    assert np.isfinite(res).all()
+    sd = torch.load(exp + "/models/best_audio_model.pth")
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+    for r_ in (0, 1):    # 3 steps per rank, two of them skipped on BOTH ranks
+        hs = json.load(open(exp + f"/host_syncs_rank{r_}.json"))
+        assert hs["steps"] == 1, hs
+
+
 def test_tunableop_solution_file_is_seeded_per_rank(monkeypatch, tmp_path):
     """aum.tunable.enable: the recorded GEMM solutions are copied where TunableOp looks for them (file name + device
     ordinal) for this rank's ordinal and for ordinal 0 (ranks masked to one visible device); env defaults are not
