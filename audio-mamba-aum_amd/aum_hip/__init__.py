@@ -1039,11 +1039,12 @@ def selftest_wave_scan(P, S, rev=False, lib=None):
 
 
 def selftest_wave_sum32(values, lib=None):
-    """values: (32, 64) fp32 -> (2, 64): row 0 the totals in the lane order of wave_sum32 (lane l: value 2 * (l & 15) + ((l >> 4) & 1)),
-    row 1 wave_sum16 of the first 16 values (lane l: value l & 15)"""
+    """values: (32, 64) fp32 -> (4, 64): row 0 the totals in the lane order of wave_sum32 (lane l: value 2 * (l & 15) + ((l >> 4) & 1)),
+    row 1 wave_sum16 of the first 16 values, rows 2 / 3 the matrix-pipe sums (terms rounded to bf16) of values 0..15 / 16..31 (lane l:
+    value 4 * (l >> 4) + bit3(l) + 2 * bit2(l) of the tile)"""
     lib = lib or get()
     inp = values.float().contiguous()
-    out = torch.empty((2, 64), dtype=torch.float32, device=inp.device)
+    out = torch.empty((4, 64), dtype=torch.float32, device=inp.device)
     _chk(lib.c.aum_selftest_wave_sum32(_ptr(inp), _ptr(out), lib.stream(inp)), "aum_selftest_wave_sum32")
     return out
 

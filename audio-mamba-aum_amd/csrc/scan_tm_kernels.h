@@ -478,6 +478,10 @@ struct ScanTBwdOut {
     unsigned long long* trace;      // -DAUM_SCANT_TRACE builds (tools/tm_trace.py): 16 x uint64 per wave behind the partials; else unused
 };
 
+#ifndef AUM_SCANT_MSUM
+#define AUM_SCANT_MSUM 1      // 0 (A/B builds): the dB / dC channel sums of 16-bit activations on the vector ALU (wave_sum16), as in round 3;
+                              // 2 (A/B builds): a tile's two matrix instructions issued inside the sweeps as soon as their four steps exist
+#endif
 #ifndef AUM_SCANT_BABL
 #define AUM_SCANT_BABL 0      // timing experiments only (wrong results): 1 no butterflies, 2 no exponentials, 4 carries at a fixed register index,
 #endif                        // 8 no loads of the next block, 16 no entry-state loads, 32 no B/C reads from LDS
@@ -543,6 +547,14 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     const vi bc_slot = st_i * SCANT_BC_ROW + st_c * 2;
     const vi vo4 = ec * 4;
     const vi dbc_slot = (((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 4) & 1)) * SCANT_BC_ROW + ((lane >> 5) & 1);
+    // 16-bit activations: the 64-channel sums of the dB / dC products go through the matrix pipe (wave.h, wave_sum_mfma_*): lane l
+    // ends up with value 2 s + h = wave_sum_mfma_value_of_lane(l) -> step s = 2 bit4 + 4 bit5 + bit2, state 2 j + h with h = bit3
+    constexpr bool MSUM = AUM_SCANT_MSUM && sizeof(T) == 2 && !(AUM_SCANT_BABL & 1);
+    const vi dbc_slot_m = (((lane >> 4) & 1) * 2 + ((lane >> 5) & 1) * 4 + ((lane >> 2) & 1)) * SCANT_BC_ROW + ((lane >> 3) & 1);
+    const WaveSumSel wsel = wave_sum_mfma_sel();
+    WaveSumAcc wacc;
+    AUM_UNROLL
+    for (int i = 0; i < 8; ++i) wacc.d[i] = splat(0.f);
 
     // per-lane row of block `blk` in a global tensor: memory row st_r for blocks inside the phase (plus the scalar offset of the
     // block's lowest time step), the clamped row's time step for ragged ones
@@ -751,31 +763,55 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             vf2 hj = mk2(vf16_get(hh, 2 * jr), vf16_get(hh, 2 * jr + 1)), dAj = mk2(vf16_get(dAacc, 2 * jr), vf16_get(dAacc, 2 * jr + 1));
             vf2 w[SCANT_CK], a[SCANT_CK];
             vf pc[16], pb[16];
+            vf2 pc2[SCANT_CK], pb2[SCANT_CK];
             // a = exp2(delta A2) of the eight steps: independent of the recurrences, used by both sweeps
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) a[s] = (AUM_SCANT_BABL & 2) ? bc_lo(P[s]) * A2j : vexp2_2(bc_lo(P[s]) * A2j);
+            if constexpr (MSUM) {
+                // the accumulator tiles of the PREVIOUS pass: their matrix instructions were issued a pass ago, so the DPP levels read
+                // them without a wait (pass 0 finishes the stale tiles of the previous block into pass 7's slots, which this block's
+                // own last pass overwrites before the tile leaves: no branch in the pass)
+                AUM_SCHED_FENCE();
+                vf sC, sB;
+                wave_sum_mfma_finish(wacc, false, sC, sB);
+                const vi slot = dbc_slot_m + 2 * ((j + N / 2 - 1) & (N / 2 - 1));
+                lds_write(t_dbc, slot, sB);
+                lds_write(t_dbc, slot + N, sC);
+                AUM_SCHED_FENCE();
+            }
             // forward sweep: steps 0 .. s_hi-1
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) {
                 if (!FULL) {
                     pc[2 * s] = pc[2 * s + 1] = splat(0.f);
                     pb[2 * s] = pb[2 * s + 1] = splat(0.f);
+                    pc2[s] = pb2[s] = spl2(splat(0.f));
                 }
                 if (FULL || s < s_hi) {
                     w[s] = a[s] * x;
                     x = vfma2(bc_hi(P[s]), mk2(qb[s][0], qb[s][1]), w[s]);
                     if (FULL || s >= s_lo) {
                         const vf2 pcs = ((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1])) * x;
-                        pc[2 * s] = lo2(pcs);
-                        pc[2 * s + 1] = hi2(pcs);
+                        if constexpr (MSUM) {
+                            pc2[s] = pcs;
+                        } else {
+                            pc[2 * s] = lo2(pcs);
+                            pc[2 * s + 1] = hi2(pcs);
+                        }
                     }
+                }
+                if constexpr (MSUM && AUM_SCANT_MSUM == 2) {      // a half tile as soon as its four steps exist
+                    if (s == 3) wave_sum_mfma_add8(wacc, 0, 0, true, wsel, *reinterpret_cast<const vf2(*)[4]>(&pc2[0]));
+                    if (s == 7) wave_sum_mfma_add8(wacc, 0, 1, false, wsel, *reinterpret_cast<const vf2(*)[4]>(&pc2[4]));
                 }
             }
             // the entry rows this pass consumed make room for the next block's
             if (cknext) request_entry(blk - 1, RPP * j, RPP * j + RPP);
             AUM_SCHED_FENCE();
             AUM_TMB_STAMP(3);
-            const vf dCsum = (AUM_SCANT_BABL & 1) ? pc[0] + pc[5] : wave_sum16(pc);
+            vf dCsum = splat(0.f);
+            if constexpr (MSUM && AUM_SCANT_MSUM != 2) wave_sum_mfma_add16(wacc, 0, wsel, pc2);
+            if constexpr (!MSUM) dCsum = (AUM_SCANT_BABL & 1) ? pc[0] + pc[5] : wave_sum16(pc);
             AUM_SCHED_FENCE();
             AUM_TMB_STAMP(4);
             // reverse sweep: steps s_hi-1 .. s_lo
@@ -784,22 +820,31 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                 if (FULL || (s >= s_lo && s < s_hi)) {
                     const vf2 g = vfma2((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1]), mk2(qc[s][0], qc[s][1]), hj);
                     const vf2 pbs = g * bc_hi(P[s]);
-                    pb[2 * s] = lo2(pbs);
-                    pb[2 * s + 1] = hi2(pbs);
+                    if constexpr (MSUM) {
+                        pb2[s] = pbs;
+                    } else {
+                        pb[2 * s] = lo2(pbs);
+                        pb[2 * s + 1] = hi2(pbs);
+                    }
                     S1[s] = vfma2(g, mk2(qb[s][0], qb[s][1]), S1[s]);
                     const vf2 r = g * w[s];
                     S2[s] = vfma2(A2j, r, S2[s]);
                     dAj = vfma2(bc_lo(P[s]), r, dAj);
                     hj = a[s] * g;
                 }
+                if constexpr (MSUM && AUM_SCANT_MSUM == 2) {      // the sweep runs downward: steps 7..4 (the tile's upper rows) come first
+                    if (s == 4) wave_sum_mfma_add8(wacc, 1, 1, true, wsel, *reinterpret_cast<const vf2(*)[4]>(&pb2[4]));
+                    if (s == 0) wave_sum_mfma_add8(wacc, 1, 0, false, wsel, *reinterpret_cast<const vf2(*)[4]>(&pb2[0]));
+                }
             }
             AUM_SCHED_FENCE();
             AUM_TMB_STAMP(5);
-            const vf dBsum = (AUM_SCANT_BABL & 1) ? pb[0] + pb[7] : wave_sum16(pb);
-            // lane l holds the totals of value k = wave_sum16_value_of_lane(l) = (step k >> 1, state 2j + (k & 1)).  The four lanes of a
-            // quad hold the same total and all write it to the same slot: a lane mask here is a branch, and everything the scheduler
-            // sinks below it loses its packed-operand broadcasts (they are folded per basic block)
-            {
+            if constexpr (MSUM && AUM_SCANT_MSUM != 2) wave_sum_mfma_add16(wacc, 1, wsel, pb2);
+            if constexpr (!MSUM) {
+                const vf dBsum = (AUM_SCANT_BABL & 1) ? pb[0] + pb[7] : wave_sum16(pb);
+                // lane l holds the totals of value k = wave_sum16_value_of_lane(l) = (step k >> 1, state 2j + (k & 1)).  The four lanes of a
+                // quad hold the same total and all write it to the same slot: a lane mask here is a branch, and everything the scheduler
+                // sinks below it loses its packed-operand broadcasts (they are folded per basic block)
                 const vi slot = dbc_slot + 2 * j;
                 lds_write(t_dbc, slot, dBsum);
                 lds_write(t_dbc, slot + N, dCsum);
@@ -809,6 +854,13 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             vf16_set(dAacc, 2 * jr, lo2(dAj));
             vf16_set(dAacc, 2 * jr + 1, hi2(dAj));
             AUM_TMB_STAMP(6);
+        }
+        if constexpr (MSUM) {      // the last pass's tiles (their matrix instructions may still be in flight: `fresh`)
+            vf sC, sB;
+            wave_sum_mfma_finish(wacc, true, sC, sB);
+            const vi slot = dbc_slot_m + 2 * (N / 2 - 1);
+            lds_write(t_dbc, slot, sB);
+            lds_write(t_dbc, slot + N, sC);
         }
         // ---- the block's du, ddelta; partials / finish ----------------------------------------------------------
         // this block's partial du / ddelta are back (younger: the CKR entry rows requested during the passes)

@@ -1125,6 +1125,151 @@ AUM_DEV vf wave_sum32(vf (&v)[32]) {
 #endif
 
 // ------------------------------------------------------------------------------------------------
+// Sums over the 64 lanes on the MATRIX pipe (round 4).  The time-serial backward scan is bound by the vector ALU and a quarter of its
+// instructions were the two transposing butterflies of a pass (wave_sum16: 2 instructions per value + the serial tail through the
+// swaps); the matrix pipe of the SIMD idles.  v_mfma_f32_16x16x32_bf16 computes D[i][j] = sum_k A[i][k] B[k][j] with k = 8 g + e spread
+// over the four 16-lane groups g (lane = 16 g + j holds B[8 g + e][j], e = 0..7 as four packed registers): with a SELECTOR as A
+// (A[i][8 g + e] = 1 iff e == i mod 8, rows 0-7 from one instruction, rows 8-15 accumulated by a second one) sixteen per-lane values
+// -- rounded to bf16, summed in fp32 -- are summed over the four lane groups by two matrix instructions, and D (lane 16 g + j,
+// register r: row 4 g + r, column j) is left with sixteen 16-lane partial sums that four masked DPP levels finish:
+//   per 16 values   8 v_cvt_pk_bf16_f32 + 2 v_mfma + 8 v_add_f32_dpp     instead of   32 VALU + 8 hazard s_nop in a serial tail.
+// Rounding the PRODUCTS to bf16 before the 64-channel sum costs 2^-9 relative per term, uncorrelated over 3072 terms (48 channel
+// groups): far below the one rounding of the 16-bit tensor the total is stored in (dx_dbl); fp32 activations keep wave_sum16.
+// wave_sum_mfma_add16: tile t of the accumulator <- sums over lane groups of the 16 values p[q] = (value 2q, value 2q + 1);
+// wave_sum_mfma_finish: both tiles -> (sum of tile 0, sum of tile 1), lane l holding the total of value
+//   wave_sum_mfma_value_of_lane(l) = 4 (l >> 4) + bit3(l) + 2 bit2(l)   (the four lanes of a quad hold the same total).
+// The matrix instruction's result may not be read by the (inline-assembly, invisible to the hazard recogniser) DPP adds for 12 issue
+// slots: callers finish a tile a pass later, or pass `fresh` (two s_nop 7 first).
+// ------------------------------------------------------------------------------------------------
+constexpr int wave_sum_mfma_value_of_lane(int l) { return 4 * (l >> 4) + ((l >> 3) & 1) + 2 * ((l >> 2) & 1); }
+AUM_DEV uint32_t f32_round_bf16_bits(float f) {
+    uint32_t u = f32_to_bits(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+struct WaveSumAcc { vf d[8]; };          // two accumulator tiles of four registers
+#ifdef AUM_EMU
+struct WaveSumSel { int unused; };
+inline WaveSumSel wave_sum_mfma_sel() { return WaveSumSel{0}; }
+inline void wave_sum_mfma_add16(WaveSumAcc& acc, int tile, const WaveSumSel&, const vf2 (&p)[8]) {
+    // the matrix instruction pair, lane by lane: D[i][j] = sum over the four lane groups of bf16(value i) at column j
+    for (int r = 0; r < 4; ++r)
+        AUM_LANES {
+            const int g = l >> 4, j = l & 15, i = 4 * g + r;
+            const vf& src = (i & 1) ? p[i >> 1].y : p[i >> 1].x;
+            float acc_ = 0.f;
+            for (int gg = 0; gg < 4; ++gg) acc_ += bits_to_f32(f32_round_bf16_bits(src.v[16 * gg + j]) << 16);
+            acc.d[4 * tile + r].v[l] = acc_;
+        }
+}
+// one half of wave_sum_mfma_add16: values 8 half .. 8 half + 7 = p[0..3] (rows 8 half .. 8 half + 7 of the tile); `first`: the tile starts from zero
+inline void wave_sum_mfma_add8(WaveSumAcc& acc, int tile, int half, bool first, const WaveSumSel&, const vf2 (&p)[4]) {
+    for (int r = 0; r < 4; ++r)
+        AUM_LANES {
+            const int g = l >> 4, j = l & 15, i = 4 * g + r;
+            float acc_ = first ? 0.f : acc.d[4 * tile + r].v[l];
+            if ((i >> 3) == half) {
+                const int k = i & 7;
+                const vf& src = (k & 1) ? p[k >> 1].y : p[k >> 1].x;
+                for (int gg = 0; gg < 4; ++gg) acc_ += bits_to_f32(f32_round_bf16_bits(src.v[16 * gg + j]) << 16);
+            }
+            acc.d[4 * tile + r].v[l] = acc_;
+        }
+}
+inline void wave_sum_mfma_finish(WaveSumAcc& acc, bool, vf& s0, vf& s1) {
+    for (int t = 0; t < 2; ++t) {
+        vf r;
+        AUM_LANES {
+            const int reg = ((l >> 3) & 1) + 2 * ((l >> 2) & 1);
+            float a = 0.f;
+            for (int j = 0; j < 16; ++j) a += acc.d[4 * t + reg].v[(l & ~15) | j];
+            r.v[l] = a;
+        }
+        (t ? s1 : s0) = r;
+    }
+}
+#else
+typedef float wsum_f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wsum_b2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wsum_b8 __attribute__((ext_vector_type(8)));
+typedef unsigned wsum_u4 __attribute__((ext_vector_type(4)));
+struct WaveSumSel { wsum_u4 lo, hi; };   // A operands: rows 0-7 <- element i of every lane group; rows 8-15 <- element i - 8
+AUM_DEV WaveSumSel wave_sum_mfma_sel() {
+    const unsigned i = threadIdx.x & 15u;
+    const unsigned one = (i & 1u) ? 0x3f800000u : 0x00003f80u;      // bf16 1.0 in the odd / even half of the packed pair
+    WaveSumSel s;
+    AUM_UNROLL
+    for (unsigned q = 0; q < 4; ++q) {
+        s.lo[q] = (i < 8u && (i >> 1) == q) ? one : 0u;
+        s.hi[q] = (i >= 8u && ((i - 8u) >> 1) == q) ? one : 0u;
+    }
+    asm volatile("" : "+v"(s.lo), "+v"(s.hi));      // loop invariants kept in registers, not re-derived by compares in every pass
+    return s;
+}
+AUM_DEV void wave_sum_mfma_add16(WaveSumAcc& acc, int tile, const WaveSumSel& sel, const vf2 (&p)[8]) {
+    wsum_u4 b0, b1;
+    AUM_UNROLL
+    for (int q = 0; q < 4; ++q) {
+        b0[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(p[q], wsum_b2));          // v_cvt_pk_bf16_f32
+        b1[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(p[4 + q], wsum_b2));
+    }
+    const wsum_f4 z = {0.f, 0.f, 0.f, 0.f};
+    wsum_f4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wsum_b8, sel.lo), __builtin_bit_cast(wsum_b8, b0), z, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wsum_b8, sel.hi), __builtin_bit_cast(wsum_b8, b1), d, 0, 0, 0);
+    acc.d[4 * tile + 0] = d[0];
+    acc.d[4 * tile + 1] = d[1];
+    acc.d[4 * tile + 2] = d[2];
+    acc.d[4 * tile + 3] = d[3];
+}
+// one half of wave_sum_mfma_add16, issued as soon as its four pairs exist (the second matrix instruction of a tile reads the first
+// one's result: back to back it waits for it): values 8 half .. 8 half + 7 = p[0..3]; `first`: the tile starts from zero
+AUM_DEV void wave_sum_mfma_add8(WaveSumAcc& acc, int tile, int half, bool first, const WaveSumSel& sel, const vf2 (&p)[4]) {
+    wsum_u4 b;
+    AUM_UNROLL
+    for (int q = 0; q < 4; ++q) b[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(p[q], wsum_b2));          // v_cvt_pk_bf16_f32
+    wsum_f4 c = {0.f, 0.f, 0.f, 0.f};
+    if (!first) c = wsum_f4{acc.d[4 * tile], acc.d[4 * tile + 1], acc.d[4 * tile + 2], acc.d[4 * tile + 3]};
+    const wsum_f4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wsum_b8, half ? sel.hi : sel.lo), __builtin_bit_cast(wsum_b8, b), c, 0, 0, 0);
+    acc.d[4 * tile + 0] = d[0];
+    acc.d[4 * tile + 1] = d[1];
+    acc.d[4 * tile + 2] = d[2];
+    acc.d[4 * tile + 3] = d[3];
+}
+AUM_DEV void wave_sum_mfma_finish(WaveSumAcc& acc, bool fresh, vf& s0, vf& s1) {
+    // `fresh`: the tiles may have been written by a matrix instruction within the last 12 issue slots
+    if (fresh) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    // levels over lane bits 3 and 2 inside a 16-lane row (masked DPP adds: bank_mask write-enables the lanes whose bit selects the
+    // register), then plain sums over bits 1 and 0.  Two wait states between a write and a DPP read of the same register: the two
+    // tiles are interleaved, s_nop where that is not enough.
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(acc.d[0]), "+v"(acc.d[1]), "+v"(acc.d[2]), "+v"(acc.d[3]), "+v"(acc.d[4]), "+v"(acc.d[5]), "+v"(acc.d[6]), "+v"(acc.d[7]));
+    s0 = acc.d[0];
+    s1 = acc.d[4];
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // The associative scan of the selective-scan recurrence x' = a*x + b over the 64 lanes.
 // Each lane holds the composition (P, S) of its own K steps:  x_out = P * x_in + S.
 // Operator (earlier) o (later):  (P1,S1) o (P2,S2) = (P1*P2, P2*S1 + S2)      (SURVEY 8a')

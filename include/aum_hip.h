@@ -440,7 +440,9 @@ int aum_abi_version(void);
 /* runs wave_scan_affine<rev> on 64 (P,S) pairs: in/out are device arrays of 128 floats (P[0..63], S[0..63]) */
 int aum_selftest_wave_scan(const float* in, float* out, int rev, void* stream);
 /* runs wave_sum32 (transposing butterfly sum over the 64 lanes) on 32 x 64 values in[k][lane]; out[lane] = the total of value
- * 2 * (lane & 15) + ((lane >> 4) & 1); out[64 + lane] = wave_sum16 of values 0..15: the total of value lane & 15.  out: 128 floats */
+ * 2 * (lane & 15) + ((lane >> 4) & 1); out[64 + lane] = wave_sum16 of values 0..15; out[128 + lane] / out[192 + lane] = the matrix-pipe
+ * sums (terms rounded to bf16, round 4) of values 0..15 / 16..31: the total of value 4 * (lane >> 4) + bit3(lane) + 2 * bit2(lane) of
+ * the tile.  out: 256 floats */
 int aum_selftest_wave_sum32(const float* in, float* out, void* stream);
 /* float4 streaming copy, the measured-HBM-roofline denominator of SURVEY.md 8(d) */
 int aum_hbm_copy(const void* src, void* dst, int64_t bytes, void* stream);

@@ -84,6 +84,37 @@ def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     return {"out": out, "y_pre": y_pre, "last_state": last}
 
 
+def scan_bc_abs_sums(u, delta, A, B, C, z, delta_bias, dout, delta_softplus=False, reverse=False):
+    """Diagnostic for tests (numpy fp64, small shapes): S_B[b,n,t] = sum_d |g_n,d,t delta_d,t u_d,t| and S_C[b,n,t] = sum_d |dy_d,t x_n,d,t|,
+    the sums of the MAGNITUDES of the terms of dB / dC (same recurrences as scan_bwd: SSI:86-152 and its adjoint).  A reduction that
+    rounds every term to bf16 before adding (the HIP kernels' matrix-pipe channel sums for 16-bit activations) is within 2^-8 S of
+    the exact sum whatever the cancellation; tests bound dB / dC by that on top of the parity tolerance."""
+    f = lambda a: None if a is None else np.asarray(a, np.float64)
+    u, delta, A, B, C, z, delta_bias, dout = f(u), f(delta), f(A), f(_bc3(B)), f(_bc3(C)), f(z), f(delta_bias), f(dout)
+    batch, dim, length = u.shape
+    dstate = A.shape[1]
+    dt = delta + (delta_bias[None, :, None] if delta_bias is not None else 0.0)
+    if delta_softplus:
+        dt = np.where(dt > 20, dt, np.log1p(np.exp(np.minimum(dt, 20))))
+    dy = dout if z is None else dout * z / (1.0 + np.exp(-z))
+    order = range(length - 1, -1, -1) if reverse else range(length)
+    a = np.exp(dt[:, :, None, :] * A[None, :, :, None])                     # (b, d, n, t)
+    x = np.zeros((batch, dim, dstate))
+    xs = np.zeros((batch, dim, dstate, length))
+    for t in order:
+        x = a[:, :, :, t] * x + (dt[:, :, t] * u[:, :, t])[:, :, None] * B[:, None, :, t]
+        xs[:, :, :, t] = x
+    S_C = np.abs(dy[:, :, None, :] * xs).sum(1)
+    g = np.zeros((batch, dim, dstate))
+    S_B = np.zeros((batch, dstate, length))
+    a_next = np.zeros((batch, dim, dstate))
+    for t in reversed(list(order)):
+        g = dy[:, :, t][:, :, None] * C[:, None, :, t] + a_next * g
+        S_B[:, :, t] = np.abs(g * (dt[:, :, t] * u[:, :, t])[:, :, None]).sum(1)
+        a_next = a[:, :, :, t]
+    return S_B, S_C
+
+
 def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, delta_softplus=False, reverse=False, prec="f32"):
     """Analytic adjoint of scan_fwd (what selective_scan_cuda.bwd returns, SSI:62-65)."""
     npdt, cdt = _DT[prec]
