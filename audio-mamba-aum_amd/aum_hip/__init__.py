@@ -149,7 +149,7 @@ EXPORTS = ["aum_gemm_tn", "aum_dtproj_tm_fwd", "aum_xdt_tm_fwd", "aum_proj_fwd",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows",
            "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_ckpt_rows", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_selftest_wave_sum32",
-           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts"]
+           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_scan_tm_bwd_matrix_sums"]
 
 
 class Lib:
@@ -176,6 +176,7 @@ class Lib:
         self.c.aum_conv1d_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_conv1d_tm_bwd.argtypes = [_vp, _vp]
         self.c.aum_conv1d_tm_nparts.argtypes = [_i32, _i32]
+        self.c.aum_scan_tm_bwd_matrix_sums.argtypes = []
         self.c.aum_gemm_tn.argtypes = [_vp, _vp]
         self.c.aum_dtproj_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_xdt_tm_fwd.argtypes = [_vp, _vp]

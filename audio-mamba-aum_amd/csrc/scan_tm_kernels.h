@@ -479,8 +479,13 @@ struct ScanTBwdOut {
 };
 
 #ifndef AUM_SCANT_MSUM
-#define AUM_SCANT_MSUM 1      // 0 (A/B builds): the dB / dC channel sums of 16-bit activations on the vector ALU (wave_sum16), as in round 3;
-                              // 2 (A/B builds): a tile's two matrix instructions issued inside the sweeps as soon as their four steps exist
+// 1 (opt-in builds, -DAUM_SCANT_MSUM=1): the dB / dC channel sums of 16-bit activations on the matrix pipe (wave.h, wave_sum_mfma_*:
+// terms rounded to bf16, selector v_mfma_f32_16x16x32_bf16 + 16 masked DPP adds instead of two 32-instruction butterflies).  Built,
+// parity-green on the GPU (543 tests incl. the oracle check of the bench launch) and measured in round 4: 25 % fewer vector-ALU
+// instructions per pass, and NOT faster -- same box, B = 64: 1.04 / 1.13 ms against 1.05 / 1.10 ms (softplus outside / inside), bench
+// 962 vs 968 clips/s (profiles/r04_ab_msum.txt).  The kernel is bound by the issue time of its two waves per SIMD, and a matrix
+// instruction occupies the SIMD's issue for its 8 passes: four per pass cost what 32 DPP adds saved.  Default 0: the butterflies.
+#define AUM_SCANT_MSUM 0
 #endif
 #ifndef AUM_SCANT_BABL
 #define AUM_SCANT_BABL 0      // timing experiments only (wrong results): 1 no butterflies, 2 no exponentials, 4 carries at a fixed register index,
@@ -767,18 +772,6 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             // a = exp2(delta A2) of the eight steps: independent of the recurrences, used by both sweeps
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) a[s] = (AUM_SCANT_BABL & 2) ? bc_lo(P[s]) * A2j : vexp2_2(bc_lo(P[s]) * A2j);
-            if constexpr (MSUM) {
-                // the accumulator tiles of the PREVIOUS pass: their matrix instructions were issued a pass ago, so the DPP levels read
-                // them without a wait (pass 0 finishes the stale tiles of the previous block into pass 7's slots, which this block's
-                // own last pass overwrites before the tile leaves: no branch in the pass)
-                AUM_SCHED_FENCE();
-                vf sC, sB;
-                wave_sum_mfma_finish(wacc, false, sC, sB);
-                const vi slot = dbc_slot_m + 2 * ((j + N / 2 - 1) & (N / 2 - 1));
-                lds_write(t_dbc, slot, sB);
-                lds_write(t_dbc, slot + N, sC);
-                AUM_SCHED_FENCE();
-            }
             // forward sweep: steps 0 .. s_hi-1
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) {
@@ -800,17 +793,13 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                         }
                     }
                 }
-                if constexpr (MSUM && AUM_SCANT_MSUM == 2) {      // a half tile as soon as its four steps exist
-                    if (s == 3) wave_sum_mfma_add8(wacc, 0, 0, true, wsel, *reinterpret_cast<const vf2(*)[4]>(&pc2[0]));
-                    if (s == 7) wave_sum_mfma_add8(wacc, 0, 1, false, wsel, *reinterpret_cast<const vf2(*)[4]>(&pc2[4]));
-                }
             }
             // the entry rows this pass consumed make room for the next block's
             if (cknext) request_entry(blk - 1, RPP * j, RPP * j + RPP);
             AUM_SCHED_FENCE();
             AUM_TMB_STAMP(3);
             vf dCsum = splat(0.f);
-            if constexpr (MSUM && AUM_SCANT_MSUM != 2) wave_sum_mfma_add16(wacc, 0, wsel, pc2);
+            if constexpr (MSUM) wave_sum_mfma_add16(wacc, 0, wsel, pc2);
             if constexpr (!MSUM) dCsum = (AUM_SCANT_BABL & 1) ? pc[0] + pc[5] : wave_sum16(pc);
             AUM_SCHED_FENCE();
             AUM_TMB_STAMP(4);
@@ -832,14 +821,22 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                     dAj = vfma2(bc_lo(P[s]), r, dAj);
                     hj = a[s] * g;
                 }
-                if constexpr (MSUM && AUM_SCANT_MSUM == 2) {      // the sweep runs downward: steps 7..4 (the tile's upper rows) come first
-                    if (s == 4) wave_sum_mfma_add8(wacc, 1, 1, true, wsel, *reinterpret_cast<const vf2(*)[4]>(&pb2[4]));
-                    if (s == 0) wave_sum_mfma_add8(wacc, 1, 0, false, wsel, *reinterpret_cast<const vf2(*)[4]>(&pb2[0]));
-                }
             }
             AUM_SCHED_FENCE();
             AUM_TMB_STAMP(5);
-            if constexpr (MSUM && AUM_SCANT_MSUM != 2) wave_sum_mfma_add16(wacc, 1, wsel, pb2);
+            if constexpr (MSUM) {
+                // dC of this pass (tile 0: its matrix instructions were issued before the reverse sweep) and dB of the PREVIOUS pass (tile 1,
+                // issued at the end of that pass) leave together -- the two tiles' DPP levels interleave -- then this pass's dB terms go into
+                // tile 1: four accumulator registers cross the pass boundary instead of eight.  Pass 0 finishes the previous block's stale
+                // tile 1 into pass 7's dB slots, which this block's own last lines overwrite: no branch in the pass.
+                AUM_SCHED_FENCE();
+                vf sC, sB;
+                wave_sum_mfma_finish(wacc, false, sC, sB);
+                lds_write(t_dbc, dbc_slot_m + 2 * j + N, sC);
+                lds_write(t_dbc, dbc_slot_m + 2 * ((j + N / 2 - 1) & (N / 2 - 1)), sB);
+                AUM_SCHED_FENCE();
+                wave_sum_mfma_add16(wacc, 1, wsel, pb2);
+            }
             if constexpr (!MSUM) {
                 const vf dBsum = (AUM_SCANT_BABL & 1) ? pb[0] + pb[7] : wave_sum16(pb);
                 // lane l holds the totals of value k = wave_sum16_value_of_lane(l) = (step k >> 1, state 2j + (k & 1)).  The four lanes of a
@@ -855,12 +852,10 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             vf16_set(dAacc, 2 * jr + 1, hi2(dAj));
             AUM_TMB_STAMP(6);
         }
-        if constexpr (MSUM) {      // the last pass's tiles (their matrix instructions may still be in flight: `fresh`)
+        if constexpr (MSUM) {      // the last pass's dB tile (its matrix instructions may still be in flight: `fresh`; tile 0 is spent)
             vf sC, sB;
             wave_sum_mfma_finish(wacc, true, sC, sB);
-            const vi slot = dbc_slot_m + 2 * (N / 2 - 1);
-            lds_write(t_dbc, slot, sB);
-            lds_write(t_dbc, slot + N, sC);
+            lds_write(t_dbc, dbc_slot_m + 2 * (N / 2 - 1), sB);
         }
         // ---- the block's du, ddelta; partials / finish ----------------------------------------------------------
         // this block's partial du / ddelta are back (younger: the CKR entry rows requested during the passes)

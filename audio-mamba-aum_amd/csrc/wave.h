@@ -1138,8 +1138,8 @@ AUM_DEV vf wave_sum32(vf (&v)[32]) {
 // wave_sum_mfma_add16: tile t of the accumulator <- sums over lane groups of the 16 values p[q] = (value 2q, value 2q + 1);
 // wave_sum_mfma_finish: both tiles -> (sum of tile 0, sum of tile 1), lane l holding the total of value
 //   wave_sum_mfma_value_of_lane(l) = 4 (l >> 4) + bit3(l) + 2 bit2(l)   (the four lanes of a quad hold the same total).
-// The matrix instruction's result may not be read by the (inline-assembly, invisible to the hazard recogniser) DPP adds for 12 issue
-// slots: callers finish a tile a pass later, or pass `fresh` (two s_nop 7 first).
+// The matrix instruction's result may not be read by inline assembly (invisible to the hazard recogniser) for 12 issue slots: callers
+// finish a tile a pass later, or pass `fresh` (two s_nop 7 first); and never by a DPP instruction directly (wave_sum_mfma_finish).
 // ------------------------------------------------------------------------------------------------
 constexpr int wave_sum_mfma_value_of_lane(int l) { return 4 * (l >> 4) + ((l >> 3) & 1) + 2 * ((l >> 2) & 1); }
 AUM_DEV uint32_t f32_round_bf16_bits(float f) {
@@ -1163,20 +1163,6 @@ inline void wave_sum_mfma_add16(WaveSumAcc& acc, int tile, const WaveSumSel&, co
             acc.d[4 * tile + r].v[l] = acc_;
         }
 }
-// one half of wave_sum_mfma_add16: values 8 half .. 8 half + 7 = p[0..3] (rows 8 half .. 8 half + 7 of the tile); `first`: the tile starts from zero
-inline void wave_sum_mfma_add8(WaveSumAcc& acc, int tile, int half, bool first, const WaveSumSel&, const vf2 (&p)[4]) {
-    for (int r = 0; r < 4; ++r)
-        AUM_LANES {
-            const int g = l >> 4, j = l & 15, i = 4 * g + r;
-            float acc_ = first ? 0.f : acc.d[4 * tile + r].v[l];
-            if ((i >> 3) == half) {
-                const int k = i & 7;
-                const vf& src = (k & 1) ? p[k >> 1].y : p[k >> 1].x;
-                for (int gg = 0; gg < 4; ++gg) acc_ += bits_to_f32(f32_round_bf16_bits(src.v[16 * gg + j]) << 16);
-            }
-            acc.d[4 * tile + r].v[l] = acc_;
-        }
-}
 inline void wave_sum_mfma_finish(WaveSumAcc& acc, bool, vf& s0, vf& s1) {
     for (int t = 0; t < 2; ++t) {
         vf r;
@@ -1194,18 +1180,21 @@ typedef float wsum_f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 wsum_b2 __attribute__((ext_vector_type(2)));
 typedef __bf16 wsum_b8 __attribute__((ext_vector_type(8)));
 typedef unsigned wsum_u4 __attribute__((ext_vector_type(4)));
-struct WaveSumSel { wsum_u4 lo, hi; };   // A operands: rows 0-7 <- element i of every lane group; rows 8-15 <- element i - 8
+// Selector operands.  Kept as ONE register (bf16 1.0 in the odd / even half by lane parity); the eight selector registers of a tile's
+// two matrix instructions are formed where they are used by v_cndmask_b32 against literal lane masks (rows 0-7 <- element i of every
+// lane group: lanes i = 2 q, 2 q + 1 of each 16-lane row for register q; rows 8-15: the same eight lanes up).  Eight persistent selector
+// registers cost the 256-register kernel spills; eight selects per tile are 2 % of a pass.
+struct WaveSumSel { unsigned one; };
 AUM_DEV WaveSumSel wave_sum_mfma_sel() {
-    const unsigned i = threadIdx.x & 15u;
-    const unsigned one = (i & 1u) ? 0x3f800000u : 0x00003f80u;      // bf16 1.0 in the odd / even half of the packed pair
     WaveSumSel s;
-    AUM_UNROLL
-    for (unsigned q = 0; q < 4; ++q) {
-        s.lo[q] = (i < 8u && (i >> 1) == q) ? one : 0u;
-        s.hi[q] = (i >= 8u && ((i - 8u) >> 1) == q) ? one : 0u;
-    }
-    asm volatile("" : "+v"(s.lo), "+v"(s.hi));      // loop invariants kept in registers, not re-derived by compares in every pass
+    s.one = (threadIdx.x & 1u) ? 0x3f800000u : 0x00003f80u;
+    asm volatile("" : "+v"(s.one));
     return s;
+}
+template <unsigned long long MASK> AUM_DEV unsigned wsum_sel_reg(unsigned one) {
+    unsigned r;
+    asm volatile("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(one), "s"(MASK));
+    return r;
 }
 AUM_DEV void wave_sum_mfma_add16(WaveSumAcc& acc, int tile, const WaveSumSel& sel, const vf2 (&p)[8]) {
     wsum_u4 b0, b1;
@@ -1214,34 +1203,56 @@ AUM_DEV void wave_sum_mfma_add16(WaveSumAcc& acc, int tile, const WaveSumSel& se
         b0[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(p[q], wsum_b2));          // v_cvt_pk_bf16_f32
         b1[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(p[4 + q], wsum_b2));
     }
+    constexpr unsigned long long M0 = 0x0003000300030003ull;
+    wsum_u4 lo, hi;
+    lo[0] = wsum_sel_reg<M0>(sel.one);
+    lo[1] = wsum_sel_reg<(M0 << 2)>(sel.one);
+    lo[2] = wsum_sel_reg<(M0 << 4)>(sel.one);
+    lo[3] = wsum_sel_reg<(M0 << 6)>(sel.one);
     const wsum_f4 z = {0.f, 0.f, 0.f, 0.f};
-    wsum_f4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wsum_b8, sel.lo), __builtin_bit_cast(wsum_b8, b0), z, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wsum_b8, sel.hi), __builtin_bit_cast(wsum_b8, b1), d, 0, 0, 0);
+    wsum_f4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wsum_b8, lo), __builtin_bit_cast(wsum_b8, b0), z, 0, 0, 0);
+    hi[0] = wsum_sel_reg<(M0 << 8)>(sel.one);
+    hi[1] = wsum_sel_reg<(M0 << 10)>(sel.one);
+    hi[2] = wsum_sel_reg<(M0 << 12)>(sel.one);
+    hi[3] = wsum_sel_reg<(M0 << 14)>(sel.one);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wsum_b8, hi), __builtin_bit_cast(wsum_b8, b1), d, 0, 0, 0);
     acc.d[4 * tile + 0] = d[0];
     acc.d[4 * tile + 1] = d[1];
     acc.d[4 * tile + 2] = d[2];
     acc.d[4 * tile + 3] = d[3];
 }
-// one half of wave_sum_mfma_add16, issued as soon as its four pairs exist (the second matrix instruction of a tile reads the first
-// one's result: back to back it waits for it): values 8 half .. 8 half + 7 = p[0..3]; `first`: the tile starts from zero
-AUM_DEV void wave_sum_mfma_add8(WaveSumAcc& acc, int tile, int half, bool first, const WaveSumSel& sel, const vf2 (&p)[4]) {
-    wsum_u4 b;
-    AUM_UNROLL
-    for (int q = 0; q < 4; ++q) b[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(p[q], wsum_b2));          // v_cvt_pk_bf16_f32
-    wsum_f4 c = {0.f, 0.f, 0.f, 0.f};
-    if (!first) c = wsum_f4{acc.d[4 * tile], acc.d[4 * tile + 1], acc.d[4 * tile + 2], acc.d[4 * tile + 3]};
-    const wsum_f4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wsum_b8, half ? sel.hi : sel.lo), __builtin_bit_cast(wsum_b8, b), c, 0, 0, 0);
-    acc.d[4 * tile + 0] = d[0];
-    acc.d[4 * tile + 1] = d[1];
-    acc.d[4 * tile + 2] = d[2];
-    acc.d[4 * tile + 3] = d[3];
+#ifndef AUM_WSUM_BUILTIN
+#define AUM_WSUM_BUILTIN 0
+#endif
+// lane l <- lane l ^ 4 of its 16-lane row: two bank-masked DPP moves
+AUM_DEV vf wsum_xor4(vf m) {
+    int t = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m), __builtin_bit_cast(int, m), 0x104, 0xf, 0x5, false);       // banks 0, 2 <- lane + 4
+    t = __builtin_amdgcn_update_dpp(t, __builtin_bit_cast(int, m), 0x114, 0xf, 0xa, false);                                    // banks 1, 3 <- lane - 4
+    return __builtin_bit_cast(float, t);
+}
+// one tile's four registers -> lane l: total of value 4 (l >> 4) + bit3 + 2 bit2, every instruction visible to the compiler (the hazard
+// recogniser places the matrix-result and DPP wait states itself)
+AUM_DEV vf wsum_finish_tile(vf r0, vf r1, vf r2, vf r3) {
+    const unsigned lane = threadIdx.x & 63u;
+    const bool b3 = (lane & 8u) != 0, b2 = (lane & 4u) != 0;
+    const vf m = b3 ? r1 + dpp_row_ror<8>(r1) : r0 + dpp_row_ror<8>(r0);
+    const vf z = b3 ? r3 + dpp_row_ror<8>(r3) : r2 + dpp_row_ror<8>(r2);
+    vf v = b2 ? z + wsum_xor4(z) : m + wsum_xor4(m);
+    v = v + dpp_mov<0x4E>(v, v);        // quad_perm [2,3,0,1]
+    v = v + dpp_mov<0xB1>(v, v);        // quad_perm [1,0,3,2]
+    return v;
 }
 AUM_DEV void wave_sum_mfma_finish(WaveSumAcc& acc, bool fresh, vf& s0, vf& s1) {
+#if AUM_WSUM_BUILTIN
+    s0 = wsum_finish_tile(acc.d[0], acc.d[1], acc.d[2], acc.d[3]);
+    s1 = wsum_finish_tile(acc.d[4], acc.d[5], acc.d[6], acc.d[7]);
+    return;
+#endif
     // `fresh`: the tiles may have been written by a matrix instruction within the last 12 issue slots
     if (fresh) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     // levels over lane bits 3 and 2 inside a 16-lane row (masked DPP adds: bank_mask write-enables the lanes whose bit selects the
-    // register), then plain sums over bits 1 and 0.  Two wait states between a write and a DPP read of the same register: the two
-    // tiles are interleaved, s_nop where that is not enough.
+    // register), then plain sums over bits 1 and 0; every read of a register is at least three issue slots behind its writer (the
+    // architecture asks for two between a vector-ALU write and a DPP read): the two tiles are interleaved, s_nop where that is not enough
     asm volatile(
         "s_nop 1\n\t"
         "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
@@ -1253,13 +1264,13 @@ AUM_DEV void wave_sum_mfma_finish(WaveSumAcc& acc, bool fresh, vf& s0, vf& s1) {
         "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
         "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
         "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
         "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
         "v_add_f32_dpp %4, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "s_nop 0\n\t"
+        "s_nop 1\n\t"
         "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
+        "s_nop 1\n\t"
         "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1"

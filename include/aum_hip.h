@@ -377,6 +377,9 @@ typedef struct AumConvTmArgs {
 int aum_conv1d_tm_fwd(const AumConvTmArgs* args, void* stream);
 int aum_conv1d_tm_bwd(const AumConvTmArgs* args, void* stream);
 int32_t aum_conv1d_tm_nparts(int32_t batch, int32_t len);
+/* 1 when the library was built with -DAUM_SCANT_MSUM=1 (aum_scan_tm_bwd sums the dB / dC terms of 16-bit activations on the matrix
+ * pipe, every term rounded to bf16 first); 0 for the default build (fp32 butterflies).  Used by the parity tests to pick the bound. */
+int32_t aum_scan_tm_bwd_matrix_sums(void);
 
 /*
  * Dense projection GEMM on token-major activations (ABI 9): the in_proj / out_proj matrix products of the Mamba block and their

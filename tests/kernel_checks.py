@@ -336,8 +336,8 @@ def check_scan_tm(lib, dev, case, dtype=torch.float32, reverse=False, bidir=Fals
                 assert got.get(k) is None, k
                 continue
             pairs[k] = (got[k], gr[k])
-        if dtype != torch.float32:
-            # 16-bit activations: the 64-channel sums of the dB / dC terms run on the matrix pipe with the TERMS rounded to bf16 (wave.h,
+        if dtype != torch.float32 and int(lib.c.aum_scan_tm_bwd_matrix_sums()):
+            # (builds with -DAUM_SCANT_MSUM=1 only) 16-bit activations: the 64-channel sums of the dB / dC terms run on the matrix pipe with the TERMS rounded to bf16 (wave.h,
             # wave_sum_mfma_*): exact to 2^-8 x the sum of the terms' magnitudes, which on these tiny launches (64 - 128 channels, one
             # outlier delta) can exceed the parity tolerance x the largest element.  Element by element: |got - ref| <= 4 tol max|ref| +
             # 2^-8 S, then the rounding-model share is taken out before the three norms below (the headline-size test holds dB / dC to
