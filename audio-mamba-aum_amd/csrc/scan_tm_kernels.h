@@ -487,6 +487,9 @@ struct ScanTBwdOut {
 // instruction occupies the SIMD's issue for its 8 passes: four per pass cost what 32 DPP adds saved.  Default 0: the butterflies.
 #define AUM_SCANT_MSUM 0
 #endif
+#ifndef AUM_SCANT_TAIL2
+#define AUM_SCANT_TAIL2 1     // 0 (A/B builds): each butterfly complete where its terms exist, as in round 3
+#endif
 #ifndef AUM_SCANT_BABL
 #define AUM_SCANT_BABL 0      // timing experiments only (wrong results): 1 no butterflies, 2 no exponentials, 4 carries at a fixed register index,
 #endif                        // 8 no loads of the next block, 16 no entry-state loads, 32 no B/C reads from LDS
@@ -800,7 +803,14 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             AUM_TMB_STAMP(3);
             vf dCsum = splat(0.f);
             if constexpr (MSUM) wave_sum_mfma_add16(wacc, 0, wsel, pc2);
-            if constexpr (!MSUM) dCsum = (AUM_SCANT_BABL & 1) ? pc[0] + pc[5] : wave_sum16(pc);
+            vf hc[4], hb[4];
+            if constexpr (!MSUM) {
+                // the dC butterfly's 24 independent levels now (16 term registers -> 4); its serial tail runs after the reverse sweep,
+                // interleaved with the dB butterfly's (wave.h, wave_sum16_tail2)
+                if (AUM_SCANT_BABL & 1) hc[0] = pc[0] + pc[5];
+                else if (AUM_SCANT_TAIL2) wave_sum16_head(pc, hc);
+                else dCsum = wave_sum16(pc);
+            }
             AUM_SCHED_FENCE();
             AUM_TMB_STAMP(4);
             // reverse sweep: steps s_hi-1 .. s_lo
@@ -838,7 +848,16 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                 wave_sum_mfma_add16(wacc, 1, wsel, pb2);
             }
             if constexpr (!MSUM) {
-                const vf dBsum = (AUM_SCANT_BABL & 1) ? pb[0] + pb[7] : wave_sum16(pb);
+                vf dBsum;
+                if (AUM_SCANT_BABL & 1) {
+                    dBsum = pb[0] + pb[7];
+                    dCsum = hc[0];
+                } else if (AUM_SCANT_TAIL2) {
+                    wave_sum16_head(pb, hb);
+                    wave_sum16_tail2(hc, hb, dCsum, dBsum);
+                } else {
+                    dBsum = wave_sum16(pb);
+                }
                 // lane l holds the totals of value k = wave_sum16_value_of_lane(l) = (step k >> 1, state 2j + (k & 1)).  The four lanes of a
                 // quad hold the same total and all write it to the same slot: a lane mask here is a branch, and everything the scheduler
                 // sinks below it loses its packed-operand broadcasts (they are folded per basic block)

@@ -974,6 +974,16 @@ inline vf wave_sum16(vf (&v)[16]) {
     }
     return r;
 }
+// the butterfly in two parts (device build: the 24 masked DPP adds / the swaps and quad sums of TWO butterflies interleaved); here the head
+// already forms the totals
+inline void wave_sum16_head(vf (&v)[16], vf (&h)[4]) {
+    h[0] = wave_sum16(v);
+    h[1] = h[2] = h[3] = splat(0.f);
+}
+inline void wave_sum16_tail2(vf (&a)[4], vf (&b)[4], vf& ra, vf& rb) {
+    ra = a[0];
+    rb = b[0];
+}
 inline vf wave_sum32(vf (&v)[32]) {
     vf r;
     AUM_LANES {
@@ -1064,6 +1074,74 @@ AUM_DEV vf wave_sum16(vf (&v)[16]) {
         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
         : "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
     return v[0];
+}
+// wave_sum16 in two parts, so that the serial tails of TWO butterflies (the pass's dC and dB sums) interleave: the levels over lane bits
+// 3 and 2 (24 independent masked DPP adds: 16 values -> 4 registers) ...
+AUM_DEV void wave_sum16_head(vf (&v)[16], vf (&h)[4]) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+        : "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    h[0] = v[0];
+    h[1] = v[1];
+    h[2] = v[2];
+    h[3] = v[3];
+}
+// ... and the levels over bits 4 and 5 (v_permlane16_swap / v_permlane32_swap + sums) and 1, 0 (quad sums) of two butterflies at once: each
+// butterfly's tail alone is a chain of six dependent steps with two idle issue slots in front of every swap / DPP read; interleaved, the
+// other butterfly's instruction fills one of them
+AUM_DEV void wave_sum16_tail2(vf (&a)[4], vf (&b)[4], vf& ra, vf& rb) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %2\n\t"
+        "v_permlane16_swap_b32 %4, %6\n\t"
+        "v_permlane16_swap_b32 %1, %3\n\t"
+        "v_permlane16_swap_b32 %5, %7\n\t"
+        "v_add_f32 %0, %0, %2\n\t"
+        "v_add_f32 %4, %4, %6\n\t"
+        "v_add_f32 %1, %1, %3\n\t"
+        "v_add_f32 %5, %5, %7\n\t"
+        "s_nop 0\n\t"
+        "v_permlane32_swap_b32 %0, %1\n\t"
+        "v_permlane32_swap_b32 %4, %5\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32 %0, %0, %1\n\t"
+        "v_add_f32 %4, %4, %5\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    ra = a[0];
+    rb = b[0];
 }
 AUM_DEV vf wave_sum32(vf (&v)[32]) {
     const int lane = (int)(threadIdx.x & 63u);
