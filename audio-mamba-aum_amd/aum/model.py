@@ -95,9 +95,13 @@ class Block(nn.Module):
         self.mixer = mixer
         self.norm = RMSNorm(dim, eps=eps)
 
-    def forward(self, hidden_states, residual=None):
+    def forward(self, hidden_states, residual=None, time_reversed=False):
+        """time_reversed: the block on the time-reversed sequence, reversed back (the odd layers of `if_bidirectional`) -- add + norm
+        is token-wise, the mixer takes the flag: no flipped copies of hidden_states / residual."""
         hidden_states, residual = rms_norm_fn(hidden_states, self.norm.weight, self.norm.bias, residual=residual,
                                               prenorm=True, residual_in_fp32=True, eps=self.norm.eps)
+        if time_reversed:
+            return self.mixer(hidden_states, time_reversed=True), residual
         return self.mixer(hidden_states), residual
 
 
@@ -192,9 +196,11 @@ class AudioMamba(nn.Module):
                 hidden, residual = layer(hidden, residual)
         else:                                                      # MM:623-638: layer 2i forward, layer 2i+1 on the flipped sequence
             for i in range(len(self.layers) // 2):
+                # flip(layer(flip(h), flip(r))) == layer(h, r, time_reversed=True): the four flipped copies per pair are direction
+                # flags on the conv and scan kernels
                 hf, rf = self.layers[2 * i](hidden, residual)
-                hb, rb = self.layers[2 * i + 1](hidden.flip([1]), None if residual is None else residual.flip([1]))
-                hidden, residual = hf + hb.flip([1]), rf + rb.flip([1])
+                hb, rb = self.layers[2 * i + 1](hidden, residual, time_reversed=True)
+                hidden, residual = hf + hb, rf + rb
         return hidden, residual
 
     def forward(self, x, return_features=False, frontend=None):

@@ -82,8 +82,13 @@ class Mamba(nn.Module):
         return p
 
     # ---- forward (MS:169-311) ---------------------------------------------------------------------
-    def forward(self, hidden_states, inference_params=None):
+    def forward(self, hidden_states, inference_params=None, time_reversed=False):
+        """MS:169.  `time_reversed` (extension, keyword only in practice): the block applied to the time-reversed sequence and reversed
+        back, flip(forward(flip(h))), without the copies -- the odd layers of an `if_bidirectional` model (MM:623-638): every stage but
+        the conv and the scan is token-wise, and those two take a direction flag."""
         conv_state = ssm_state = None
+        if time_reversed and (inference_params is not None or not self.use_fast_path):
+            return self.forward(hidden_states.flip([1]), inference_params).flip([1])
         if inference_params is not None:                                   # streaming inference, MS:176-182
             if self.bimamba_type != "none":
                 raise NotImplementedError("inference caches only make sense for the causal (bimamba_type='none') block")
@@ -94,7 +99,7 @@ class Mamba(nn.Module):
         batch, seqlen, _ = hidden_states.shape
         tm = (ssi.TOKEN_MAJOR and self.use_fast_path and inference_params is None
               and not (ssi._REF_DZ_DROP and self.bimamba_type == "v1")      # that option lives in the channel-major block
-              and self.bimamba_type in ("v1", "none") and ssi.token_major_preferred(batch, self.d_inner, self.bimamba_type == "v1")
+              and ssi.token_major_preferred(batch, self.d_inner, self.bimamba_type != "none")
               and ssi.token_major_ok(self.d_inner, self.d_state, self.d_conv, self.dt_rank,
                                      torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else hidden_states.dtype))
         if tm:
@@ -114,29 +119,35 @@ class Mamba(nn.Module):
                 out = bimamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                        self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A, A_b, None,
                                        None, self.D.float(), delta_bias=self.dt_proj.bias.float(),
-                                       delta_softplus=True)
+                                       delta_softplus=True, reverse=time_reversed)
             elif self.bimamba_type == "v2":
                 A_b = neg_exp(self.A_b_log)
                 out_f = mamba_inner_fn_no_out_proj(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                                    self.dt_proj.weight, A, None, None, self.D.float(),
-                                                   delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
+                                                   delta_bias=self.dt_proj.bias.float(), delta_softplus=True,
+                                                   reverse=time_reversed)
                 out_b = mamba_inner_fn_no_out_proj(xz, self.conv1d_b.weight, self.conv1d_b.bias,
                                                    self.x_proj_b.weight, self.dt_proj_b.weight, A_b, None, None,
                                                    self.D_b.float(), delta_bias=self.dt_proj_b.bias.float(),
-                                                   delta_softplus=True, reverse=True)
-                y = out_f + out_b                                          # (B, E, L), both channel-major
+                                                   delta_softplus=True, reverse=not time_reversed)
+                y = out_f + out_b                                          # (B, E, L) logical, both in xz's storage order
                 if self.if_devide_out:
                     y = y / 2
                 E = y.shape[1]
-                y2 = y.permute(1, 0, 2).reshape(E, batch * seqlen)
-                out = torch.matmul(y2.t(), self.out_proj.weight.t().to(y2.dtype))
+                if tm:
+                    # token-major pipelines: y is the transposed view of (B, L, E) rows -- out_proj on the rows (SSI:517 dispatch)
+                    out = ssi.OutProjTmFn.apply(self.out_proj.weight, y.transpose(1, 2).reshape(batch * seqlen, E))
+                else:
+                    y2 = y.permute(1, 0, 2).reshape(E, batch * seqlen)
+                    out = torch.matmul(y2.t(), self.out_proj.weight.t().to(y2.dtype))
                 if self.out_proj.bias is not None:
                     out = out + self.out_proj.bias.to(out.dtype)
                 out = out.reshape(batch, seqlen, -1)
             else:
                 out = mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                      self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A, None, None,
-                                     self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
+                                     self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True,
+                                     reverse=time_reversed)
         else:       # un-fused composition of the same ops (MS:264-308)
             x, z = xz.chunk(2, dim=1)
             if conv_state is not None:                                     # MS:268-271: the last d_conv inputs

@@ -404,6 +404,29 @@ class InProjTmFn(torch.autograd.Function):
         return dw, (None if dh is None else dh.to(ctx.hdtype))
 
 
+class OutProjTmFn(torch.autograd.Function):
+    """out2d [B*L, D] = y2d [B*L, E] @ W_out^T on token-major rows (SSI:517 for the Bi-Bi block, whose two pipelines share one out_proj,
+    MS:240-246): the same GEMM dispatch as inside the fused inner functions -- forward and data gradient on aum_gemm_tn where the
+    step is faster with it, the weight gradient as split-K batches."""
+
+    @staticmethod
+    def forward(ctx, weight, y2d):
+        w = _cast(weight, _autocast_dtype())
+        y = y2d.to(w.dtype)
+        w_t = _weight_t_for_dgrad(weight, w, y.is_cuda) if ctx.needs_input_grad[1] else None
+        ctx.save_for_backward(w, y, w_t)
+        ctx.wdtype, ctx.ydtype = weight.dtype, y2d.dtype
+        return _gemm_rows(y, w, 2)
+
+    @staticmethod
+    def backward(ctx, dout2d):
+        w, y, w_t = ctx.saved_tensors
+        dout2d = dout2d.to(w.dtype)
+        dy = _gemm_dgrad(dout2d, w, w_t, 4) if ctx.needs_input_grad[1] else None
+        dw = split_k_wgrad(dout2d.t(), y, _pick_splits(y.shape[0], _WGRAD_SPLITS[1]), ctx.wdtype) if ctx.needs_input_grad[0] else None
+        return dw, (None if dy is None else dy.to(ctx.ydtype))
+
+
 def token_major_ok(d_inner, d_state, d_conv, dt_rank, dtype=None):
     """shapes the token-major kernels take (include/aum_hip.h: aum_scan_tm_*, aum_conv1d_tm_*); B and C are read in place from the
     x_proj output rows, so the dt block in front of them has to keep them 16-byte aligned"""
@@ -592,7 +615,8 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     bidir_fused = A_b is not None and L <= aum_hip.get().max_single_pass_len
     if A_b is None or bidir_fused:
         ck_f = aum_hip.scan_ckpt(conv_out, A.shape[1]) if need_bwd and A_b is None else None    # long one-direction rows only
-        out_z, out_pre, _ = aum_hip.scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, reverse,
+        out_z, out_pre, _ = aum_hip.scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus,
+                                             reverse if A_b is None else False,        # Fo-Bi: the directions are A (forward), A_b (reverse)
                                              A_b=A_b, want_out_pre=need_bwd, dmajor=True, x_ck=ck_f)   # SSI:499-507, one launch
         out_pre_b = ck_b = None
     else:   # long rows: two reverse-flag launches, still no flip copies; the chunked kernels checkpoint the chunk-entry states
@@ -644,7 +668,7 @@ def _inner_backward(ctx, dout):
     drop = _REF_DZ_DROP and A_b is not None
     if A_b is None or ctx.bidir_fused:
         g = aum_hip.scan_bwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_z, out_pre, ctx.delta_softplus,
-                             ctx.reverse, A_b=A_b, dz_out=dz, dmajor=True, x_ck=ck_f)        # SSI:541-561, one launch
+                             ctx.reverse if A_b is None else False, A_b=A_b, dz_out=dz, dmajor=True, x_ck=ck_f)        # SSI:541-561, one launch
     else:
         g = aum_hip.scan_bwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_z, out_pre, ctx.delta_softplus, False,
                              dz_out=dz, dmajor=True, x_ck=ck_f)
@@ -727,10 +751,10 @@ class MambaInnerFn(torch.autograd.Function):
     @_custom_fwd
     def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
                 A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True,
-                checkpoint_lvl=1):
+                checkpoint_lvl=1, reverse=False):
         _check_variable_bc(B, C)
         return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
-                              out_proj_bias, A, None, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, False)
+                              out_proj_bias, A, None, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, reverse)
 
     @staticmethod
     @_custom_bwd
@@ -738,7 +762,7 @@ class MambaInnerFn(torch.autograd.Function):
         g = _inner_backward(ctx, dout)
         return (g["dxz"], g["dconv_w"], g["dconv_b"], g["dx_proj_w"], g["ddt_proj_w"], g["dout_proj_w"],
                 g["dout_proj_b"], g["dA"], None, None, g["dD"], g["ddelta_bias"], g["dB_proj_bias"],
-                g["dC_proj_bias"], None, None)
+                g["dC_proj_bias"], None, None, None)
 
 
 class BiMambaInnerFn(torch.autograd.Function):
@@ -749,32 +773,41 @@ class BiMambaInnerFn(torch.autograd.Function):
     @_custom_fwd
     def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
                 A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
-                delta_softplus=True, checkpoint_lvl=1):
+                delta_softplus=True, checkpoint_lvl=1, reverse=False):
+        """`reverse` (extension): the block applied to the time-reversed sequence and reversed back -- flip(fn(flip(xz))) -- without the
+        copies: the conv runs anti-causally and the two scan directions trade their A matrices (MM:623-638, the odd layers of an
+        `if_bidirectional` model)."""
         _check_variable_bc(B, C)
+        ctx.swapped = bool(reverse)
+        if reverse:
+            A, A_b = A_b, A
         return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
-                              out_proj_bias, A, A_b, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, False)
+                              out_proj_bias, A, A_b, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, bool(reverse))
 
     @staticmethod
     @_custom_bwd
     def backward(ctx, dout):
         g = _inner_backward(ctx, dout)
+        dA, dA_b = (g["dA_b"], g["dA"]) if ctx.swapped else (g["dA"], g["dA_b"])
         return (g["dxz"], g["dconv_w"], g["dconv_b"], g["dx_proj_w"], g["ddt_proj_w"], g["dout_proj_w"],
-                g["dout_proj_b"], g["dA"], g["dA_b"], None, None, g["dD"], g["ddelta_bias"], g["dB_proj_bias"],
-                g["dC_proj_bias"], None, None)
+                g["dout_proj_b"], dA, dA_b, None, None, g["dD"], g["ddelta_bias"], g["dB_proj_bias"],
+                g["dC_proj_bias"], None, None, None)
 
 
 def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
                    A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
-                   delta_softplus=True):
+                   delta_softplus=True, reverse=False):
+    """`reverse=True` (extension) == flip(fn(flip(xz))) without the two copies."""
     return MambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
-                              out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+                              out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, 1, reverse)
 
 
 def bimamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
                      A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
-                     delta_softplus=True):
+                     delta_softplus=True, reverse=False):
+    """`reverse=True` (extension) == flip(fn(flip(xz))) without the two copies."""
     return BiMambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
-                                out_proj_bias, A, A_b, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+                                out_proj_bias, A, A_b, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, 1, reverse)
 
 
 def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,

@@ -21,9 +21,15 @@ BF16_GNORM_TOL = 2.5e-2
 BF16_GRAD_TOL = 7e-2
 
 
+@pytest.mark.parametrize("layout", ["dispatch", "token_major"])
 @pytest.mark.parametrize("case", cases.MODEL_CASES, ids=lambda c: c[0])
-def test_audio_mamba_vs_reference_model(case):
+def test_audio_mamba_vs_reference_model(case, layout, monkeypatch):
+    """layout = token_major: the blocks forced onto the token-major kernels wherever their limits allow (AUM_TM_MIN_WAVES = 0) -- Fo-Bi,
+    Fo-Fo and, since round 4, Bi-Bi (two token-major pipelines + OutProjTmFn) and the flip-free `if_bidirectional` layer pairing."""
     from aum.model import AudioMamba
+    if layout == "token_major":
+        import mamba_ssm.ops.selective_scan_interface as ssi
+        monkeypatch.setattr(ssi, "_TM_MIN_WAVES", 0)
     g = load_golden("model")
     name, btype, depth, dim, spec, ncls, batch = case[:7]
     model = AudioMamba(spectrogram_size=spec, depth=depth, embed_dim=dim, num_classes=ncls, bimamba_type=btype,

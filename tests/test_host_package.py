@@ -336,8 +336,8 @@ def test_token_major_module_matches_channel_major(monkeypatch):
     # AuM-Small at batch 64 is 1536 waves: enough for the forward alone, not when a backward follows
     assert ssi.token_major_preferred(64, 768, True, training=False) and not ssi.token_major_preferred(64, 768, True, training=True)
     torch.manual_seed(3)
-    for btype in ("v1", "none"):
-        m = Mamba(64, bimamba_type=btype)
+    for btype in ("v1", "none", "v2"):
+        m = Mamba(64, bimamba_type=btype, if_devide_out=btype == "v2")
         x = torch.randn(2, 70, 64)
         w = torch.randn(2, 70, 64)
         res = []
@@ -351,6 +351,35 @@ def test_token_major_module_matches_channel_major(monkeypatch):
         assert rel_err(res[0][0].numpy(), res[1][0].numpy()) < 1e-5 and rel_err(res[0][1].numpy(), res[1][1].numpy()) < 1e-4
         for k in res[0][2]:
             assert rel_err(res[0][2][k].numpy(), res[1][2][k].numpy()) < 2e-4, (btype, k)
+
+
+def test_time_reversed_block_equals_flip_sandwich(monkeypatch):
+    """Mamba.forward(h, time_reversed=True) == flip(forward(flip(h))) for the three block types in both activation layouts -- outputs,
+    input gradient and every parameter gradient (the odd layers of an `if_bidirectional` model, MM:623-638, run without the four flipped
+    copies per pair: the conv and the scan take direction flags, Fo-Bi's two directions trade their A matrices)."""
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(5)
+    for btype in ("v1", "none", "v2"):
+        m = Mamba(64, bimamba_type=btype, if_devide_out=btype == "v2")
+        with torch.no_grad():
+            for n_, p_ in m.named_parameters():
+                if n_.startswith("A_b_log"):
+                    p_.add_(0.3 * torch.randn_like(p_))          # the two directions must be distinguishable
+        x, w = torch.randn(2, 41, 64), torch.randn(2, 41, 64)
+        for min_waves in (0, 10 ** 9):
+            monkeypatch.setattr(ssi, "_TM_MIN_WAVES", min_waves)
+            res = []
+            for mode in ("flag", "flips"):
+                m.zero_grad()
+                xi = x.clone().requires_grad_(True)
+                y = m(xi, time_reversed=True) if mode == "flag" else m(xi.flip([1])).flip([1])
+                (y * w).sum().backward()
+                res.append((y.detach(), xi.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+            assert rel_err(res[0][0].numpy(), res[1][0].numpy()) < 1e-5, (btype, min_waves)
+            assert rel_err(res[0][1].numpy(), res[1][1].numpy()) < 1e-4, (btype, min_waves)
+            for k in res[0][2]:
+                assert rel_err(res[0][2][k].numpy(), res[1][2][k].numpy()) < 2e-4, (btype, min_waves, k)
 
 
 def test_bench_launches_itself_for_n_gpus():

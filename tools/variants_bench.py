@@ -60,8 +60,11 @@ def run(size, btype, train, batch=64, steps=6, warm=3, frames=1024):
 if __name__ == "__main__":
     # `--only long` runs just the long-form configuration (BASELINE config 5: B = 8, 128 x 8192 frames, L = 4097)
     long_form = lambda: run("base", "v1", True, batch=8, steps=4, warm=2, frames=8192)
-    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "long":
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    if only == "long":
         out, name = [long_form()], "variants_bench_long.json"
+    elif only == "bibi":      # the Bi-Bi block (and Fo-Fo beside it); AUM_DEBUG=1 AUM_TM_MIN_WAVES=1000000000 keeps the channel-major block for A/B
+        out, name = [run("base", "v2", True), run("base", "none", True)], "variants_bench_bibi.json"
     else:
         out = [run("base", "v1", True), run("base", "v1", False), run("base", "v2", True), run("base", "none", True),
                run("small", "v1", True), run("small", "v1", False), run("tiny", "v1", True), run("base", "v1", True, batch=256, steps=3, warm=2), long_form()]
