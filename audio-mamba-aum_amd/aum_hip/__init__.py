@@ -136,6 +136,11 @@ class GemmArgs(C.Structure):
     _fields_ = ([(n, _vp) for n in ("a", "b", "c")] + [(n, _i32) for n in ("m", "n", "k", "lda", "ldb", "ldc", "dtype")] + [("flags", _u32)])
 
 
+class GemmWArgs(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("x", C.c_void_p), ("part", C.c_void_p), ("t", C.c_int64), ("ldy", C.c_int64), ("ldx", C.c_int64),
+                ("n", C.c_int32), ("k", C.c_int32), ("splits", C.c_int32), ("dtype", C.c_int32)]
+
+
 class DtProjArgs(C.Structure):
     _fields_ = ([(n, _vp) for n in ("x", "w", "out")] + [("ntok", _i64)] + [(n, _i32) for n in ("dim", "rank", "ldx", "ldw", "ldo", "dtype")])
 
@@ -149,7 +154,7 @@ EXPORTS = ["aum_gemm_tn", "aum_dtproj_tm_fwd", "aum_xdt_tm_fwd", "aum_proj_fwd",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows",
            "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_ckpt_rows", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_selftest_wave_sum32",
-           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_scan_tm_bwd_matrix_sums"]
+           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_scan_tm_bwd_matrix_sums", "aum_gemm_wgrad"]
 
 
 class Lib:
@@ -178,6 +183,7 @@ class Lib:
         self.c.aum_conv1d_tm_nparts.argtypes = [_i32, _i32]
         self.c.aum_scan_tm_bwd_matrix_sums.argtypes = []
         self.c.aum_gemm_tn.argtypes = [_vp, _vp]
+        self.c.aum_gemm_wgrad.argtypes = [_vp, _vp]
         self.c.aum_dtproj_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_xdt_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_scan_tm_workspace_bytes.restype = _i64
@@ -600,6 +606,41 @@ def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_
 
 
 GEMM_BN, GEMM_BK = 256, 64
+
+
+def gemm_wgrad_supported(y, x):
+    """shapes aum_gemm_wgrad takes (include/aum_hip.h, ABI 10): 16-bit 2-D token-major operands (rows = tokens, unit column stride), both
+    widths multiples of 256"""
+    return (y.dim() == 2 and x.dim() == 2 and y.dtype == x.dtype and y.dtype in (torch.bfloat16, torch.float16) and y.shape[0] == x.shape[0]
+            and y.stride(1) == 1 and x.stride(1) == 1 and y.shape[1] % 256 == 0 and x.shape[1] % 256 == 0 and y.stride(0) % 8 == 0
+            and x.stride(0) % 8 == 0 and y.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and y.shape[0] > 0)
+
+
+def gemm_wgrad_splits(n, k, ncu=256):
+    """token splits that give every CU one workgroup: (n / 256) (k / 256) output tiles x splits ~ the CU count"""
+    tiles = (n // 256) * (k // 256)
+    return max(1, min(64, ncu // max(tiles, 1)))
+
+
+def gemm_wgrad(y, x, splits=None, lib=None, partials=False):
+    """dW (n, k) fp32 = y (t, n)^T @ x (t, k): the weight gradient of a projection from token-major operands (aum_gemm_wgrad: hand-written
+    MFMA kernel with transposing LDS reads, fp32 partial tiles over `splits` token ranges summed in a fixed order by aum_sum_rows)."""
+    lib = lib or get()
+    if not gemm_wgrad_supported(y, x):
+        raise RuntimeError("gemm_wgrad: operands outside the kernel's limits (see gemm_wgrad_supported)")
+    lib.check_tensor(y)
+    lib.check_tensor(x)
+    t, n = y.shape
+    k = x.shape[1]
+    splits = splits or gemm_wgrad_splits(n, k)
+    part = torch.empty((splits, n, k), dtype=torch.float32, device=y.device)
+    a = GemmWArgs()
+    a.y, a.x, a.part = _ptr(y), _ptr(x), _ptr(part)
+    a.t, a.ldy, a.ldx, a.n, a.k, a.splits, a.dtype = t, y.stride(0), x.stride(0), n, k, splits, _DT[y.dtype]
+    _launch(lib.c.aum_gemm_wgrad, a, y, lib, "gemm_wgrad", (t, n, k, y.element_size()))
+    if partials:
+        return part
+    return part[0] if splits == 1 else sum_rows(part, lib=lib)
 
 
 def gemm_tn_supported(a, b):

@@ -50,6 +50,19 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
     return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
 }
 
+extern "C" int aum_gemm_wgrad(const AumGemmWArgs* p, void* stream) {
+    const int rc = aumg::gemm_wgrad_check(p);
+    if (rc != AUM_OK) return rc;
+    const AumGemmWArgs& g = *p;
+    const int nitems = (g.n / 256) * (g.k / 256) * g.splits;
+    const int grid = (nitems + 7) / 8 * 8;          // eight XCD runs of equal length; the surplus workgroups return at once
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    if (g.dtype == AUM_BF16) hipLaunchKernelGGL(aumg::k_gemm_wgrad<true>, dim3(grid), dim3(aumg::THREADS), 0, s, g);
+    else hipLaunchKernelGGL(aumg::k_gemm_wgrad<false>, dim3(grid), dim3(aumg::THREADS), 0, s, g);
+    return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
+}
+
 extern "C" int aum_dtproj_tm_fwd(const AumDtProjArgs* p, void* stream) {
     const int rc = aumd::dtproj_check(p);
     if (rc != AUM_OK) return rc;

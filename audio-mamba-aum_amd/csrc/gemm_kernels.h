@@ -391,4 +391,165 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_persistent(GemmLaunch L)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM (round 4; ABI 10, aum_gemm_wgrad):   C[n][k] = sum over tokens t of Y[t][n] * X[t][k]
+// -- dW_in = dxz^T . hidden (autograd of MS:185-189), dW_out = dout^T . out_z (SSI:563).  Both operands are token-major, i.e. the
+// contraction index is the ROW index of both stored matrices: the MFMA wants 8 consecutive t per lane, memory has them a row pitch apart.
+//   * tiles go HBM -> LDS as they are stored ([64 tokens][256 columns] per operand and K-step, 16-byte chunks by buffer_load ... lds: a wave
+//     instruction is two token rows of 512 bytes), and the fragments are read with ds_read_b64_tr_b16: inside a 16-lane group lane
+//     4 j + q hands in the address of 4 consecutive columns (4 q ..) of token j, and gets back, as lane i, column i of the four tokens --
+//     the 4 x 16 block transposed.  Two reads (tokens 8 g .. + 3, + 4 .. + 7 of lane group g) are one 16 x 32 operand fragment.
+//   * bank conflicts: a token row is 512 bytes, so the eight tokens two lane groups read at once would all sit on the same bank columns;
+//     (a transposing read is served 32 lanes at a time: tokens j and 8 + j, j = 0..3).  The 16-byte chunk c of token t is stored at chunk
+//     c ^ 2 ((t & 3) + 4 ((t >> 3) & 1)) (the swizzle is in the DMA's per-lane SOURCE column, the image stays lane-linear) and the reads apply
+//     the same XOR: the 32 lanes cover the 64 banks once (first version, XOR with 2 (t & 7): tokens j and 8 + j collided, SQ_LDS_BANK_CONFLICT
+//     50 %).  Per-lane address registers for the wave's 8 + 4 fragment columns, token and stage offsets as instruction immediates (Y stages
+//     at 0 / 32 KB, X stages at 64 / 96 KB: every immediate below 64 KB).
+//   * MFMA roles: X fragment = A operand (rows = k), Y fragment = B operand (columns = n): a lane's four accumulator values are four
+//     consecutive k of one n -- 16 contiguous bytes of the fp32 result row.
+//   * K = 32 832 tokens against 36 / 18 output tiles: the token range is split over `splits` workgroups per tile (7 / 14: 252 workgroups),
+//     each writes its fp32 partial tile, the caller sums them in a fixed order (aum_sum_rows): no atomics, bitwise repeatable.
+// ------------------------------------------------------------------------------------------------------------------------------------
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s4v lds_s4v;
+constexpr int W_YOFF = 0, W_XOFF = 2 * TILE_BYTES, W_STAGE = 32 * 512, W_NST = 4;          // four 16 KB stages of Y from 0, of X from 64 KB
+
+// One 1 KB piece global -> LDS, written as inline assembly: behind the builtin the compiler puts `s_waitcnt vmcnt(0)` in front of every
+// transposing read (it cannot tell which LDS-DMA the read depends on), i.e. waits for the pieces it has just requested for LATER stages;
+// with the load opaque to it, the counted waits below are the only ones (first version: 2.2 us per 64-token step with the fragment reads
+// removed altogether -- the loop ran at the memory latency).
+__device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t r, const char* lds_dst, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"((int)(size_t)(__attribute__((address_space(3))) const char*)lds_dst), "v"(voff), "s"(r), "s"(soff)
+                 : "memory", "m0");
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(THREADS, 1) void k_gemm_wgrad(AumGemmWArgs g) {
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = w >> 2, wc = w & 3;
+    const int ntn = g.n / 256, ntk = g.k / 256;
+    // work item (split, tile) of this workgroup.  Every workgroup of a split streams the same token rows, so the items are numbered split-major
+    // and each XCD (blockIdx % 8: its CUs share an L2) takes a contiguous run of them: its ~32 workgroups walk one or two token ranges in step and
+    // fetch each row from HBM once per XCD instead of once per workgroup (numbered tile-major, the kernel ran at HBM's pace: 1.2 GB per launch).
+    const int nitems = ntn * ntk * g.splits, per = (nitems + 7) / 8;
+    const int item = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (((int)blockIdx.x >> 3) >= per || item >= nitems) return;
+    const int s = item / (ntn * ntk);
+    const int id = item - s * (ntn * ntk);
+    const int tk = id % ntk, tn = id / ntk;
+    const int n0 = tn * 256, k0 = tk * 256;
+    const int64_t chunk = ((((int64_t)g.t + g.splits - 1) / g.splits) + 63) / 64 * 64;      // tokens per split, a multiple of the K-step
+    const int64_t t0 = (int64_t)s * chunk;
+    const int rows = (int)(t0 >= g.t ? 0 : (g.t - t0 < chunk ? g.t - t0 : chunk));
+    const int nk = (rows + 31) / 32;            // K-steps of 32 tokens
+
+    const char* y_base = static_cast<const char*>(g.y) + (t0 * g.ldy + n0) * 2;
+    const char* x_base = static_cast<const char*>(g.x) + (t0 * g.ldx + k0) * 2;
+    // rows beyond the split's range are outside the descriptor: they read as zero and add nothing
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(y_base), 0, rows > 0 ? (int)((int64_t)(rows - 1) * g.ldy * 2 + 512) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x_base), 0, rows > 0 ? (int)((int64_t)(rows - 1) * g.ldx * 2 + 512) : 0, 0x00020000);
+
+    // staging: piece c = jj * 8 + w is tokens 2 c, 2 c + 1 of the K-step; lane l fills physical chunk l & 31 of token 2 c + (l >> 5) with
+    // logical chunk (l & 31) ^ swizzle(token)
+    const int trow = 2 * w + (lane >> 5);                          // + 16 jj: token inside the K-step
+    const int csrc = (lane & 31) ^ (2 * ((trow & 3) + 4 * ((trow >> 3) & 1)));
+    const int voff_y = trow * (int)g.ldy * 2 + csrc * 16;
+    const int voff_x = trow * (int)g.ldx * 2 + csrc * 16;
+    const int step_y = 16 * (int)g.ldy * 2, step_x = 16 * (int)g.ldx * 2;           // jj -> jj + 1; a K-step is two of them
+    // a stage = 32 tokens of both operands (16 + 16 KB: two Y and two X pieces per wave), four stages in a ring: the pieces of stage t + 3
+    // are requested when stage t is computed -- three steps (~3 us) of flight time.  (Two 64-token stages, fetched one step ahead, ran at
+    // the memory latency: 2.2 us per step with the fragment reads removed altogether, against 1.5 us for the same bytes in aum_gemm_tn,
+    // whose rows are mostly L2 hits; here every token row is a first touch for its XCD.)
+    auto stage_w = [&](int kstep, int st) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            wg_dma16(ry, lds + W_YOFF + st * W_STAGE + (jj * 8 + w) * 1024, voff_y, (kstep * 2 + jj) * step_y);
+            wg_dma16(rx, lds + W_XOFF + st * W_STAGE + (jj * 8 + w) * 1024, voff_x, (kstep * 2 + jj) * step_x);
+        }
+    };
+
+    // fragment reads: lane = 16 gq + 4 j + q hands in columns 4 q .. 4 q + 3 (chunk q >> 1, half q & 1) of token 8 gq + j (+ 4 for the second
+    // read, + 32 for the second half of the K-step).  Address of logical chunk c: token * 512 + ((c ^ 2 (token & 7)) * 16).
+    const int gq = lane >> 4, j = (lane >> 2) & 3, q = lane & 3;
+    const int swz = 2 * j + 8 * (gq & 1);          // 2 ((token & 3) + 4 ((token >> 3) & 1)): the same for both reads of a fragment and both halves of a K-step
+    const int lane_lo = (8 * gq + j) * 512 + (q >> 1) * 16 + (q & 1) * 8;
+    int ay[8], ax[4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) ay[m] = W_YOFF + lane_lo + (((16 * wr + 2 * m) ^ swz) * 16);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) ax[f] = W_XOFF + lane_lo + (((8 * wc + 2 * f) ^ swz) * 16);
+
+    f4v acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f4v{0.f, 0.f, 0.f, 0.f};
+
+    // fragment loads of one phase = half a K-step's columns of Y: X fragments once per 32 tokens, Y fragments in two halves of four
+#ifndef AUM_WGRAD_ABL
+#define AUM_WGRAD_ABL 0        // timing experiments only (wrong results): 1 plain ds_read_b64, 2 one ds_read_b128 per fragment, 3 no fragment reads
+#endif
+    auto frag = [&](int addr) -> s8v {
+#if AUM_WGRAD_ABL == 1
+        const s4v lo = *reinterpret_cast<const s4v*>(lds + addr), hi = *reinterpret_cast<const s4v*>(lds + addr + 4 * 512);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#elif AUM_WGRAD_ABL == 2
+        return *reinterpret_cast<const s8v*>(lds + (addr & ~15));
+#elif AUM_WGRAD_ABL == 3
+        s8v r;
+        for (int i = 0; i < 8; ++i) r[i] = (short)(addr + i);
+        return r;
+#else
+        const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(lds + addr));
+        const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(lds + addr + 4 * 512));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#endif
+    };
+    auto load_x = [&](s8v (&xf)[4], int st, int ks) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) xf[f] = frag(ax[f] + st + ks * 32 * 512);
+    };
+    auto load_y = [&](s8v (&yf)[4], int st, int ks, int half) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) yf[f] = frag(ay[half * 4 + f] + st + ks * 32 * 512);
+    };
+    // Memory operations retire in issue order: with the four pieces of each of the next two stages behind them, the pieces of stage t have
+    // landed when at most 8 are outstanding (fewer stages were requested near the end: wait for everything there).
+#pragma unroll
+    for (int p = 0; p < W_NST - 1; ++p)
+        if (p < nk) stage_w(p, p);
+    for (int t = 0; t < nk; ++t) {
+        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // everybody's pieces of stage t are in LDS, and everybody is done reading stage t - 1
+        if (t + W_NST - 1 < nk) stage_w(t + W_NST - 1, (t + W_NST - 1) & (W_NST - 1));
+        const int st = (t & (W_NST - 1)) * W_STAGE;
+        // two phases of 16 MFMAs; the second phase's Y fragments are requested before the first phase's MFMAs
+        s8v xf[4], yf[2][4];
+        load_x(xf, st, 0);
+        load_y(yf[0], st, 0, 0);
+        load_y(yf[1], st, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[half * 4 + fn][f] = mfma<BF16>(xf[f], yf[half][fn], acc[half * 4 + fn][f]);
+    }
+
+    // store the fp32 partial tile: lane (gq, i = lane & 15) holds C[n0 + wr * 128 + fn * 16 + i][k0 + wc * 64 + f * 16 + 4 gq + r], r = 0..3
+    float* c_base = g.part + ((int64_t)s * g.n + n0 + wr * 128 + (lane & 15)) * g.k + k0 + wc * 64 + 4 * gq;
+#pragma unroll
+    for (int fn = 0; fn < 8; ++fn)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) *reinterpret_cast<f4v*>(c_base + (int64_t)fn * 16 * g.k + f * 16) = acc[fn][f];
+}
+
 }  // namespace aumg

@@ -300,6 +300,19 @@ def split_k_wgrad(a_mk, b_kn, splits, out_dtype=None):
     return aum_hip.sum_rows(torch.bmm(a3, b3)).to(out_dtype)
 
 
+# The weight gradients of the token-major block's in / out projections (d W = d out^T . input, both operands token-major) on the hand-written
+# kernel aum_gemm_wgrad (csrc/gemm_kernels.h: transposing LDS reads, fp32 partial tiles over token splits summed by aum_sum_rows) instead of the
+# library's strided batched GEMMs.  AUM_DEBUG=1 AUM_WGRAD=lib restores those (A/B runs).
+_HIP_WGRAD = _dbg_env("AUM_WGRAD", "hip") != "lib"
+
+
+def _wgrad_tm(dy2d, x2d, splits_hint, out_dtype):
+    """dW [N, K] = dy2d [T, N]^T @ x2d [T, K] for token-major operands"""
+    if _HIP_WGRAD and _HIP_GEMM and dy2d.is_cuda and aum_hip.gemm_wgrad_supported(dy2d, x2d):
+        return aum_hip.gemm_wgrad(dy2d, x2d).to(out_dtype)
+    return split_k_wgrad(dy2d.t(), x2d, _pick_splits(x2d.shape[0], splits_hint), out_dtype)
+
+
 class InProjFn(torch.autograd.Function):
     """xz2d [2E, B*L] = W [2E, D] @ hidden2d[B*L, D]^T (MS:185-189: matmul and BLH -> HBL transpose in one GEMM) with the
     split-K weight gradient above; autocast casts both operands like F.linear would."""
@@ -400,7 +413,7 @@ class InProjTmFn(torch.autograd.Function):
         w, h, w_t = ctx.saved_tensors
         dxz2d = dxz2d.to(w.dtype)
         dh = _gemm_dgrad(dxz2d, w, w_t, 8) if ctx.needs_input_grad[1] else None
-        dw = split_k_wgrad(dxz2d.t(), h, _pick_splits(h.shape[0], _WGRAD_SPLITS[0]), ctx.wdtype) if ctx.needs_input_grad[0] else None
+        dw = _wgrad_tm(dxz2d, h, _WGRAD_SPLITS[0], ctx.wdtype) if ctx.needs_input_grad[0] else None
         return dw, (None if dh is None else dh.to(ctx.hdtype))
 
 
@@ -423,7 +436,7 @@ class OutProjTmFn(torch.autograd.Function):
         w, y, w_t = ctx.saved_tensors
         dout2d = dout2d.to(w.dtype)
         dy = _gemm_dgrad(dout2d, w, w_t, 4) if ctx.needs_input_grad[1] else None
-        dw = split_k_wgrad(dout2d.t(), y, _pick_splits(y.shape[0], _WGRAD_SPLITS[1]), ctx.wdtype) if ctx.needs_input_grad[0] else None
+        dw = _wgrad_tm(dout2d, y, _WGRAD_SPLITS[1], ctx.wdtype) if ctx.needs_input_grad[0] else None
         return dw, (None if dy is None else dy.to(ctx.ydtype))
 
 
@@ -524,8 +537,7 @@ def _inner_backward_tm(ctx, dout):
     if ctx.has_out_proj:
         dout2 = dout.reshape(Bsz * L, -1).to(out_proj_weight.dtype)
         dout_z = _gemm_dgrad(dout2, out_proj_weight, out_proj_wt, 4).view(Bsz, L, E).to(conv_out.dtype)     # SSI:540
-        dout_proj_weight = split_k_wgrad(dout2.t(), out_z.view(Bsz * L, E), _pick_splits(dout2.shape[0], _WGRAD_SPLITS[1]),
-                                         ctx.out_proj_wdtype)                                 # SSI:563
+        dout_proj_weight = _wgrad_tm(dout2, out_z.view(Bsz * L, E), _WGRAD_SPLITS[1], ctx.out_proj_wdtype)       # SSI:563
         dout_proj_bias = dout2.sum(0) if not ctx.out_proj_bias_is_None else None
     else:
         dout_z = dout.transpose(1, 2)

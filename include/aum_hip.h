@@ -402,6 +402,26 @@ typedef struct AumGemmArgs {
 int aum_gemm_tn(const AumGemmArgs* args, void* stream);
 
 /*
+ * Weight-gradient GEMM of the in / out projections on token-major operands (ABI 10; autograd of mamba_simple.py:185-189 and
+ * selective_scan_interface.py:563: d W = d out^T . input):
+ *   part[s][n][k] = sum over the tokens t of split s of  y[t][n] * x[t][k]          s = 0 .. splits - 1
+ *   y: (t, n) rows of pitch ldy (the output gradient);  x: (t, k) rows of pitch ldx (the layer's input) -- pitches in ELEMENTS, both `dtype`
+ *   (AUM_BF16 / AUM_F16; else AUM_E_DTYPE);  part: (splits, n, k) fp32, contiguous: the caller sums the splits in a fixed order (aum_sum_rows).
+ *   Split s takes tokens [s c, min(t, (s + 1) c)) with c = ceil(ceil(t / splits) / 64) * 64 (a split may be empty: its tile is zero).
+ *   n % 256 == 0, k % 256 == 0, splits <= 64, pitches % 8 == 0, 16-byte aligned pointers, c * pitch * 2 < 2 GiB (else AUM_E_UNSUPPORTED: callers
+ *   use a library GEMM).  fp32 accumulation; no atomics: the result is bitwise repeatable.
+ */
+typedef struct AumGemmWArgs {
+    const void *y, *x;
+    float* part;
+    int64_t t;
+    int64_t ldy, ldx;
+    int32_t n, k, splits;
+    int32_t dtype;
+} AumGemmWArgs;
+int aum_gemm_wgrad(const AumGemmWArgs* args, void* stream);
+
+/*
  * dt projection of the token-major block (ABI 9): delta = x_dbl[:, :dt_rank] . dt_proj.weight^T (selective_scan_interface.py:468 without
  * its transposes; the bias and the softplus stay in the scan, as in the reference).
  *   x: (ntok, >= rank) rows of pitch ldx, the first `rank` columns are read (x_dbl: the dt block sits in front of B and C);

@@ -29,6 +29,30 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void*) {
     return AUM_OK;
 }
 
+// aum_gemm_wgrad on host pointers: same arrangement (shared argument rules and split boundaries, arithmetic as a plain loop).
+extern "C" int aum_gemm_wgrad(const AumGemmWArgs* p, void*) {
+    const int rc = aumg::gemm_wgrad_check(p);
+    if (rc != AUM_OK) return rc;
+    const int64_t chunk = (((p->t + p->splits - 1) / p->splits) + 63) / 64 * 64;
+    auto run = [&](auto tag) {
+        using T = decltype(tag);
+        const T* y = static_cast<const T*>(p->y);
+        const T* x = static_cast<const T*>(p->x);
+        for (int s = 0; s < p->splits; ++s) {
+            const int64_t t0 = s * chunk, t1 = t0 + chunk < p->t ? t0 + chunk : p->t;
+            for (int n = 0; n < p->n; ++n)
+                for (int k = 0; k < p->k; ++k) {
+                    float acc = 0.f;
+                    for (int64_t t = t0; t < t1; ++t) acc += aum::elem_to_f32(y[t * p->ldy + n]) * aum::elem_to_f32(x[t * p->ldx + k]);
+                    p->part[((int64_t)s * p->n + n) * p->k + k] = acc;
+                }
+        }
+    };
+    if (p->dtype == AUM_BF16) run(aum::bf16_t{});
+    else run(aum::f16_t{});
+    return AUM_OK;
+}
+
 // aum_dtproj_tm_fwd on host pointers: same arrangement as aum_gemm_tn above (argument rules shared, arithmetic as a plain loop).
 #include "../../audio-mamba-aum_amd/csrc/dtproj_args.h"
 extern "C" int aum_dtproj_tm_fwd(const AumDtProjArgs* p, void*) {

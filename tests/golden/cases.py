@@ -328,6 +328,9 @@ GEMM_CASES = [
     ("m385_n512_k128", 385, 512, 128, 0, 0),
     ("m576_n512_k192", 576, 512, 192, 0, 0),
 ]
+# aum_gemm_wgrad: (tokens, n, k, splits, pad_y, pad_x) -- one K-step, ragged last step, empty splits, both operands slices of wider rows
+GEMM_WGRAD_CASES = [(64, 256, 256, 1, 0, 0), (65, 256, 256, 1, 0, 0), (200, 256, 512, 2, 0, 0), (513, 512, 256, 3, 8, 16), (130, 256, 256, 7, 0, 8),
+                    (1026, 768, 256, 4, 768, 0)]
 # (the GPU-only sizes below also cover more items than CUs: several tiles per workgroup, odd and even step counts)
 # on the GPU only (the host build's triple loop would take minutes): the bench's own GEMMs, (m, n, k) of in_proj / out_proj forward and
 # data gradient at 64 x 513 tokens and at 3 x 513 tokens

@@ -486,6 +486,28 @@ def check_gemm(lib, dev, case, dtype, flags=0):
         assert torch.all(c_full[:, :pad_c] == 7.0), "columns outside the result were written"
 
 
+def check_gemm_wgrad(lib, dev, t, n, k, splits, dtype, pad_y=0, pad_x=0):
+    """aum_gemm_wgrad (ABI 10; autograd of MS:185-189, SSI:563) against an fp64 product of the same 16-bit token-major operands: every
+    split's partial tile (its token range, an empty split = zeros) and the summed result; operands may be column slices of wider rows"""
+    g = torch.Generator().manual_seed(t * 7 + n + k + splits)
+    y_full = (torch.randn(t, n + pad_y, generator=g)).to(dtype).to(dev)
+    x_full = (torch.randn(t, k + pad_x, generator=g)).to(dtype).to(dev)
+    y, x = y_full[:, pad_y:], x_full[:, :k]
+    part = aum_hip.gemm_wgrad(y, x, splits=splits, lib=lib, partials=True)
+    assert part.shape == (splits, n, k) and part.dtype == torch.float32
+    chunk = (((t + splits - 1) // splits) + 63) // 64 * 64
+    yd, xd = y.double().cpu(), x.double().cpu()
+    scale = float((yd.t() @ xd).abs().max()) + 1e-30
+    for s_ in range(splits):
+        t0, t1 = min(s_ * chunk, t), min((s_ + 1) * chunk, t)
+        ref = yd[t0:t1].t() @ xd[t0:t1]
+        err = (part[s_].double().cpu() - ref).abs().max().item()
+        assert err <= 2e-6 * scale * max(1.0, (t1 - t0) ** 0.5 / 8), (t, n, k, splits, s_, err, scale)      # fp32 accumulation of exact 16-bit products
+    total = aum_hip.gemm_wgrad(y, x, splits=splits, lib=lib)
+    assert rel_err(N(total), (yd.t() @ xd).numpy()) < 1e-5
+    assert torch.equal(total, aum_hip.gemm_wgrad(y, x, splits=splits, lib=lib))
+
+
 def check_gemm_args(lib, dev):
     """argument rules of aum_gemm_tn (csrc/gemm_args.h): refused shapes return an error code, nothing is launched"""
     a = torch.zeros(8, 64, dtype=torch.bfloat16, device=dev)

@@ -60,6 +60,7 @@ def test_struct_layouts_match_header(tmp_path):
         "AumDtProjArgs": (aum_hip.DtProjArgs, ["x", "w", "out", "ntok", "dim", "rank", "ldx", "ldw", "ldo", "dtype"]),
         "AumXdtArgs": (aum_hip.XdtArgs, ["u", "wx", "wdt", "x_dbl", "delta", "ntok", "dim", "rank", "ncols", "ldu", "ldwx", "ldwdt", "ldx", "ldd", "dtype"]),
         "AumGemmArgs": (aum_hip.GemmArgs, ["a", "b", "c", "m", "n", "k", "lda", "ldb", "ldc", "dtype", "flags"]),
+        "AumGemmWArgs": (aum_hip.GemmWArgs, ["y", "x", "part", "t", "ldy", "ldx", "n", "k", "splits", "dtype"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']
     for cname, (_, fields) in probes.items():

@@ -266,3 +266,10 @@ def test_scan_tm_grid_small(emu):
     units -> forward workgroups of 2 and backward workgroups of 3 pairs, both with a ragged last workgroup"""
     rows = {0: [0, 63, 64, 191], 1: [5, 100], 2: [128, 127], 4: [0, 191, 77]}
     KC.check_scan_tm_grid(emu, "cpu", 5, 41, 192, rows, (0, 4), [0, 63, 64, 191], 1)
+
+
+@pytest.mark.parametrize("case", cases.GEMM_WGRAD_CASES[:4], ids=lambda c: "x".join(map(str, c)))
+def test_gemm_wgrad_contract(emu, case):
+    """the host twin of aum_gemm_wgrad (tests/emu/aum_emu.cpp: shared argument rules and split boundaries): what the host-side dispatch
+    tests run against; the device kernel's own parity is test_gpu_kernels.py::test_gemm_wgrad*"""
+    KC.check_gemm_wgrad(emu, "cpu", *case[:4], torch.bfloat16, *case[4:])

@@ -475,6 +475,28 @@ def test_gemm_tn(lib, case, dtype, sched):
     KC.check_gemm(lib, "cuda", case, dtype, flags={"auto": 0, "persistent": aum_hip.GEMM_PERSISTENT, "lockstep": aum_hip.GEMM_LOCKSTEP, "staggered": aum_hip.GEMM_STAGGERED}[sched])
 
 
+@pytest.mark.parametrize("case", cases.GEMM_WGRAD_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_wgrad(lib, case, dtype):
+    KC.check_gemm_wgrad(lib, "cuda", *case[:4], dtype, *case[4:])
+
+
+def test_gemm_wgrad_full_size(lib):
+    """the bench's two weight-gradient GEMMs (64 x 513 tokens; d W_in = dxz^T . hidden: 36 tiles x 7 splits, d W_out = dout^T . out_z: 18 x 14)
+    against fp64 on sampled rows of the result, with the operands laid out as the block has them, bitwise repeatable"""
+    t = 64 * 513
+    for n, k in ((3072, 768), (768, 1536)):
+        torch.manual_seed(n + k)
+        y = (torch.randn(t, n, device="cuda") * 0.1).to(torch.bfloat16)
+        x = torch.randn(t, k, device="cuda").to(torch.bfloat16)
+        out = aum_hip.gemm_wgrad(y, x, lib=lib)
+        rows = torch.cat([torch.arange(0, 40, device="cuda"), torch.randint(0, n, (60,), device="cuda"), torch.arange(n - 40, n, device="cuda")])
+        ref = y[:, rows].double().t() @ x.double()
+        assert (out[rows].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), (n, k)
+        for _ in range(2):
+            assert torch.equal(out, aum_hip.gemm_wgrad(y, x, lib=lib))
+
+
 def test_gemm_tn_argument_rules(lib):
     KC.check_gemm_args(lib, "cuda")
 
