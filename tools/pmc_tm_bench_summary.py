@@ -15,6 +15,7 @@ NAMES = [("k_scant_bwd<aum::bf16_t, true, true, true>", "scan_tm_bwd_bidir"), ("
          ("k_scant_fwd<aum::bf16_t, false, true, false, true>", "scan_tm_fwd_bidir_inference"),
          ("k_scant_bwd_reduce", "scan_tm_bwd_reduce"), ("k_convt_fwd<aum::bf16_t", "conv_tm_fwd"), ("k_convt_bwd<aum::bf16_t", "conv_tm_bwd")]
 stamp = {"_commit": os.environ.get("AUM_COMMIT", "unknown"), "_date": datetime.date.today().isoformat()}
+SRC = os.environ.get("AUM_PMC_SOURCE", "tools/tm_time.py")
 
 
 def collect(path):
@@ -28,7 +29,7 @@ def collect(path):
 
 
 fetch, write, valu = collect(out + "/FETCH_SIZE.csv"), collect(out + "/WRITE_SIZE.csv"), collect(out + "/valu.csv")
-tr = dict(stamp, _method="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/tm_time.py (B=64, E=1536, L=513, bf16, "
+tr = dict(stamp, _method="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over " + SRC + " (B=64, E=1536, L=513, bf16, "
           "[x | z] rows); units KiB, mean over the launches of each kernel; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a "
           "wide coalesced read: calibrated in round 2 with a 1 GiB copy, profiles/pmc_traffic.json hbm_copy)")
 for k in sorted(set(fetch) | set(write)):
@@ -36,7 +37,7 @@ for k in sorted(set(fetch) | set(write)):
     tr[k] = int(rd + wr)
     tr[k + "_detail"] = {"read_bytes_corrected": int(rd), "write_bytes": int(wr)}
 json.dump(tr, open(out + "/pmc_traffic_tm.json", "w"), indent=1)
-vb = dict(stamp, _method="rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over tools/tm_time.py; "
+vb = dict(stamp, _method="rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over " + SRC + "; "
           "busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)")
 for k, m in sorted(valu.items()):
     a, i, g = m.get("SQ_ACTIVE_INST_VALU", 0.0), m.get("SQ_INSTS_VALU", 0.0), m.get("GRBM_GUI_ACTIVE", 0.0)
