@@ -141,6 +141,17 @@ class GemmWArgs(C.Structure):
                 ("n", C.c_int32), ("k", C.c_int32), ("splits", C.c_int32), ("dtype", C.c_int32)]
 
 
+class ConvUpdateArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("conv_state", C.c_void_p), ("weight", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+                ("batch", C.c_int32), ("dim", C.c_int32), ("width", C.c_int32), ("dtype", C.c_int32), ("flags", C.c_uint32)]
+
+
+class StateUpdateArgs(C.Structure):
+    _fields_ = [("state", C.c_void_p), ("x", C.c_void_p), ("dt", C.c_void_p), ("z", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+                ("A", C.c_void_p), ("D", C.c_void_p), ("dt_bias", C.c_void_p), ("out", C.c_void_p),
+                ("batch", C.c_int32), ("dim", C.c_int32), ("dstate", C.c_int32), ("dtype", C.c_int32), ("flags", C.c_uint32)]
+
+
 class DtProjArgs(C.Structure):
     _fields_ = ([(n, _vp) for n in ("x", "w", "out")] + [("ntok", _i64)] + [(n, _i32) for n in ("dim", "rank", "ldx", "ldw", "ldo", "dtype")])
 
@@ -154,7 +165,7 @@ EXPORTS = ["aum_gemm_tn", "aum_dtproj_tm_fwd", "aum_xdt_tm_fwd", "aum_proj_fwd",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows",
            "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_ckpt_rows", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_selftest_wave_sum32",
-           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_scan_tm_bwd_matrix_sums", "aum_gemm_wgrad"]
+           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_scan_tm_bwd_matrix_sums", "aum_gemm_wgrad", "aum_causal_conv1d_update", "aum_selective_state_update"]
 
 
 class Lib:
@@ -184,6 +195,8 @@ class Lib:
         self.c.aum_scan_tm_bwd_matrix_sums.argtypes = []
         self.c.aum_gemm_tn.argtypes = [_vp, _vp]
         self.c.aum_gemm_wgrad.argtypes = [_vp, _vp]
+        self.c.aum_causal_conv1d_update.argtypes = [_vp, _vp]
+        self.c.aum_selective_state_update.argtypes = [_vp, _vp]
         self.c.aum_dtproj_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_xdt_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_scan_tm_workspace_bytes.restype = _i64
@@ -678,6 +691,47 @@ def gemm_tn(a, b, out=None, lib=None, flags=0):
     g.m, g.n, g.k, g.lda, g.ldb, g.ldc, g.dtype = m, n, k, a.stride(0), b.stride(0), out.stride(0), _DT[a.dtype]
     g.flags = flags
     _launch(lib.c.aum_gemm_tn, g, a, lib, "gemm_tn", (m, n, k))
+    return out
+
+
+def conv1d_update(x, conv_state, weight, bias=None, silu=True, lib=None):
+    """one token of the causal conv (aum_causal_conv1d_update): x (batch, dim); conv_state (batch, dim, width) fp32 contiguous, shifted and
+    extended IN PLACE; weight (dim, width); returns act(<window, weight> + bias) (batch, dim) in x's dtype"""
+    lib = lib or get()
+    if x.dim() != 2 or conv_state.dim() != 3 or conv_state.shape[:2] != x.shape or conv_state.dtype != torch.float32 or not conv_state.is_contiguous():
+        raise RuntimeError("conv1d_update: x (batch, dim), conv_state (batch, dim, width) fp32 contiguous")
+    for t in (x, conv_state):
+        lib.check_tensor(t)
+    x = x.contiguous()
+    weight, bias = _f32c(weight.reshape(x.shape[1], -1)), _f32c(bias)
+    out = torch.empty_like(x)
+    a = ConvUpdateArgs()
+    a.x, a.conv_state, a.weight, a.bias, a.out = _ptr(x), _ptr(conv_state), _ptr(weight), _ptr(bias), _ptr(out)
+    a.batch, a.dim, a.width, a.dtype, a.flags = x.shape[0], x.shape[1], conv_state.shape[2], _DT[x.dtype], (CONV_SILU if silu else 0)
+    _launch(lib.c.aum_causal_conv1d_update, a, x, lib, "conv1d_update")
+    return out
+
+
+def state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None, dt_softplus=False, lib=None):
+    """one token of the selective scan (aum_selective_state_update): state (batch, dim, dstate) fp32 contiguous, advanced IN PLACE;
+    x, dt, z (batch, dim), B, C (batch, dstate) in one dtype; A (dim, dstate), D, dt_bias (dim); returns (batch, dim) in x's dtype"""
+    lib = lib or get()
+    if state.dim() != 3 or state.dtype != torch.float32 or not state.is_contiguous() or x.shape != state.shape[:2]:
+        raise RuntimeError("state_update: state (batch, dim, dstate) fp32 contiguous, x (batch, dim)")
+    for t in (state, x, dt, z, B, C):
+        lib.check_tensor(t)
+    dty = x.dtype
+    x, dt, B, C = x.contiguous(), dt.to(dty).contiguous(), B.to(dty).contiguous(), C.to(dty).contiguous()
+    z = None if z is None else z.to(dty).contiguous()
+    if dt.shape != x.shape or B.shape != (x.shape[0], state.shape[2]) or C.shape != B.shape or (z is not None and z.shape != x.shape):
+        raise RuntimeError("state_update: dt, z (batch, dim); B, C (batch, dstate)")
+    A, D, dt_bias = _f32c(A), _f32c(D), _f32c(dt_bias)
+    out = torch.empty_like(x)
+    a = StateUpdateArgs()
+    a.state, a.x, a.dt, a.z, a.B, a.C = _ptr(state), _ptr(x), _ptr(dt), _ptr(z), _ptr(B), _ptr(C)
+    a.A, a.D, a.dt_bias, a.out = _ptr(A), _ptr(D), _ptr(dt_bias), _ptr(out)
+    a.batch, a.dim, a.dstate, a.dtype, a.flags = x.shape[0], x.shape[1], state.shape[2], _DT[dty], (SCAN_SOFTPLUS if dt_softplus else 0)
+    _launch(lib.c.aum_selective_state_update, a, x, lib, "state_update")
     return out
 
 

@@ -32,5 +32,14 @@ def causal_conv1d_fn(x, weight, bias=None, activation=None):
     return CausalConv1dFn.apply(x, weight, bias, activation)
 
 
-def causal_conv1d_update(*args, **kwargs):
-    raise NotImplementedError("single-token decode (Mamba.step) is out of scope: AuM never decodes (SURVEY 2.1 #2)")
+def causal_conv1d_update(x, conv_state, weight, bias=None, activation=None):
+    """One token of streaming inference (the wheel's function of the same name, call site MS:328-334): x (batch, dim); conv_state (batch, dim,
+    width) is shifted left and extended by x IN PLACE; returns act(sum(conv_state * weight, -1) + bias) in x's dtype (aum_causal_conv1d_update;
+    a cache that is not fp32 goes through an fp32 copy and is written back)."""
+    if activation not in (None, "silu", "swish"):
+        raise NotImplementedError("activation must be None, silu, or swish")
+    st = conv_state if conv_state.dtype == torch.float32 and conv_state.is_contiguous() else conv_state.float().contiguous()
+    out = aum_hip.conv1d_update(x, st, weight, bias, activation in ("silu", "swish"))
+    if st is not conv_state:
+        conv_state.copy_(st)
+    return out

@@ -4,6 +4,7 @@
 #include "gemm_kernels.h"
 #include "dtproj_kernels.h"
 #include "xdt_kernels.h"
+#include "decode_kernels.h"
 
 extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
     const int rc = aumg::gemm_check(p);
@@ -89,5 +90,31 @@ extern "C" int aum_xdt_tm_fwd(const AumXdtArgs* p, void* stream) {
     else if (bf) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<true, 2>), grid, block, 0, s, g);
     else if (one) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<false, 1>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<false, 2>), grid, block, 0, s, g);
+    return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
+}
+
+extern "C" int aum_causal_conv1d_update(const AumConvUpdateArgs* p, void* stream) {
+    const int rc = aumdec::conv_update_check(p);
+    if (rc != AUM_OK) return rc;
+    const int64_t n = (int64_t)p->batch * p->dim;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    if (p->dtype == AUM_F32) hipLaunchKernelGGL(aumdec::k_conv_update<float>, grid, block, 0, s, *p);
+    else if (p->dtype == AUM_BF16) hipLaunchKernelGGL(aumdec::k_conv_update<__bf16>, grid, block, 0, s, *p);
+    else hipLaunchKernelGGL(aumdec::k_conv_update<_Float16>, grid, block, 0, s, *p);
+    return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
+}
+
+extern "C" int aum_selective_state_update(const AumStateUpdateArgs* p, void* stream) {
+    const int rc = aumdec::state_update_check(p);
+    if (rc != AUM_OK) return rc;
+    const int64_t n = (int64_t)p->batch * p->dim;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    if (p->dtype == AUM_F32) hipLaunchKernelGGL(aumdec::k_state_update<float>, grid, block, 0, s, *p);
+    else if (p->dtype == AUM_BF16) hipLaunchKernelGGL(aumdec::k_state_update<__bf16>, grid, block, 0, s, *p);
+    else hipLaunchKernelGGL(aumdec::k_state_update<_Float16>, grid, block, 0, s, *p);
     return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
 }

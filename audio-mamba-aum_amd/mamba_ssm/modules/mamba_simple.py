@@ -17,7 +17,8 @@ import torch.nn.functional as F
 from mamba_ssm.ops.selective_scan_interface import (InProjFn, bimamba_inner_fn, mamba_inner_fn, mamba_inner_fn_no_out_proj,
                                                     neg_exp, selective_scan_fn)
 import mamba_ssm.ops.selective_scan_interface as ssi
-from causal_conv1d import causal_conv1d_fn
+from causal_conv1d import causal_conv1d_fn, causal_conv1d_update
+from mamba_ssm.ops.triton.selective_state_update import selective_state_update
 
 
 class Mamba(nn.Module):
@@ -170,35 +171,24 @@ class Mamba(nn.Module):
         return out
 
     def step(self, hidden_states, conv_state, ssm_state):
-        """One token of streaming inference for the causal block: (batch, 1, d_model) in, (batch, 1, d_model) out, the caches
-        conv_state (batch, d_inner, d_conv) and ssm_state (batch, d_inner, d_state) advanced in place.  Written from the block's
-        recurrence -- the same four stages as `forward` on a sequence of length one:
-            window  <- last d_conv inputs of the conv;           xc = silu(<window, w> + b)
-            (dt, B, C) = x_proj(xc);                             delta = softplus(dt W_dt^T + b_dt)
-            h <- exp(delta A) * h + (delta xc) B^T;              y = <h, C> + D xc
-            out = out_proj(y * silu(z))
-        Decode is outside SURVEY section 8's hot path: plain torch ops on (batch, d_inner[, d_state]) tensors, no kernels of their own."""
+        """One token of streaming inference for the causal block (MS:313-358): (batch, 1, d_model) in, (batch, 1, d_model) out, the caches
+        conv_state (batch, d_inner, d_conv) and ssm_state (batch, d_inner, d_state) advanced in place -- the block's four stages on a
+        sequence of length one, the two recurrent ones on the library's per-token kernels (round 4):
+            xc = causal_conv1d_update(x, conv_state, w, b, silu)                 window <- last d_conv inputs; silu(<window, w> + b)
+            (dt, B, C) = x_proj(xc);   dt = dt W_dt^T                            (bias and softplus inside the state update, MS:340)
+            y = selective_state_update(ssm_state, xc, dt, A, B, C, D, z, dt_bias, softplus)
+            out = out_proj(y)"""
         if hidden_states.dim() != 3 or hidden_states.shape[1] != 1:
             raise ValueError("step() advances the caches by exactly one token: hidden_states must be (batch, 1, d_model)")
-        E, N, R, W = self.d_inner, self.d_state, self.dt_rank, self.d_conv
-        io_dtype = hidden_states.dtype
+        E, N, R = self.d_inner, self.d_state, self.dt_rank
         x_new, z = self.in_proj(hidden_states[:, 0]).split(E, dim=-1)
-        # slide the window one position to the left and append the new input
-        conv_state[:, :, :W - 1] = conv_state[:, :, 1:].clone()
-        conv_state[:, :, W - 1] = x_new
-        taps = self.conv1d.weight.view(E, W)
-        pre = (conv_state * taps).sum(dim=2)
-        if self.conv1d.bias is not None:
-            pre = pre + self.conv1d.bias
-        xc = F.silu(pre).to(io_dtype)
+        xc = causal_conv1d_update(x_new, conv_state, self.conv1d.weight.view(E, self.d_conv), self.conv1d.bias, self.activation)
         proj = self.x_proj(xc)
         dt_in, B_t, C_t = proj[:, :R], proj[:, R:R + N], proj[:, R + N:R + 2 * N]
-        delta = F.softplus(F.linear(dt_in, self.dt_proj.weight, self.dt_proj.bias.to(dt_in.dtype)))     # (batch, E)
-        decay = torch.exp(delta.unsqueeze(2) * (-torch.exp(self.A_log.float())))                       # (batch, E, N)
-        drive = (delta * xc).unsqueeze(2) * B_t.unsqueeze(1)                                           # (batch, E, N)
-        ssm_state.mul_(decay.to(ssm_state.dtype)).add_(drive.to(ssm_state.dtype))
-        y = (ssm_state.to(io_dtype) * C_t.unsqueeze(1)).sum(dim=2) + self.D.to(io_dtype) * xc
-        return self.out_proj(y * F.silu(z)).unsqueeze(1), conv_state, ssm_state
+        dt = F.linear(dt_in, self.dt_proj.weight)                                   # the bias is not added here (MS:340)
+        y = selective_state_update(ssm_state, xc, dt, -torch.exp(self.A_log.float()), B_t, C_t, self.D, z=z, dt_bias=self.dt_proj.bias,
+                                   dt_softplus=True)
+        return self.out_proj(y).unsqueeze(1), conv_state, ssm_state
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         """MS:360-373"""

@@ -458,6 +458,39 @@ typedef struct AumXdtArgs {
 } AumXdtArgs;
 int aum_xdt_tm_fwd(const AumXdtArgs* args, void* stream);
 
+/*
+ * Streaming inference, one token per call (ABI 10; mamba_simple.py:313-358 `Mamba.step`).  The caches are fp32, contiguous, updated in place.
+ *
+ * aum_causal_conv1d_update -- `causal_conv1d_update(x, conv_state, weight, bias, activation)` of the causal_conv1d wheel (call site
+ *   mamba_simple.py:328-334; arithmetic = the fallback at :322-327): conv_state (batch, dim, width) <- (conv_state[..., 1:], x);
+ *   out (batch, dim) = act(sum_k conv_state[..., k] * weight[dim][k] + bias).  x / out: `dtype`, contiguous; weight (dim, width), bias (dim) fp32;
+ *   flags: AUM_CONV_SILU.  width <= 8.
+ * aum_selective_state_update -- `selective_state_update(state, x, dt, A, B, C, D, z, dt_bias, dt_softplus)` (ops/triton/selective_state_update.py:
+ *   157-192, call site mamba_simple.py:352-354): dt' = softplus?(dt + dt_bias); state (batch, dim, dstate) <- exp(dt' A) state + dt' x B;
+ *   out (batch, dim) = (<state, C> + D x) * silu(z).  x, dt, z, out (batch, dim) and B, C (batch, dstate): `dtype`, contiguous; A (dim, dstate),
+ *   D, dt_bias (dim) fp32 (D, dt_bias, z may be NULL);  flags: AUM_SCAN_SOFTPLUS.  dstate <= 256.
+ */
+typedef struct AumConvUpdateArgs {
+    const void* x;
+    float* conv_state;
+    const float *weight, *bias;
+    void* out;
+    int32_t batch, dim, width;
+    int32_t dtype;
+    uint32_t flags;
+} AumConvUpdateArgs;
+int aum_causal_conv1d_update(const AumConvUpdateArgs* args, void* stream);
+typedef struct AumStateUpdateArgs {
+    float* state;
+    const void *x, *dt, *z, *B, *C;
+    const float *A, *D, *dt_bias;
+    void* out;
+    int32_t batch, dim, dstate;
+    int32_t dtype;
+    uint32_t flags;
+} AumStateUpdateArgs;
+int aum_selective_state_update(const AumStateUpdateArgs* args, void* stream);
+
 /* Self-tests and calibration (used by tests/ and bench.py; not part of the reference's surface). */
 int aum_abi_version(void);
 /* runs wave_scan_affine<rev> on 64 (P,S) pairs: in/out are device arrays of 128 floats (P[0..63], S[0..63]) */

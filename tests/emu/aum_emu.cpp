@@ -104,3 +104,56 @@ extern "C" int aum_xdt_tm_fwd(const AumXdtArgs* p, void*) {
     else run(aum::f16_t{});
     return AUM_OK;
 }
+
+// the per-token decode kernels on host pointers: shared argument rules (decode_args.h), the arithmetic of csrc/decode_kernels.h as plain loops
+#include "../../audio-mamba-aum_amd/csrc/decode_args.h"
+extern "C" int aum_causal_conv1d_update(const AumConvUpdateArgs* p, void*) {
+    const int rc = aumdec::conv_update_check(p);
+    if (rc != AUM_OK) return rc;
+    auto run = [&](auto tag) {
+        using T = decltype(tag);
+        const T* x = static_cast<const T*>(p->x);
+        T* out = static_cast<T*>(p->out);
+        for (int64_t i = 0; i < (int64_t)p->batch * p->dim; ++i) {
+            const int d = (int)(i % p->dim);
+            float* win = p->conv_state + i * p->width;
+            const float* w = p->weight + (int64_t)d * p->width;
+            float acc = p->bias ? p->bias[d] : 0.f;
+            for (int k = 0; k + 1 < p->width; ++k) { win[k] = win[k + 1]; acc += win[k] * w[k]; }
+            win[p->width - 1] = aum::elem_to_f32(x[i]);
+            acc += win[p->width - 1] * w[p->width - 1];
+            if (p->flags & AUM_CONV_SILU) acc = acc / (1.f + std::exp(-acc));
+            aum::f32_to_elem(acc, out[i]);
+        }
+    };
+    if (p->dtype == AUM_F32) run(float{}); else if (p->dtype == AUM_BF16) run(aum::bf16_t{}); else run(aum::f16_t{});
+    return AUM_OK;
+}
+extern "C" int aum_selective_state_update(const AumStateUpdateArgs* p, void*) {
+    const int rc = aumdec::state_update_check(p);
+    if (rc != AUM_OK) return rc;
+    auto run = [&](auto tag) {
+        using T = decltype(tag);
+        const T *x = static_cast<const T*>(p->x), *dtp = static_cast<const T*>(p->dt), *z = static_cast<const T*>(p->z);
+        const T *Bm = static_cast<const T*>(p->B), *Cm = static_cast<const T*>(p->C);
+        T* out = static_cast<T*>(p->out);
+        for (int64_t i = 0; i < (int64_t)p->batch * p->dim; ++i) {
+            const int d = (int)(i % p->dim);
+            const int64_t b = i / p->dim;
+            float dt = aum::elem_to_f32(dtp[i]) + (p->dt_bias ? p->dt_bias[d] : 0.f);
+            if (p->flags & AUM_SCAN_SOFTPLUS) dt = dt > 20.f ? dt : std::log1p(std::exp(dt));
+            const float xv = aum::elem_to_f32(x[i]);
+            float y = 0.f;
+            for (int n = 0; n < p->dstate; ++n) {
+                float& h = p->state[i * p->dstate + n];
+                h = std::exp(dt * p->A[(int64_t)d * p->dstate + n]) * h + dt * xv * aum::elem_to_f32(Bm[b * p->dstate + n]);
+                y += h * aum::elem_to_f32(Cm[b * p->dstate + n]);
+            }
+            if (p->D) y += p->D[d] * xv;
+            if (z) { const float zv = aum::elem_to_f32(z[i]); y *= zv / (1.f + std::exp(-zv)); }
+            aum::f32_to_elem(y, out[i]);
+        }
+    };
+    if (p->dtype == AUM_F32) run(float{}); else if (p->dtype == AUM_BF16) run(aum::bf16_t{}); else run(aum::f16_t{});
+    return AUM_OK;
+}

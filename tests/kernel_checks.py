@@ -508,6 +508,50 @@ def check_gemm_wgrad(lib, dev, t, n, k, splits, dtype, pad_y=0, pad_x=0):
     assert torch.equal(total, aum_hip.gemm_wgrad(y, x, splits=splits, lib=lib))
 
 
+def check_decode_kernels(lib, dev, dtype, batch=3, dim=70, dstate=16, width=4):
+    """aum_causal_conv1d_update / aum_selective_state_update (ABI 10; MS:313-358) over several consecutive tokens against the reference's
+    own fallback expressions (MS:322-327, 343-350) restated in fp64: the caches advanced in place, outputs in the activations' dtype"""
+    from mamba_ssm.ops.triton.selective_state_update import selective_state_update, selective_state_update_ref
+    g = torch.Generator().manual_seed(17)
+    r = lambda *s_: torch.randn(*s_, generator=g)
+    w, b = r(dim, width), r(dim)
+    A, D, dtb = -torch.rand(dim, dstate, generator=g) - 0.1, r(dim), r(dim) - 3.0
+    conv = r(batch, dim, width).to(dev)
+    conv_ref = conv.double().cpu()
+    st = r(batch, dim, dstate).to(dev)
+    st_ref = st.double().cpu()
+    st_ref2 = st.clone().cpu()
+    tol = 1e-5 if dtype == torch.float32 else TOL_BF16
+    for step in range(5):
+        x, dt, z = r(batch, dim).to(dtype), (0.5 * r(batch, dim)).to(dtype), r(batch, dim).to(dtype)
+        Bm, Cm = r(batch, dstate).to(dtype), r(batch, dstate).to(dtype)
+        for silu in (True, False):
+            c_in = conv.clone()
+            y = aum_hip.conv1d_update(x.to(dev), c_in, w.to(dev), b.to(dev), silu, lib=lib)
+            cr = torch.cat([conv_ref[:, :, 1:], x.double()[:, :, None]], dim=2)
+            yr = (cr * w.double()).sum(-1) + b.double()
+            yr = torch.nn.functional.silu(yr) if silu else yr
+            assert y.dtype == dtype and rel_err(N(y), yr.numpy()) < tol, ("conv_update", step, silu)
+            assert torch.equal(c_in.cpu().double(), cr.float().double()), "conv window"
+        conv, conv_ref = c_in, cr
+        out = aum_hip.state_update(st, x.to(dev), dt.to(dev), A.to(dev), Bm.to(dev), Cm.to(dev), D.to(dev), z.to(dev), dtb.to(dev), True, lib=lib)
+        dtt = torch.nn.functional.softplus(dt.double() + dtb.double())
+        st_ref = st_ref * torch.exp(dtt[:, :, None] * A.double()) + (dtt * x.double())[:, :, None] * Bm.double()[:, None, :]
+        yr = ((st_ref * Cm.double()[:, None, :]).sum(-1) + D.double() * x.double()) * torch.nn.functional.silu(z.double())
+        assert out.dtype == dtype and rel_err(N(out), yr.numpy()) < tol, ("state_update", step)
+        assert rel_err(N(st), st_ref.numpy()) < 1e-5, ("state", step)
+        # the package's own torch statement (the public *_ref name) agrees too
+        o2 = selective_state_update_ref(st_ref2, x.float(), dt.float(), A, Bm.float(), Cm.float(), D, z.float(), dtb, True)
+        assert rel_err(o2.numpy(), yr.numpy()) < 1e-4
+    # no gate, no skip, no bias, no softplus
+    x, dt = r(batch, dim).to(dtype), (0.1 * r(batch, dim)).abs().to(dtype)
+    Bm, Cm = r(batch, dstate).to(dtype), r(batch, dstate).to(dtype)
+    s0 = st.clone()
+    out = aum_hip.state_update(st, x.to(dev), dt.to(dev), A.to(dev), Bm.to(dev), Cm.to(dev), lib=lib)
+    sr = s0.double().cpu() * torch.exp(dt.double()[:, :, None] * A.double()) + (dt.double() * x.double())[:, :, None] * Bm.double()[:, None, :]
+    assert rel_err(N(out), (sr * Cm.double()[:, None, :]).sum(-1).numpy()) < tol
+
+
 def check_gemm_args(lib, dev):
     """argument rules of aum_gemm_tn (csrc/gemm_args.h): refused shapes return an error code, nothing is launched"""
     a = torch.zeros(8, 64, dtype=torch.bfloat16, device=dev)

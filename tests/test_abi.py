@@ -61,6 +61,8 @@ def test_struct_layouts_match_header(tmp_path):
         "AumXdtArgs": (aum_hip.XdtArgs, ["u", "wx", "wdt", "x_dbl", "delta", "ntok", "dim", "rank", "ncols", "ldu", "ldwx", "ldwdt", "ldx", "ldd", "dtype"]),
         "AumGemmArgs": (aum_hip.GemmArgs, ["a", "b", "c", "m", "n", "k", "lda", "ldb", "ldc", "dtype", "flags"]),
         "AumGemmWArgs": (aum_hip.GemmWArgs, ["y", "x", "part", "t", "ldy", "ldx", "n", "k", "splits", "dtype"]),
+        "AumConvUpdateArgs": (aum_hip.ConvUpdateArgs, ["x", "conv_state", "weight", "bias", "out", "batch", "dim", "width", "dtype", "flags"]),
+        "AumStateUpdateArgs": (aum_hip.StateUpdateArgs, ["state", "x", "dt", "z", "B", "C", "A", "D", "dt_bias", "out", "batch", "dim", "dstate", "dtype", "flags"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']
     for cname, (_, fields) in probes.items():

@@ -273,3 +273,9 @@ def test_gemm_wgrad_contract(emu, case):
     """the host twin of aum_gemm_wgrad (tests/emu/aum_emu.cpp: shared argument rules and split boundaries): what the host-side dispatch
     tests run against; the device kernel's own parity is test_gpu_kernels.py::test_gemm_wgrad*"""
     KC.check_gemm_wgrad(emu, "cpu", *case[:4], torch.bfloat16, *case[4:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decode_kernels_contract(emu, dtype):
+    """the host twins of the per-token kernels (tests/emu/aum_emu.cpp) against the reference's step arithmetic in fp64"""
+    KC.check_decode_kernels(emu, "cpu", dtype)

@@ -497,6 +497,13 @@ def test_gemm_wgrad_full_size(lib):
             assert torch.equal(out, aum_hip.gemm_wgrad(y, x, lib=lib))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_decode_kernels(lib, dtype):
+    """streaming inference, one token per call (MS:313-358): conv window update and single-step state update on the device"""
+    KC.check_decode_kernels(lib, "cuda", dtype)
+    KC.check_decode_kernels(lib, "cuda", dtype, batch=64, dim=1536)
+
+
 def test_gemm_tn_argument_rules(lib):
     KC.check_gemm_args(lib, "cuda")
 
