@@ -86,6 +86,14 @@ class ScanTmBwdArgs(C.Structure):
                 + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32)])
 
 
+class ScanTmSegFwdArgs(C.Structure):
+    _fields_ = [("base", ScanTmFwdArgs), ("carry", _vp), ("carry_bytes", _i64), ("segments", _i32), ("reserved", _i32)]
+
+
+class ScanTmSegBwdArgs(C.Structure):
+    _fields_ = [("base", ScanTmBwdArgs), ("segments", _i32), ("reserved", _i32)]
+
+
 class ConvArgs(C.Structure):
     _fields_ = ([(n, _vp) for n in ("x", "dy", "weight", "bias", "y", "dx", "dweight", "dbias")]
                 + [(n, _i64) for n in ("x_bs", "x_ds", "y_bs", "y_ds", "dy_bs", "dy_ds", "dx_bs", "dx_ds")]
@@ -164,7 +172,8 @@ class XdtArgs(C.Structure):
 EXPORTS = ["aum_gemm_tn", "aum_dtproj_tm_fwd", "aum_xdt_tm_fwd", "aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows",
-           "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_ckpt_rows", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_selftest_wave_sum32",
+           "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_ckpt_rows", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_scan_tm_seg_fwd", "aum_scan_tm_seg_bwd",
+           "aum_scan_tm_seg_carry_bytes", "aum_scan_tm_seg_workspace_bytes", "aum_selftest_wave_sum32",
            "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_scan_tm_bwd_matrix_sums", "aum_gemm_wgrad", "aum_causal_conv1d_update", "aum_selective_state_update"]
 
 
@@ -187,6 +196,8 @@ class Lib:
             getattr(self.c, n).argtypes = [_vp, _vp]
         self.c.aum_scan_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_scan_tm_bwd.argtypes = [_vp, _vp]
+        self.c.aum_scan_tm_seg_fwd.argtypes = [_vp, _vp]
+        self.c.aum_scan_tm_seg_bwd.argtypes = [_vp, _vp]
         self.c.aum_scan_tm_nck.argtypes = [_i32]
         self.c.aum_scan_tm_ckpt_rows.argtypes = [_i32]
         self.c.aum_conv1d_tm_fwd.argtypes = [_vp, _vp]
@@ -201,6 +212,9 @@ class Lib:
         self.c.aum_xdt_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_scan_tm_workspace_bytes.restype = _i64
         self.c.aum_scan_tm_workspace_bytes.argtypes = [_i32] * 5
+        for fn in (self.c.aum_scan_tm_seg_carry_bytes, self.c.aum_scan_tm_seg_workspace_bytes):
+            fn.restype = _i64
+            fn.argtypes = [_i32] * 6
         self.c.aum_fbank_fwd.argtypes = [_vp, _vp]
         self.c.aum_frontend_tokens_fwd.argtypes = [_vp, _vp]
         for n in ("aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight"):
@@ -510,10 +524,31 @@ def scan_tm_ckpt(batch, length, dim, dstate, bidir, device, lib=None, dtype=torc
     return torch.empty((2 if bidir else 1, batch, max(nck, 1), rows, dim), dtype=torch.float32, device=device)
 
 
+SCAN_TM_MAX_SEGMENTS = 32
+
+
+def scan_tm_segments(batch, dim, length, bidir, training=False, nsimd=1024):
+    """time segments a token-major launch of this shape is cut into (1: not cut).  One wave per (batch entry, 64 channels, direction)
+    leaves most SIMDs idle at a small batch while every wave walks the whole row; segments multiply the waves at the price of one
+    carry pass (the recurrence once more, without outputs).  Rows are cut only when they are long (>= 1024 steps) and the uncut launch is
+    under one wave per two SIMDs, into as many ranges as give every SIMD three waves per launch (each direction of a Fo-Bi pair is a
+    launch of its own), ranges no shorter than 128 steps.  Measured at B = 8, L = 4097, E = 1536 (profiles/r04_seg_time.json): 16
+    ranges are the fastest cut for the forward (three resident waves per SIMD: one round) AND for the backward (two resident: 11 or
+    12 ranges leave a tail round, 16 is 1.5 rounds of shorter waves) -- 0.68 / 1.39 ms against 1.29 / 5.03 ms uncut."""
+    per_dir = batch * (dim // 64)
+    waves = per_dir * (2 if bidir else 1)
+    if per_dir <= 0 or waves * 2 > nsimd or length < 1024:
+        return 1
+    want = -(-nsimd * 3 // per_dir)
+    seg = min(want, length // 128, SCAN_TM_MAX_SEGMENTS)
+    return seg if seg >= 2 else 1
+
+
 def scan_tm_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, reverse=False, A_b=None,
-                want_out_pre=False, ckpt=None, out=None, lib=None):
+                want_out_pre=False, ckpt=None, out=None, lib=None, segments=1):
     """Selective scan forward on token-major tensors: u, delta, z (batch, len, dim) with channels contiguous (row strides free: z
     may be a slice of an xz tensor); B, C (batch, len, dstate) in u's dtype.  A_b != None: both directions (Fo-Bi).
+    segments > 1: the rows are cut into that many time ranges that run as waves of their own (aum_scan_tm_seg_fwd).
     Returns (out, out_pre|None), both (batch, len, dim) contiguous."""
     lib = lib or get()
     batch, length, dim = u.shape
@@ -549,13 +584,25 @@ def scan_tm_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softpl
         a.ckpt = _ptr(ckpt)
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
     a.flags = (SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0)
+    if segments > 1:
+        sa = ScanTmSegFwdArgs()
+        sa.base = a
+        sa.segments = int(segments)
+        sa.carry_bytes = int(lib.c.aum_scan_tm_seg_carry_bytes(batch, dim, length, dstate, int(A_b is not None), int(segments)))
+        if sa.carry_bytes <= 0:
+            raise RuntimeError(f"scan_tm_fwd: segments={segments} not supported for this shape")
+        carry = torch.empty((sa.carry_bytes // 4,), dtype=torch.float32, device=u.device)
+        sa.carry = _ptr(carry)
+        _launch(lib.c.aum_scan_tm_seg_fwd, sa, u, lib, "scan_tm_seg_fwd_bidir" if A_b is not None else "scan_tm_seg_fwd",
+                (batch, dim, length, dstate, u.element_size(), want_out_pre, int(segments)))
+        return out, out_pre
     _launch(lib.c.aum_scan_tm_fwd, a, u, lib, "scan_tm_fwd_bidir" if A_b is not None else "scan_tm_fwd",
             (batch, dim, length, dstate, u.element_size(), want_out_pre))
     return out, out_pre
 
 
 def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_softplus=False, reverse=False, A_b=None, dz_out=None,
-                lib=None):
+                lib=None, segments=1):
     """Backward of scan_tm_fwd (same tensor conventions; ckpt: the tensor scan_tm_fwd filled).  Returns dict(du, ddelta, dz (batch, len,
     dim) in u's dtype, dBC (batch, len, 2 * dstate) fp32 = dB | dC, dA, dA_b (dim, dstate), dD, ddelta_bias (dim) fp32)."""
     lib = lib or get()
@@ -593,7 +640,12 @@ def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_
     dA_b = torch.empty((dim, dstate), **f32) if bidir else None
     dD = torch.empty((dim,), **f32) if D is not None else None
     dbias = torch.empty((dim,), **f32) if delta_bias is not None else None
-    ws_bytes = int(lib.c.aum_scan_tm_workspace_bytes(batch, dim, length, dstate, int(bidir)))
+    if segments > 1:
+        ws_bytes = int(lib.c.aum_scan_tm_seg_workspace_bytes(batch, dim, length, dstate, int(bidir), int(segments)))
+        if ws_bytes <= 0:
+            raise RuntimeError(f"scan_tm_bwd: segments={segments} not supported for this shape")
+    else:
+        ws_bytes = int(lib.c.aum_scan_tm_workspace_bytes(batch, dim, length, dstate, int(bidir)))
     ws = torch.empty((max(ws_bytes, 4) // 4,), **f32)
     a = ScanTmBwdArgs()
     a.u, a.delta, a.z, a.B, a.C, a.dout, a.out_pre = map(_ptr, (u, delta, z, B, C, dout, out_pre))
@@ -614,7 +666,14 @@ def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_
         a.dz_bs, a.dz_ts = _tm3(dz, "dz", dim)
     a.batch, a.dim, a.len, a.dstate, a.dtype = batch, dim, length, dstate, _DT[u.dtype]
     a.flags = (SCAN_SOFTPLUS if delta_softplus else 0) | (SCAN_REVERSE if reverse else 0)
-    _launch(lib.c.aum_scan_tm_bwd, a, u, lib, "scan_tm_bwd_bidir" if bidir else "scan_tm_bwd", (batch, dim, length, dstate, u.element_size(), True))
+    if segments > 1:
+        sa = ScanTmSegBwdArgs()
+        sa.base = a
+        sa.segments = int(segments)
+        _launch(lib.c.aum_scan_tm_seg_bwd, sa, u, lib, "scan_tm_seg_bwd_bidir" if bidir else "scan_tm_seg_bwd",
+                (batch, dim, length, dstate, u.element_size(), True, int(segments)))
+    else:
+        _launch(lib.c.aum_scan_tm_bwd, a, u, lib, "scan_tm_bwd_bidir" if bidir else "scan_tm_bwd", (batch, dim, length, dstate, u.element_size(), True))
     return dict(du=du, ddelta=ddelta, dz=dz, dBC=dBC, dA=dA, dA_b=dA_b, dD=dD, ddelta_bias=dbias, _ws=ws)
 
 

@@ -72,6 +72,10 @@ struct ScanTRaw { vi u, d, z, part; };       // one step's inputs as read from t
 // PHASE 0: the whole direction alone -- out = gate * (y + D u), out_pre = y + D u.
 // PHASE 1: first half of a direction pair -- out <- partial y (no skip, no gate).
 // PHASE 2: second half -- tot = y + partial(out) + dmul D u;  out_pre <- tot;  out <- gate * tot.
+// PHASE 3 / 4 (time segments, scant_seg_*): carry passes that write nothing per step and keep, next to the state, the product of
+//   the decays a over the range in pacc (out only: exp2(A2 * the sum of the range's deltas)).  3: the state recurrence itself, x = a x + (delta u) B.  4: the ADJOINT recurrence of the
+//   backward, h = a (h + dy C) with dy = dout * gate(z), walked in the order the backward walks -- the caller passes dout as `u`, C
+//   as `B` and the direction's time mapping reversed.
 // Blocks of SCANT_CK steps aligned to multiples of SCANT_CK in `it`.  At the top of a block the wave requests the NEXT block's
 // inputs (u, delta, z, partial, B, C: six 16-byte-per-lane loads) and holds them in registers while it computes the current block
 // out of LDS; at the end of the block it flushes the output tiles (two 16-byte-per-lane stores) and parks the new inputs in the
@@ -83,11 +87,12 @@ struct ScanTRaw { vi u, d, z, part; };       // one step's inputs as read from t
 // their rows per lane and mask their stores.
 template <class T, int N, int PHASE, bool SP, bool HAS_Z, bool HAS_PRE>
 AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, int t0, int tstep, int it0, int it1, const float* Aptr,
-                           float dmul, vf2 (&x)[N / 2], float* lds, unsigned long long* scant_trace_acc = nullptr) {
+                           float dmul, vf2 (&x)[N / 2], float* lds, unsigned long long* scant_trace_acc = nullptr, vf2* pacc = nullptr) {
     using TL = ScanTTile<T>;
     constexpr int ES = TL::ES, ROWB = TL::ROWB, NLD = TL::NLD;
     static_assert(N == 16 && SCANT_CK == 8, "lane = (row, chunk) staging below assumes 8 steps x 8 chunks / state pairs");
-    constexpr bool LD_Z = HAS_Z && PHASE != 1, LD_PART = PHASE == 2, ST_PRE = HAS_PRE && PHASE != 1;
+    constexpr bool CARRY = PHASE >= 3;
+    constexpr bool LD_Z = HAS_Z && PHASE != 1 && PHASE != 3, LD_PART = PHASE == 2, ST_PRE = HAS_PRE && PHASE != 1 && !CARRY;
     const int L = p.len;
     const vi lane = lane_id();
     const vi ec = lane + e0;                     // dim % 64 == 0: every lane is a channel
@@ -179,7 +184,7 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
     };
     // write the output tiles of block `blk` back (rows outside the phase are not written)
     auto flush = [&](int blk) {
-        if (AUM_SCANT_ABL & 4) return;
+        if ((AUM_SCANT_ABL & 4) || CARRY) return;
         const int base = blk * SCANT_CK;
         const bool inside = base >= it0 && base + SCANT_CK <= it1;
         wave_lds_fence();
@@ -240,16 +245,19 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
     // trips, and the next delta (the softplus chain) after this step's state updates.
     // The arithmetic is written stage by stage over the eight state pairs -- all exponents, then all sixteen v_exp_f32, then the
     // updates -- because the compiler keeps source order: pair by pair, every v_pk_fma waited for the v_exp right in front of it.
+    vf dsum = splat(0.f);       // carry passes: the sum of this range's deltas
     auto step = [&](int s, const float* bc, bool prefetch, const ScanTRaw& r, vf dl, vf2 (&Bp)[N / 2], ScanTRaw& rn, vf& dln, vf2 (&Bn)[N / 2]) {
         const float* bcrow = bc + s * SCANT_BC_ROW;
         vf2 Cp[N / 2];
-        AUM_UNROLL
-        for (int k = 0; k < N / 4; ++k) {
-            vf q[4];
-            if (AUM_SCANT_ABL & 16) q[0] = q[1] = q[2] = q[3] = splat(1.f);
-            else lds_read4_u(bcrow, N + 4 * k, q);
-            Cp[2 * k] = mk2(q[0], q[1]);
-            Cp[2 * k + 1] = mk2(q[2], q[3]);
+        if (!CARRY) {
+            AUM_UNROLL
+            for (int k = 0; k < N / 4; ++k) {
+                vf q[4];
+                if (AUM_SCANT_ABL & 16) q[0] = q[1] = q[2] = q[3] = splat(1.f);
+                else lds_read4_u(bcrow, N + 4 * k, q);
+                Cp[2 * k] = mk2(q[0], q[1]);
+                Cp[2 * k + 1] = mk2(q[2], q[3]);
+            }
         }
         if (prefetch) {
             read_B(bcrow + SCANT_BC_ROW, Bn);
@@ -262,6 +270,26 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
         vf2 a[N / 2];
         AUM_UNROLL
         for (int j = 0; j < N / 2; ++j) a[j] = dl2 * A2[j];
+        if (CARRY) {
+            AUM_UNROLL
+            for (int j = 0; j < N / 2; ++j) a[j] = vexp2_2(a[j]);
+            if (PHASE == 3) {
+                AUM_UNROLL
+                for (int j = 0; j < N / 2; ++j) x[j] = vfma2(a[j], x[j], du2 * Bp[j]);
+            } else {        // uu = dout of the step, Bp = its C row
+                vf dy = uu;
+                if (LD_Z) {
+                    const vf zz = raw_to_f32<T>(r.z);
+                    dy = uu * (zz * vsigmoid(zz));
+                }
+                const vf2 dy2 = spl2(dy);
+                AUM_UNROLL
+                for (int j = 0; j < N / 2; ++j) x[j] = a[j] * vfma2(dy2, Bp[j], x[j]);
+            }
+            dsum = dsum + dl;          // the product of the decays is exp2(A2 * sum of delta): formed once, after the last block
+            if (prefetch) dln = delta_of(rn);
+            return;
+        }
         vf zz = splat(0.f), ez = splat(0.f);
         if (LD_Z) {
             zz = raw_to_f32<T>(r.z);
@@ -367,7 +395,7 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
                     for (int j = 0; j < N / 2; ++j) Bq[j] = Bn[j];
                 }
             }
-            if (want_ck && blk < nck) ckpt_store(blk);
+            if (want_ck && !CARRY && blk < nck) ckpt_store(blk);
         } else {        // ragged: steps outside the phase are skipped
             for (int s = 0; s < SCANT_CK; ++s) {
                 if (base + s < it0 || base + s >= it1) continue;
@@ -379,7 +407,7 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
                 step(s, bc, false, r, delta_of(r), Bq, rn, dln, Bn);
             }
             // the block's exit state is complete only in the phase that ran its last step
-            if (want_ck && blk < nck && base + SCANT_CK - 1 >= it0 && base + SCANT_CK - 1 < it1) ckpt_store(blk);
+            if (want_ck && !CARRY && blk < nck && base + SCANT_CK - 1 >= it0 && base + SCANT_CK - 1 < it1) ckpt_store(blk);
         }
         AUM_TM_STAMP(2);
         flush(blk);
@@ -388,6 +416,11 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
         AUM_TM_STAMP(4);
     }
 #undef AUM_TM_STAMP
+    if (CARRY) {
+        const vf2 ds2 = spl2(dsum);
+        AUM_UNROLL
+        for (int j = 0; j < N / 2; ++j) pacc[j] = vexp2_2(ds2 * A2[j]);
+    }
 }
 
 // iterations the forward-time wave (dir 0) and the reverse-time wave (dir 1) of a pair run before they meet: together they cover
@@ -441,6 +474,87 @@ AUM_DEV void scant_fwd(const AumScanTmFwdArgs& p, int wg, float* lds, unsigned l
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Time segments (round 4): long rows at a small batch.  One wave per (batch entry, channel group, direction) is 8 x 24 x 2 = 384
+// waves at the long-form shape (B = 8, L = 4097) -- 0.4 per SIMD, each a 4097-step latency chain.  The recurrence is affine in the
+// state, so a direction's iterations are cut into `nseg` segments of seg_len steps (a multiple of the checkpoint block) that run as
+// separate waves:
+//   carry pass   every segment from a zero entry state: X_s = its exit state, P_s = the product of its decays (PHASE 3);
+//   main pass    segment s starts from  x = P_{s-1} ( ... (P_0 0 + X_0) ... ) + X_{s-1}  (s multiply-adds per state in the wave's
+//                prologue) and runs the ordinary phases.  Fo-Bi: direction 0 writes its partial y for the whole row (PHASE 1) in
+//                one launch, direction 1 finishes the row (PHASE 2) in the next -- the hand-over a barrier orders inside the
+//                unsegmented kernel is ordered by the stream here.
+// The backward is the same construction on the adjoint h (affine, the same decays): PHASE 4 is its carry pass.
+// ------------------------------------------------------------------------------------------------
+struct ScanTSeg {
+    float* carry;          // [ndir][batch][nseg][2][N][dim] fp32: P rows, then X rows of a segment
+    int nseg, seg_len;     // seg_len % SCANT_CK == 0
+    int dir0, ndl;         // this launch runs directions dir0 .. dir0 + ndl - 1
+};
+AUM_HOSTDEV constexpr int scant_seg_len(int len, int nseg) { return ((len + nseg - 1) / nseg + SCANT_CK - 1) / SCANT_CK * SCANT_CK; }
+AUM_HOSTDEV constexpr int64_t scant_seg_carry_floats(int batch, int dim, int nseg, bool bidir) {
+    return (int64_t)(bidir ? 2 : 1) * batch * nseg * 2 * SCANT_N * dim;
+}
+
+// workgroup = four independent waves; item = ((unit * nseg) + segment) * ndl + local direction
+template <class T, int PHASE, bool SP, bool HAS_Z, bool HAS_PRE>
+AUM_DEV void scant_seg_fwd(const AumScanTmFwdArgs& p, const ScanTSeg& sg, int wg, float* lds) {
+    constexpr int N = SCANT_N;
+    constexpr int NW = SCANT_NW;
+    const int gpb = p.dim / WAVE;
+    const int L = p.len;
+    const int items = p.batch * gpb * sg.nseg * sg.ndl;
+    const bool bidir = p.A_b != nullptr;
+    vf2 x[AUM_PER_WAVE(NW)][N / 2], P[AUM_PER_WAVE(NW)][N / 2];
+    AUM_FOR_EACH_WAVE(w, NW) {
+        const int item = wg * NW + w;
+        // the carries of a direction's last segment (state) / first segment (adjoint) are never used
+        const int s = item < items ? (item / sg.ndl) % sg.nseg : 0;
+        const bool idle = item >= items || (PHASE == 3 && s == sg.nseg - 1) || (PHASE == 4 && s == 0);
+        if (!idle) {
+            const int d = sg.dir0 + item % sg.ndl, unit = item / (sg.ndl * sg.nseg);
+            const int b = unit / gpb, e0 = (unit % gpb) * WAVE;
+            const bool rev = bidir ? d == 1 : (p.flags & AUM_SCAN_REVERSE) != 0;
+            const float* Aptr = d ? p.A_b : p.A;
+            const int it0 = s * sg.seg_len < L ? s * sg.seg_len : L;
+            const int it1 = it0 + sg.seg_len < L ? it0 + sg.seg_len : L;
+            const vi ec = lane_id() + e0;
+            float* cb = sg.carry + ((int64_t)d * p.batch + b) * sg.nseg * (2 * N) * p.dim;
+            float* lw = lds + w * scant_lds_wave_floats<T>();
+            AUM_UNROLL
+            for (int j = 0; j < N / 2; ++j) x[AUM_W(w)][j] = spl2(splat(0.f));
+            if (PHASE >= 3) {
+                AUM_UNROLL
+                for (int j = 0; j < N / 2; ++j) P[AUM_W(w)][j] = spl2(splat(1.f));
+                if (PHASE == 3)
+                    scant_fwd_run<T, N, 3, SP, HAS_Z, HAS_PRE>(p, b, e0, d, rev ? L - 1 : 0, rev ? -1 : 1, it0, it1, Aptr, 1.f, x[AUM_W(w)], lw, nullptr,
+                                                               P[AUM_W(w)]);
+                else        // the adjoint walks the direction's iterations downward: iteration L - 1 - it of the reversed mapping
+                    scant_fwd_run<T, N, 4, SP, HAS_Z, HAS_PRE>(p, b, e0, d, rev ? 0 : L - 1, rev ? 1 : -1, L - it1, L - it0, Aptr, 1.f, x[AUM_W(w)], lw,
+                                                               nullptr, P[AUM_W(w)]);
+                float* cs = cb + (int64_t)s * (2 * N) * p.dim;
+                AUM_UNROLL
+                for (int n = 0; n < N; ++n) {
+                    gstore(cs + (int64_t)n * p.dim, ec, (n & 1) ? hi2(P[AUM_W(w)][n >> 1]) : lo2(P[AUM_W(w)][n >> 1]), ec >= 0);
+                    gstore(cs + (int64_t)(N + n) * p.dim, ec, (n & 1) ? hi2(x[AUM_W(w)][n >> 1]) : lo2(x[AUM_W(w)][n >> 1]), ec >= 0);
+                }
+            } else {
+                for (int sp = 0; sp < s; ++sp) {
+                    const float* cs = cb + (int64_t)sp * (2 * N) * p.dim;
+                    AUM_UNROLL
+                    for (int j = 0; j < N / 2; ++j) {
+                        const vf2 pj = mk2(gload_u(cs + (int64_t)(2 * j) * p.dim, ec), gload_u(cs + (int64_t)(2 * j + 1) * p.dim, ec));
+                        const vf2 xj = mk2(gload_u(cs + (int64_t)(N + 2 * j) * p.dim, ec), gload_u(cs + (int64_t)(N + 2 * j + 1) * p.dim, ec));
+                        x[AUM_W(w)][j] = vfma2(pj, x[AUM_W(w)][j], xj);
+                    }
+                }
+                scant_fwd_run<T, N, PHASE, SP, HAS_Z, HAS_PRE>(p, b, e0, d, rev ? L - 1 : 0, rev ? -1 : 1, it0, it1, Aptr, bidir ? 2.f : 1.f,
+                                                               x[AUM_W(w)], lw);
+            }
+        }
+    }
+}
 
 // ================================================================================================
 // Backward.  The same division of the work: lane = channel, a wave owns one direction of a channel group and walks its blocks of
@@ -1030,6 +1144,55 @@ AUM_DEV void scant_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int wg,
             }
         }
         if (stage < 2) AUM_WG_BARRIER();
+    }
+}
+
+// Time segments of the backward (see scant_seg_fwd): segment s of a direction starts from the adjoint
+//   h = P_{nseg-1} ( ... ) ... : h <- P_s' h + H_s' for s' = nseg - 1 down to s + 1 (PHASE 4 carries: H_s' = the adjoint at the segment's
+// first step from zero behind its last), and leaves its partial sums of dA / dD / ddelta_bias in rows of their own: the reduce
+// kernel sums batch * nseg rows per direction.  PHASE 0: one direction alone; 1 / 2: direction 0 / direction 1 of a Fo-Bi pair, each
+// over the whole row, in two launches.
+template <class T, int PHASE, bool SP, bool HAS_Z>
+AUM_DEV void scant_seg_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, const ScanTSeg& sg, int wg, float* lds) {
+    constexpr int N = SCANT_N;
+    constexpr int NW = SCANT_NW;
+    const int gpb = p.dim / WAVE;
+    const int L = p.len;
+    const int items = p.batch * gpb * sg.nseg;
+    const bool bidir = p.A_b != nullptr;
+    vf16 hh[AUM_PER_WAVE(NW)], dA[AUM_PER_WAVE(NW)];
+    vf dD[AUM_PER_WAVE(NW)], dbias[AUM_PER_WAVE(NW)];
+    AUM_FOR_EACH_WAVE(w, NW) {
+        const int item = wg * NW + w;
+        if (item < items) {
+            const int d = sg.dir0, s = item % sg.nseg, unit = item / sg.nseg;
+            const int b = unit / gpb, e0 = (unit % gpb) * WAVE, prt = bidir ? (unit % gpb) * 2 + d : unit % gpb;
+            const bool rev = bidir ? d == 1 : (p.flags & AUM_SCAN_REVERSE) != 0;
+            const int it0 = s * sg.seg_len < L ? s * sg.seg_len : L;
+            const int it1 = it0 + sg.seg_len < L ? it0 + sg.seg_len : L;
+            const vi ec = lane_id() + e0;
+            AUM_UNROLL
+            for (int n = 0; n < N; ++n) {
+                vf16_set(hh[AUM_W(w)], n, splat(0.f));
+                vf16_set(dA[AUM_W(w)], n, splat(0.f));
+            }
+            dD[AUM_W(w)] = dbias[AUM_W(w)] = splat(0.f);
+            const float* cb = sg.carry + ((int64_t)d * p.batch + b) * sg.nseg * (2 * N) * p.dim;
+            for (int sp = sg.nseg - 1; sp > s; --sp) {
+                const float* cs = cb + (int64_t)sp * (2 * N) * p.dim;
+                AUM_UNROLL
+                for (int n = 0; n < N; ++n)
+                    vf16_set(hh[AUM_W(w)], n, vfma(gload_u(cs + (int64_t)n * p.dim, ec), vf16_get(hh[AUM_W(w)], n), gload_u(cs + (int64_t)(N + n) * p.dim, ec)));
+            }
+            scant_bwd_run<T, N, PHASE, SP, HAS_Z>(p, wo, b, e0, d, prt, rev ? L - 1 : 0, rev ? -1 : 1, it0, it1, d ? p.A_b : p.A, bidir ? 2.f : 1.f,
+                                                  hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)], dbias[AUM_W(w)], lds + w * scant_bwd_lds_wave_floats<T>());
+            const int64_t q = ((int64_t)d * p.batch + b) * sg.nseg + s;
+            float* pa = wo.dA + q * N * p.dim;
+            AUM_UNROLL
+            for (int n = 0; n < N; ++n) gstore(pa + (int64_t)n * p.dim, ec, vf16_get(dA[AUM_W(w)], n), ec >= 0);
+            gstore(wo.dD + q * p.dim, ec, dD[AUM_W(w)] * (bidir ? 2.f : 1.f), ec >= 0);
+            gstore(wo.dbias + q * p.dim, ec, dbias[AUM_W(w)], ec >= 0);
+        }
     }
 }
 

@@ -100,7 +100,7 @@ class Mamba(nn.Module):
         batch, seqlen, _ = hidden_states.shape
         tm = (ssi.TOKEN_MAJOR and self.use_fast_path and inference_params is None
               and not (ssi._REF_DZ_DROP and self.bimamba_type == "v1")      # that option lives in the channel-major block
-              and ssi.token_major_preferred(batch, self.d_inner, self.bimamba_type != "none")
+              and ssi.token_major_preferred(batch, self.d_inner, self.bimamba_type != "none", seqlen=seqlen)
               and ssi.token_major_ok(self.d_inner, self.d_state, self.d_conv, self.dt_rank,
                                      torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else hidden_states.dtype))
         if tm:

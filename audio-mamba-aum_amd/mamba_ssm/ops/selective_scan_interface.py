@@ -457,10 +457,25 @@ def token_major_ok(d_inner, d_state, d_conv, dt_rank, dtype=None):
 _TM_MIN_WAVES = int(_dbg_env("AUM_TM_MIN_WAVES", "1536"))
 
 
-def token_major_preferred(batch, d_inner, bidirectional, training=None):
+# Long rows at a small batch (the long-form clips: B = 8, L = 4097) are cut into time segments that run as waves of their own
+# (aum_hip.scan_tm_segments, aum_scan_tm_seg_*): AUM_TM_SEGMENTS=0 keeps them on the channel-major kernels, a number > 1 forces it.
+_TM_SEGMENTS = int(_dbg_env("AUM_TM_SEGMENTS", "-1"))
+
+
+def tm_segments(batch, d_inner, seqlen, bidirectional, training):
+    if _TM_SEGMENTS == 0 or seqlen is None:
+        return 1
+    if _TM_SEGMENTS > 1:
+        return min(_TM_SEGMENTS, aum_hip.SCAN_TM_MAX_SEGMENTS)
+    return aum_hip.scan_tm_segments(batch, d_inner, seqlen, bidirectional, training)
+
+
+def token_major_preferred(batch, d_inner, bidirectional, training=None, seqlen=None):
     training = torch.is_grad_enabled() if training is None else training
     need = -(-_TM_MIN_WAVES * 4 // 3) if training else _TM_MIN_WAVES
-    return batch * (d_inner // 64) * (2 if bidirectional else 1) >= need
+    if batch * (d_inner // 64) * (2 if bidirectional else 1) >= need:
+        return True
+    return tm_segments(batch, d_inner, seqlen, bidirectional, training) > 1
 
 
 def _is_tm(xz):
@@ -506,8 +521,12 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
     Bm, Cm = x3[:, :, R:R + N], x3[:, :, R + N:]                                            # SSI:479  views, no copies
     need_bwd = any(ctx.needs_input_grad)
     ckpt = aum_hip.scan_tm_ckpt(Bsz, L, E, N, A_b is not None, xz.device, dtype=conv_out.dtype) if need_bwd else None
+    waves = Bsz * (E // 64) * (2 if A_b is not None else 1)
+    cut = waves < (-(-_TM_MIN_WAVES * 4 // 3) if need_bwd else _TM_MIN_WAVES)
     out_z, out_pre = aum_hip.scan_tm_fwd(conv_out, delta.view(Bsz, L, E), A, Bm, Cm, D, z, delta_bias, delta_softplus,
-                                         reverse if A_b is None else False, A_b=A_b, want_out_pre=need_bwd, ckpt=ckpt)
+                                         reverse if A_b is None else False, A_b=A_b, want_out_pre=need_bwd, ckpt=ckpt,
+                                         segments=tm_segments(Bsz, E, L, A_b is not None, False) if cut else 1)
+    ctx.tm_cut = cut
     ctx.tm = True
     ctx.delta_softplus, ctx.reverse = delta_softplus, reverse
     ctx.has_out_proj = out_proj_weight is not None
@@ -544,7 +563,8 @@ def _inner_backward_tm(ctx, dout):
         dout_z = (dout_z if dout_z.stride(2) == 1 else dout_z.contiguous()).to(xz.dtype)
     x3 = x_dbl.view(Bsz, L, R + 2 * N)
     g = aum_hip.scan_tm_bwd(conv_out, delta.view(Bsz, L, E), A, x3[:, :, R:R + N], x3[:, :, R + N:], D, z, delta_bias, dout_z, out_pre,
-                            ckpt, ctx.delta_softplus, ctx.reverse if A_b is None else False, A_b=A_b, dz_out=dz)   # SSI:541-561
+                            ckpt, ctx.delta_softplus, ctx.reverse if A_b is None else False, A_b=A_b, dz_out=dz,
+                            segments=tm_segments(Bsz, E, L, A_b is not None, True) if ctx.tm_cut else 1)   # SSI:541-561
     du2, ddelta2 = g["du"].view(Bsz * L, E), g["ddelta"].view(Bsz * L, E)
     dx_dbl = torch.empty_like(x_dbl)
     dx_dbl[:, R:].copy_(g["dBC"].view(Bsz * L, 2 * N))                                       # SSI:570-574

@@ -354,6 +354,36 @@ int aum_scan_tm_bwd(const AumScanTmBwdArgs* args, void* stream);
 int64_t aum_scan_tm_workspace_bytes(int32_t batch, int32_t dim, int32_t len, int32_t dstate, int32_t bidirectional);
 
 /*
+ * The same two operators on rows cut into TIME SEGMENTS (ABI 10): long rows at a small batch -- the reference's long-form setting
+ * (B = 8, L = 4097: SURVEY section 8 config 5) is 384 (batch entry, channel group, direction) waves on 1024 SIMDs, each a 4097-step
+ * serial chain.  The recurrence x_t = a_t x_{t-1} + b_t is affine in the state, so every direction is cut into `segments` ranges of
+ * steps that run as waves of their own: a carry pass leaves each range's exit state from a zero entry and the product of its decays,
+ * every range then starts from the composition of the carries before it (selective_scan_fn's results: SSI:86-152 restated on
+ * ranges; nothing is approximated -- the sums are re-associated in fp32).  The backward cuts the adjoint recurrence the same way.
+ *   segments: 2 .. AUM_SCAN_TM_MAX_SEGMENTS; ranges are ceil(len / segments) steps rounded up to a multiple of AUM_SCAN_TM_CK.
+ *   carry: aum_scan_tm_seg_carry_bytes(...) bytes of scratch (forward); the backward keeps its carries in its workspace, which is
+ *   aum_scan_tm_seg_workspace_bytes(...) bytes.  ckpt has the unsegmented layout: the two forms of the forward may be mixed with the
+ *   two forms of the backward.  Everything else as aum_scan_tm_fwd / aum_scan_tm_bwd (base).
+ */
+#define AUM_SCAN_TM_MAX_SEGMENTS 32
+typedef struct AumScanTmSegFwdArgs {
+    AumScanTmFwdArgs base;
+    float* carry;
+    int64_t carry_bytes;
+    int32_t segments;
+    int32_t reserved;
+} AumScanTmSegFwdArgs;
+typedef struct AumScanTmSegBwdArgs {
+    AumScanTmBwdArgs base;
+    int32_t segments;
+    int32_t reserved;
+} AumScanTmSegBwdArgs;
+int aum_scan_tm_seg_fwd(const AumScanTmSegFwdArgs* args, void* stream);
+int aum_scan_tm_seg_bwd(const AumScanTmSegBwdArgs* args, void* stream);
+int64_t aum_scan_tm_seg_carry_bytes(int32_t batch, int32_t dim, int32_t len, int32_t dstate, int32_t bidirectional, int32_t segments);
+int64_t aum_scan_tm_seg_workspace_bytes(int32_t batch, int32_t dim, int32_t len, int32_t dstate, int32_t bidirectional, int32_t segments);
+
+/*
  * Depthwise causal conv1d (+ SiLU) on TOKEN-MAJOR activations (ABI 8): the same operator as aum_causal_conv1d_fwd / _bwd
  * (MS:272 causal_conv1d_fn; SSI:463 forward and SSI:594-596 backward call sites) for tensors laid out (batch, len, dim) with the
  * channel contiguous -- the layout of the in_proj output rows [x | z] and of the time-serial scan's operands, so x / dx may be the

@@ -285,10 +285,11 @@ def check_scan_accumulate(lib, dev, case, dtype=torch.float32, tol=None):
 
 
 
-def check_scan_tm(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, tol=None, xz_layout=False, backward=True):
+def check_scan_tm(lib, dev, case, dtype=torch.float32, reverse=False, bidir=False, tol=None, xz_layout=False, backward=True, segments=1):
     """aum_scan_tm_fwd / _bwd (time-serial scan on token-major activations) against the fp64 oracle on the same seeded inputs as the
     channel-major kernels.  xz_layout: u and z are the two
-    halves of one (batch, len, 2 dim) tensor (row stride 2 dim), as in_proj leaves them."""
+    halves of one (batch, len, 2 dim) tensor (row stride 2 dim), as in_proj leaves them.  segments > 1: the time-segmented launches
+    (aum_scan_tm_seg_fwd / _bwd), held to the same oracle and the same tolerances."""
     name, batch, dim, length, dstate, has_z, has_D, has_bias, softplus = case
     d = cases.scan_inputs(*case)
     tol = tol or (TOL_F32 if dtype == torch.float32 else TOL_BF16)
@@ -308,7 +309,7 @@ def check_scan_tm(lib, dev, case, dtype=torch.float32, reverse=False, bidir=Fals
     if ck is not None:
         ck.fill_(float("nan"))
     out, out_pre = aum_hip.scan_tm_fwd(u, delta, A, Bm, Cm, D, z, bias, softplus, reverse, T(A_b, dev), want_out_pre=True, ckpt=ck,
-                                       lib=lib)
+                                       lib=lib, segments=segments)
     ref = O.scan_fwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], softplus, reverse, "f64")
     ref_out, ref_pre = ref["out"], ref["y_pre"]
     if bidir:
@@ -316,11 +317,12 @@ def check_scan_tm(lib, dev, case, dtype=torch.float32, reverse=False, bidir=Fals
         ref_out, ref_pre = ref_out + rb["out"], ref_pre + rb["y_pre"]
     cm = lambda t: N(t).transpose(0, 2, 1)
     pairs = {"out": (cm(out), ref_out), "out_pre": (cm(out_pre), ref_pre)}
-    out2, none = aum_hip.scan_tm_fwd(u, delta, A, Bm, Cm, D, z, bias, softplus, reverse, T(A_b, dev), lib=lib)    # inference form
+    out2, none = aum_hip.scan_tm_fwd(u, delta, A, Bm, Cm, D, z, bias, softplus, reverse, T(A_b, dev), lib=lib, segments=segments)    # inference form
     assert none is None
     pairs["out_nopre"] = (cm(out2), ref_out)
     if backward:
-        g = aum_hip.scan_tm_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, out_pre if has_z else None, ck, softplus, reverse, T(A_b, dev), lib=lib)
+        g = aum_hip.scan_tm_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, out_pre if has_z else None, ck, softplus, reverse, T(A_b, dev), lib=lib,
+                                segments=segments)
         gr = O.scan_bwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus, reverse, "f64")
         if bidir:
             gb = O.scan_bwd(q["u"], q["delta"], A_b, q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus, True, "f64")
@@ -381,7 +383,7 @@ def _tm_rows_vs_oracle(O, b, es, u, dl, z, Bm, Cm, A, A_b, D, bias, dout, softpl
     return out, pre, gr
 
 
-def check_scan_tm_grid(lib, dev, Bsz, L, E, rows, entries, chans, split):
+def check_scan_tm_grid(lib, dev, Bsz, L, E, rows, entries, chans, split, segments=(1, 1)):
     """The token-major Fo-Bi scan pair (k_scant_fwd / k_scant_bwd) at a whole launch of (Bsz, L, E), N = 16, bf16, the block's row layouts (z = second half of [x | z] rows, B / C = column blocks of 80-column x_dbl rows), batch-
     distinct random data -- against the ORACLE, not against themselves (the pattern of test_scan_headline_grid_b64):
     (i) sampled (batch entry, channel) rows of out, out_pre, du, ddelta, dz vs the fp64 oracle on exactly those rows, both
@@ -404,8 +406,9 @@ def check_scan_tm_grid(lib, dev, Bsz, L, E, rows, entries, chans, split):
     dout = bf(torch.randn(Bsz, L, E, device=dev))
     ck = aum_hip.scan_tm_ckpt(Bsz, L, E, N, True, dev, dtype=torch.bfloat16)
     ck.fill_(float("nan"))
-    out, pre = aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, ckpt=ck, lib=lib)
-    g = aum_hip.scan_tm_bwd(u, dl, A, Bm, Cm, D, z, bias, dout, pre, ck, True, A_b=A_b, lib=lib)
+    sf, sb = segments           # time segments of the forward / the backward launches (1: the uncut kernels)
+    out, pre = aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, ckpt=ck, lib=lib, segments=sf)
+    g = aum_hip.scan_tm_bwd(u, dl, A, Bm, Cm, D, z, bias, dout, pre, ck, True, A_b=A_b, lib=lib, segments=sb)
     f = lambda t: t.float().cpu().numpy()
     worst = {}
 
@@ -450,9 +453,10 @@ def check_scan_tm_grid(lib, dev, Bsz, L, E, rows, entries, chans, split):
     for b0 in range(0, Bsz, split):
         s8 = lambda t: t[b0:b0 + split]
         ck8 = aum_hip.scan_tm_ckpt(split, L, E, N, True, dev, dtype=torch.bfloat16)
-        o8, p8 = aum_hip.scan_tm_fwd(s8(u), s8(dl), A, s8(Bm), s8(Cm), D, s8(z), bias, True, A_b=A_b, want_out_pre=True, ckpt=ck8, lib=lib)
+        o8, p8 = aum_hip.scan_tm_fwd(s8(u), s8(dl), A, s8(Bm), s8(Cm), D, s8(z), bias, True, A_b=A_b, want_out_pre=True, ckpt=ck8, lib=lib,
+                                     segments=sf)
         assert torch.equal(o8, out[b0:b0 + split]) and torch.equal(p8, pre[b0:b0 + split]), b0
-        g8 = aum_hip.scan_tm_bwd(s8(u), s8(dl), A, s8(Bm), s8(Cm), D, s8(z), bias, s8(dout), p8, ck8, True, A_b=A_b, lib=lib)
+        g8 = aum_hip.scan_tm_bwd(s8(u), s8(dl), A, s8(Bm), s8(Cm), D, s8(z), bias, s8(dout), p8, ck8, True, A_b=A_b, lib=lib, segments=sb)
         for k in ("du", "ddelta", "dz", "dBC"):
             assert torch.equal(g8[k], g[k][b0:b0 + split]), (b0, k)
         for k in acc8:

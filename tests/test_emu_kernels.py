@@ -218,6 +218,17 @@ def test_scan_tm(emu, case, mode):
         KC.check_scan_tm(emu, "cpu", case, dt, reverse=(mode == "rev"), bidir=(mode == "bidir"), xz_layout=xz, backward=True)
 
 
+@pytest.mark.parametrize("case", [c for c in cases.SCAN_TM_CASES if c[3] >= 9], ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+@pytest.mark.parametrize("segments", [2, 3, 5])
+def test_scan_tm_segments(emu, case, mode, segments):
+    """aum_scan_tm_seg_fwd / _bwd: the rows cut into time segments that run as waves of their own (carry pass + main pass; the adjoint
+    the same way in the backward), against the same fp64 oracle at the same tolerances as the uncut launches: ranges of one block,
+    ragged last ranges, empty ranges (more segments than blocks), z / D absent, both directions and the Fo-Bi pair"""
+    for dt, xz in ((torch.float32, False), (torch.bfloat16, True)):
+        KC.check_scan_tm(emu, "cpu", case, dt, reverse=(mode == "rev"), bidir=(mode == "bidir"), xz_layout=xz, backward=True, segments=segments)
+
+
 @pytest.mark.parametrize("case", cases.CONV_TM_CASES, ids=lambda c: c[0])
 @pytest.mark.parametrize("reverse", [False, True])
 def test_conv_tm(emu, case, reverse):
@@ -266,6 +277,13 @@ def test_scan_tm_grid_small(emu):
     units -> forward workgroups of 2 and backward workgroups of 3 pairs, both with a ragged last workgroup"""
     rows = {0: [0, 63, 64, 191], 1: [5, 100], 2: [128, 127], 4: [0, 191, 77]}
     KC.check_scan_tm_grid(emu, "cpu", 5, 41, 192, rows, (0, 4), [0, 63, 64, 191], 1)
+
+
+def test_scan_tm_grid_small_segments(emu):
+    """the long-form whole-launch check (test_gpu_kernels.py::test_scan_tm_longform_grid_b8) at a size the lane-array build finishes:
+    forward cut into 4 ranges, backward into 3, rows of 75 steps (ranges of 24 / 32 steps, the last ragged)"""
+    rows = {0: [0, 63, 64, 191], 1: [5, 100], 2: [128, 127]}
+    KC.check_scan_tm_grid(emu, "cpu", 3, 75, 192, rows, (0, 2), [0, 63, 64, 191], 1, segments=(4, 3))
 
 
 @pytest.mark.parametrize("case", cases.GEMM_WGRAD_CASES[:4], ids=lambda c: "x".join(map(str, c)))

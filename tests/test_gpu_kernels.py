@@ -400,6 +400,29 @@ def test_scan_tm_headline_grid_b64(lib):
     print("scan_tm headline grid, worst errors:", {k: float("%.3g" % v) for k, v in sorted(worst.items())})
 
 
+@pytest.mark.parametrize("case", [c for c in cases.SCAN_TM_CASES if c[3] >= 9], ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+@pytest.mark.parametrize("segments", [2, 3, 5])
+def test_scan_tm_segments(lib, case, mode, segments):
+    """aum_scan_tm_seg_fwd / _bwd on the GPU: rows cut into time segments (carry pass + main pass per direction, the adjoint the same
+    way), same fp64 oracle and tolerances as the uncut launches; ragged and empty ranges, all three dtypes"""
+    for dt, xz in ((torch.float32, False), (torch.bfloat16, True), (torch.float16, False)):
+        KC.check_scan_tm(lib, "cuda", case, dt, reverse=(mode == "rev"), bidir=(mode == "bidir"), xz_layout=xz, backward=True, segments=segments)
+
+
+def test_scan_tm_longform_grid_b8(lib):
+    """SURVEY section 8 config 5 (long-form clips: B = 8, 128 x 8192 frames -> L = 4097 tokens, AuM-Base widths) on the time-segmented
+    token-major launches the dispatch takes there (16 ranges of 264 steps: aum_hip.scan_tm_segments) against the fp64 ORACLE
+    on whole 4097-step rows: sampled (entry, channel) rows of out / out_pre / du / ddelta / dz, dB | dC of whole batch entries,
+    parameter gradients of sampled channels over all entries, and the batch-split identity."""
+    import aum_hip
+    sf, sb = aum_hip.scan_tm_segments(8, 1536, 4097, True, False), aum_hip.scan_tm_segments(8, 1536, 4097, True, True)
+    assert sf > 1 and sb > 1, (sf, sb)
+    rows = {0: [0, 63, 64, 700], 3: [5, 64 * 7 + 1, 1535], 7: [64 * 23 + 62, 3, 1000]}
+    worst = KC.check_scan_tm_grid(lib, "cuda", 8, 4097, 1536, rows, (0, 7), [0, 63, 64, 1535], 4, segments=(sf, sb))
+    print("scan_tm long-form grid, segments", (sf, sb), "worst errors:", {k: float("%.3g" % v) for k, v in sorted(worst.items())})
+
+
 def test_scan_tm_small_inference_grid_b64(lib):
     """BASELINE config 2 at its bench batch on the dispatch the bench takes: AuM-Small, B = 64, E = 768, bf16,
     forward only -- token-major, 56-column x_dbl rows (dt rank 24 | B | C), which xdt_tm_supported refuses, so delta comes from

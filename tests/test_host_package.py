@@ -332,7 +332,11 @@ def test_token_major_module_matches_channel_major(monkeypatch):
     assert ssi.token_major_ok(1536, 16, 4, 48, torch.bfloat16) and ssi.token_major_ok(768, 16, 4, 24, torch.bfloat16)
     assert not ssi.token_major_ok(384, 16, 4, 12, torch.bfloat16)       # B / C rows of x_dbl not 16-byte aligned behind 12 bf16 dt columns
     assert not ssi.token_major_ok(1536, 8, 4, 48, torch.bfloat16) and not ssi.token_major_ok(96, 16, 4, 4, torch.float32)
-    assert ssi.token_major_preferred(64, 1536, True) and not ssi.token_major_preferred(8, 1536, True)      # long-form batch 8: chunk kernels
+    assert ssi.token_major_preferred(64, 1536, True) and not ssi.token_major_preferred(8, 1536, True)      # batch 8, short rows: chunk kernels
+    # long-form clips (B = 8, L = 4097): token-major on time segments -- as many ranges as give every SIMD its resident waves
+    assert ssi.token_major_preferred(8, 1536, True, training=True, seqlen=4097) and not ssi.token_major_preferred(8, 1536, True, seqlen=513)
+    assert ssi.tm_segments(8, 1536, 4097, True, False) == 16 and ssi.tm_segments(8, 1536, 4097, True, True) == 16
+    assert ssi.tm_segments(64, 1536, 4097, True, True) == 1 and ssi.tm_segments(1, 1536, 513, True, False) == 1
     # AuM-Small at batch 64 is 1536 waves: enough for the forward alone, not when a backward follows
     assert ssi.token_major_preferred(64, 768, True, training=False) and not ssi.token_major_preferred(64, 768, True, training=True)
     torch.manual_seed(3)
@@ -347,6 +351,34 @@ def test_token_major_module_matches_channel_major(monkeypatch):
             xi = x.clone().requires_grad_(True)
             y = m(xi)
             (y * w).sum().backward()
+            res.append((y.detach(), xi.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+        assert rel_err(res[0][0].numpy(), res[1][0].numpy()) < 1e-5 and rel_err(res[0][1].numpy(), res[1][1].numpy()) < 1e-4
+        for k in res[0][2]:
+            assert rel_err(res[0][2][k].numpy(), res[1][2][k].numpy()) < 2e-4, (btype, k)
+
+
+def test_token_major_segments_module(monkeypatch):
+    """the block on time-segmented token-major launches (what long-form clips dispatch to; forced here on a short row with
+    AUM_TM_SEGMENTS' module switch) against the channel-major block: output, input gradient, every parameter gradient"""
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(4)
+    for btype in ("v1", "none", "v2"):
+        m = Mamba(64, bimamba_type=btype, if_devide_out=btype == "v2")
+        x, w = torch.randn(2, 70, 64), torch.randn(2, 70, 64)
+        res = []
+        for seg in (3, 0):
+            monkeypatch.setattr(ssi, "_TM_SEGMENTS", seg)
+            monkeypatch.setattr(ssi, "_TM_MIN_WAVES", 10 ** 9)
+            calls = []
+            real = aum_hip.scan_tm_fwd
+            monkeypatch.setattr(aum_hip, "scan_tm_fwd", lambda *a, **k: (calls.append(k.get("segments")), real(*a, **k))[1])
+            m.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            y = m(xi)
+            (y * w).sum().backward()
+            monkeypatch.setattr(aum_hip, "scan_tm_fwd", real)
+            assert calls == (([3, 3] if btype == "v2" else [3]) if seg else []), (btype, seg, calls)
             res.append((y.detach(), xi.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
         assert rel_err(res[0][0].numpy(), res[1][0].numpy()) < 1e-5 and rel_err(res[0][1].numpy(), res[1][1].numpy()) < 1e-4
         for k in res[0][2]:
