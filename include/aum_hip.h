@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AUM_ABI_VERSION 9   /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
+#define AUM_ABI_VERSION 10  /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
                                3: x_lane (lane-entry state checkpoint of the L = 513 row kernels) appended after it;
                                4: aug / noise (per-clip augmentation in the log-mel kernel's epilogue) appended to AumFbankArgs;
                                5: aum_frontend_tokens_fwd (waveform -> token sequence in one launch);
@@ -35,7 +35,9 @@ extern "C" {
                                7: aum_scan_tm_fwd / _bwd (time-serial selective scan on token-major activations);
                                8: aum_conv1d_tm_fwd / _bwd (the causal conv on token-major activations);
                                9: aum_gemm_tn (the dense in_proj / out_proj GEMMs on token-major activations); aum_dtproj_tm_fwd, aum_xdt_tm_fwd; aum_scan_tm_ckpt_rows
-                                  (packed 16-bit state checkpoints of the token-major scan for 16-bit activations) */
+                                  (packed 16-bit state checkpoints of the token-major scan for 16-bit activations);
+                               10: aum_gemm_wgrad (weight gradients of the projections), aum_scan_tm_seg_fwd / _bwd (time segments: long rows at a small
+                                  batch), aum_causal_conv1d_update / aum_selective_state_update (streaming inference), aum_scan_tm_bwd_matrix_sums */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(so_path):
     lib = ctypes.CDLL(so_path)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.aum_abi_version() == aum_hip.ABI_VERSION == 9
+    assert lib.aum_abi_version() == aum_hip.ABI_VERSION == 10
     assert lib.aum_scan_max_single_pass_len() == 576
     assert lib.aum_rmsnorm_bwd_partials(32832) == 4096
 
@@ -61,6 +61,8 @@ def test_struct_layouts_match_header(tmp_path):
         "AumXdtArgs": (aum_hip.XdtArgs, ["u", "wx", "wdt", "x_dbl", "delta", "ntok", "dim", "rank", "ncols", "ldu", "ldwx", "ldwdt", "ldx", "ldd", "dtype"]),
         "AumGemmArgs": (aum_hip.GemmArgs, ["a", "b", "c", "m", "n", "k", "lda", "ldb", "ldc", "dtype", "flags"]),
         "AumGemmWArgs": (aum_hip.GemmWArgs, ["y", "x", "part", "t", "ldy", "ldx", "n", "k", "splits", "dtype"]),
+        "AumScanTmSegFwdArgs": (aum_hip.ScanTmSegFwdArgs, ["base", "carry", "carry_bytes", "segments"]),
+        "AumScanTmSegBwdArgs": (aum_hip.ScanTmSegBwdArgs, ["base", "segments"]),
         "AumConvUpdateArgs": (aum_hip.ConvUpdateArgs, ["x", "conv_state", "weight", "bias", "out", "batch", "dim", "width", "dtype", "flags"]),
         "AumStateUpdateArgs": (aum_hip.StateUpdateArgs, ["state", "x", "dt", "z", "B", "C", "A", "D", "dt_bias", "out", "batch", "dim", "dstate", "dtype", "flags"]),
     }
