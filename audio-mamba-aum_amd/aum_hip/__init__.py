@@ -144,6 +144,11 @@ class GemmArgs(C.Structure):
     _fields_ = ([(n, _vp) for n in ("a", "b", "c")] + [(n, _i32) for n in ("m", "n", "k", "lda", "ldb", "ldc", "dtype")] + [("flags", _u32)])
 
 
+class XdtBwdArgs(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("ddelta", "dbc", "wdt_t", "wx_t", "du", "dx_dbl")] + [("ntok", _i64)]
+                + [(n, _i32) for n in ("dim", "rank", "ncols", "ldd", "lddbc", "ldwdt", "ldwx", "ldu", "ldx", "dtype")])
+
+
 class GemmWArgs(C.Structure):
     _fields_ = [("y", C.c_void_p), ("x", C.c_void_p), ("part", C.c_void_p), ("t", C.c_int64), ("ldy", C.c_int64), ("ldx", C.c_int64),
                 ("n", C.c_int32), ("k", C.c_int32), ("splits", C.c_int32), ("dtype", C.c_int32)]
@@ -174,7 +179,7 @@ EXPORTS = ["aum_gemm_tn", "aum_dtproj_tm_fwd", "aum_xdt_tm_fwd", "aum_proj_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows",
            "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_ckpt_rows", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_scan_tm_seg_fwd", "aum_scan_tm_seg_bwd",
            "aum_scan_tm_seg_carry_bytes", "aum_scan_tm_seg_workspace_bytes", "aum_selftest_wave_sum32",
-           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_scan_tm_bwd_matrix_sums", "aum_gemm_wgrad", "aum_causal_conv1d_update", "aum_selective_state_update"]
+           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_scan_tm_bwd_matrix_sums", "aum_gemm_wgrad", "aum_xdt_tm_bwd", "aum_causal_conv1d_update", "aum_selective_state_update"]
 
 
 class Lib:
@@ -210,6 +215,7 @@ class Lib:
         self.c.aum_selective_state_update.argtypes = [_vp, _vp]
         self.c.aum_dtproj_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_xdt_tm_fwd.argtypes = [_vp, _vp]
+        self.c.aum_xdt_tm_bwd.argtypes = [_vp, _vp]
         self.c.aum_scan_tm_workspace_bytes.restype = _i64
         self.c.aum_scan_tm_workspace_bytes.argtypes = [_i32] * 5
         for fn in (self.c.aum_scan_tm_seg_carry_bytes, self.c.aum_scan_tm_seg_workspace_bytes):
@@ -681,16 +687,17 @@ GEMM_BN, GEMM_BK = 256, 64
 
 
 def gemm_wgrad_supported(y, x):
-    """shapes aum_gemm_wgrad takes (include/aum_hip.h, ABI 10): 16-bit 2-D token-major operands (rows = tokens, unit column stride), both
-    widths multiples of 256"""
+    """shapes aum_gemm_wgrad takes (include/aum_hip.h, ABI 10): 16-bit 2-D token-major operands (rows = tokens, unit column stride), y's
+    width a multiple of 256, x's a multiple of 256 or one of the skinny widths 48 / 80"""
     return (y.dim() == 2 and x.dim() == 2 and y.dtype == x.dtype and y.dtype in (torch.bfloat16, torch.float16) and y.shape[0] == x.shape[0]
-            and y.stride(1) == 1 and x.stride(1) == 1 and y.shape[1] % 256 == 0 and x.shape[1] % 256 == 0 and y.stride(0) % 8 == 0
+            and y.stride(1) == 1 and x.stride(1) == 1 and y.shape[1] % 256 == 0 and (x.shape[1] % 256 == 0 or x.shape[1] in (48, 80))
+            and y.stride(0) % 8 == 0
             and x.stride(0) % 8 == 0 and y.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and y.shape[0] > 0)
 
 
 def gemm_wgrad_splits(n, k, ncu=256):
     """token splits that give every CU one workgroup: (n / 256) (k / 256) output tiles x splits ~ the CU count"""
-    tiles = (n // 256) * (k // 256)
+    tiles = (n // 256) * max(1, k // 256)          # a skinny operand (k = 48 / 80) is one column tile
     return max(1, min(64, ncu // max(tiles, 1)))
 
 
@@ -830,6 +837,37 @@ def xdt_tm_supported(u, wx, wdt):
     ok_t = lambda t: t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
     return (wx.shape == (XDT_COLS, dim) and wdt.shape[0] == dim and dim % 256 == 0 and dim <= XDT_MAX_DIM and rank % 8 == 0 and rank <= 64
             and ok_t(u) and ok_t(wx) and ok_t(wdt))
+
+
+def xdt_tm_bwd_supported(ddelta, dbc, wdt_t, wx_t, du):
+    """shapes aum_xdt_tm_bwd takes (include/aum_hip.h, ABI 10): 16-bit row-major ddelta / du (ntok, dim), fp32 dB | dC rows (ntok, 32),
+    dt_proj.weight^T (48, dim), x_proj.weight^T (dim, 80)"""
+    if not (ddelta.dim() == 2 and du.shape == ddelta.shape and ddelta.dtype == du.dtype == wdt_t.dtype == wx_t.dtype
+            and ddelta.dtype in (torch.bfloat16, torch.float16) and dbc.dtype == torch.float32 and dbc.dim() == 2):
+        return False
+    ntok, dim = ddelta.shape
+    ok_t = lambda t, m=8: t.stride(1) == 1 and t.stride(0) % m == 0 and t.data_ptr() % 16 == 0
+    return (wx_t.shape == (dim, XDT_COLS) and wdt_t.shape == (XDT_COLS - 32, dim) and dbc.shape == (ntok, 32) and dim % 256 == 0
+            and dim <= XDT_MAX_DIM and ok_t(ddelta) and ok_t(du) and ok_t(wdt_t) and ok_t(wx_t) and ok_t(dbc, 4))
+
+
+def xdt_tm_bwd(ddelta, dbc, wdt_t, wx_t, du, lib=None):
+    """dx_dbl (ntok, 80) = [ddelta @ wdt_t^T | dbc] in ddelta's dtype, and du += dx_dbl @ wx_t^T IN PLACE (SSI:570-574, 587, 590 on
+    token-major rows: one pass over ddelta and du).  Returns dx_dbl."""
+    lib = lib or get()
+    for t in (ddelta, dbc, wdt_t, wx_t, du):
+        lib.check_tensor(t)
+    if not xdt_tm_bwd_supported(ddelta, dbc, wdt_t, wx_t, du):
+        raise RuntimeError(f"xdt_tm_bwd: unsupported operands {tuple(ddelta.shape)} {ddelta.dtype}, {tuple(dbc.shape)}, {tuple(wdt_t.shape)}, {tuple(wx_t.shape)}")
+    ntok, dim = ddelta.shape
+    dx_dbl = torch.empty((ntok, XDT_COLS), dtype=ddelta.dtype, device=ddelta.device)
+    a = XdtBwdArgs()
+    a.ddelta, a.dbc, a.wdt_t, a.wx_t, a.du, a.dx_dbl = _ptr(ddelta), _ptr(dbc), _ptr(wdt_t), _ptr(wx_t), _ptr(du), _ptr(dx_dbl)
+    a.ntok, a.dim, a.rank, a.ncols = ntok, dim, XDT_COLS - 32, XDT_COLS
+    a.ldd, a.lddbc, a.ldwdt, a.ldwx, a.ldu, a.ldx = ddelta.stride(0), dbc.stride(0), wdt_t.stride(0), wx_t.stride(0), du.stride(0), XDT_COLS
+    a.dtype = _DT[ddelta.dtype]
+    _launch(lib.c.aum_xdt_tm_bwd, a, ddelta, lib, "xdt_tm_bwd", (ntok, dim))
+    return dx_dbl
 
 
 def xdt_tm_fwd(u, wx, wdt, lib=None):

@@ -55,11 +55,19 @@ extern "C" int aum_gemm_wgrad(const AumGemmWArgs* p, void* stream) {
     const int rc = aumg::gemm_wgrad_check(p);
     if (rc != AUM_OK) return rc;
     const AumGemmWArgs& g = *p;
-    const int nitems = (g.n / 256) * (g.k / 256) * g.splits;
+    const bool skinny = g.k % 256 != 0;
+    const int nitems = (g.n / 256) * (skinny ? 1 : g.k / 256) * g.splits;
     const int grid = (nitems + 7) / 8 * 8;          // eight XCD runs of equal length; the surplus workgroups return at once
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)hipGetLastError();
-    if (g.dtype == AUM_BF16) hipLaunchKernelGGL(aumg::k_gemm_wgrad<true>, dim3(grid), dim3(aumg::THREADS), 0, s, g);
+    const bool bf = g.dtype == AUM_BF16;
+    if (skinny && g.k == 48) {
+        if (bf) hipLaunchKernelGGL((aumg::k_gemm_wgrad_skinny<true, 3>), dim3(grid), dim3(aumg::THREADS), 0, s, g);
+        else hipLaunchKernelGGL((aumg::k_gemm_wgrad_skinny<false, 3>), dim3(grid), dim3(aumg::THREADS), 0, s, g);
+    } else if (skinny) {
+        if (bf) hipLaunchKernelGGL((aumg::k_gemm_wgrad_skinny<true, 5>), dim3(grid), dim3(aumg::THREADS), 0, s, g);
+        else hipLaunchKernelGGL((aumg::k_gemm_wgrad_skinny<false, 5>), dim3(grid), dim3(aumg::THREADS), 0, s, g);
+    } else if (bf) hipLaunchKernelGGL(aumg::k_gemm_wgrad<true>, dim3(grid), dim3(aumg::THREADS), 0, s, g);
     else hipLaunchKernelGGL(aumg::k_gemm_wgrad<false>, dim3(grid), dim3(aumg::THREADS), 0, s, g);
     return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
 }
@@ -79,17 +87,71 @@ extern "C" int aum_dtproj_tm_fwd(const AumDtProjArgs* p, void* stream) {
     return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
 }
 
+// CU count of the CURRENT device (one process may drive several devices from several threads): a small per-device cache, filled with
+// relaxed atomics -- racing fillers write the same value
+static int cu_count() {
+    static std::atomic<int> ncu_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int ncu = ncu_of[dev].load(std::memory_order_relaxed);
+    if (!ncu) {
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) return 0;
+        ncu_of[dev].store(ncu, std::memory_order_relaxed);
+    }
+    return ncu;
+}
+
+template <int NW> static void xdt_launch(const AumXdtArgs& g, hipStream_t s) {
+    const dim3 grid((unsigned)((g.ntok + NW * XDT_TOK_W - 1) / (NW * XDT_TOK_W))), block(NW * 64);
+    const bool bf = g.dtype == AUM_BF16, one = g.rank <= 32;
+    if (bf && one) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<true, 1, NW>), grid, block, 0, s, g);
+    else if (bf) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<true, 2, NW>), grid, block, 0, s, g);
+    else if (one) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<false, 1, NW>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<false, 2, NW>), grid, block, 0, s, g);
+}
+
 extern "C" int aum_xdt_tm_fwd(const AumXdtArgs* p, void* stream) {
     const int rc = aumx::xdt_check(p);
     if (rc != AUM_OK) return rc;
     const AumXdtArgs& g = *p;
-    const dim3 grid((unsigned)((g.ntok + XDT_TOK_WG - 1) / XDT_TOK_WG)), block(XDT_WAVES * 64);
+    const int ncu = cu_count();
+    if (ncu <= 0) return AUM_E_LAUNCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool bf = g.dtype == AUM_BF16, one = g.rank <= 32;
-    if (bf && one) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<true, 1>), grid, block, 0, s, g);
-    else if (bf) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<true, 2>), grid, block, 0, s, g);
-    else if (one) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<false, 1>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<false, 2>), grid, block, 0, s, g);
+    (void)hipGetLastError();
+    switch (aumx::xdt_waves(g.ntok, ncu)) {
+        case 8: xdt_launch<8>(g, s); break;
+        case 9: xdt_launch<9>(g, s); break;
+        case 10: xdt_launch<10>(g, s); break;
+        case 11: xdt_launch<11>(g, s); break;
+        default: xdt_launch<12>(g, s); break;
+    }
+    return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
+}
+
+template <int NW> static void xdt_bwd_launch(const AumXdtBwdArgs& g, hipStream_t s) {
+    const dim3 grid((unsigned)((g.ntok + NW * XDT_TOK_W - 1) / (NW * XDT_TOK_W))), block(NW * 64);
+    const bool bf = g.dtype == AUM_BF16, deep = g.dim % 512 == 0;          // du read-ahead of four channel pairs where a quarter of the channels holds a multiple of four
+    if (bf && deep) hipLaunchKernelGGL((aumx::k_xdt_tm_bwd<true, 3, NW, 4>), grid, block, 0, s, g);
+    else if (bf) hipLaunchKernelGGL((aumx::k_xdt_tm_bwd<true, 3, NW, 2>), grid, block, 0, s, g);
+    else if (deep) hipLaunchKernelGGL((aumx::k_xdt_tm_bwd<false, 3, NW, 4>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((aumx::k_xdt_tm_bwd<false, 3, NW, 2>), grid, block, 0, s, g);
+}
+
+extern "C" int aum_xdt_tm_bwd(const AumXdtBwdArgs* p, void* stream) {
+    const int rc = aumx::xdt_bwd_check(p);
+    if (rc != AUM_OK) return rc;
+    const AumXdtBwdArgs& g = *p;
+    const int ncu = cu_count();
+    if (ncu <= 0) return AUM_E_LAUNCH;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    switch (aumx::xdt_waves(g.ntok, ncu)) {
+        case 8: xdt_bwd_launch<8>(g, s); break;
+        case 9: xdt_bwd_launch<9>(g, s); break;
+        case 10: xdt_bwd_launch<10>(g, s); break;
+        case 11: xdt_bwd_launch<11>(g, s); break;
+        default: xdt_bwd_launch<12>(g, s); break;
+    }
     return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
 }
 

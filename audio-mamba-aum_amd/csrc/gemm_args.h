@@ -23,7 +23,8 @@ inline int gemm_wgrad_check(const AumGemmWArgs* p) {
     const AumGemmWArgs& g = *p;
     if (g.t <= 0 || g.n <= 0 || g.k <= 0 || g.splits <= 0 || g.ldy < g.n || g.ldx < g.k) return AUM_E_SHAPE;
     if (g.dtype != AUM_BF16 && g.dtype != AUM_F16) return AUM_E_DTYPE;
-    if (g.n % 256 || g.k % 256 || g.ldy % 8 || g.ldx % 8 || g.splits > 64) return AUM_E_UNSUPPORTED;
+    // k: multiples of 256 (the projections), or 48 / 80 (the skinny operands x_dbl[:, :48] and dx_dbl: dt_proj's and x_proj's weight gradients)
+    if (g.n % 256 || (g.k % 256 && g.k != 48 && g.k != 80) || g.ldy % 8 || g.ldx % 8 || g.splits > 64) return AUM_E_UNSUPPORTED;
     if (((uintptr_t)g.y | (uintptr_t)g.x | (uintptr_t)g.part) & 15u) return AUM_E_UNSUPPORTED;
     const int64_t chunk = (((g.t + g.splits - 1) / g.splits) + 63) / 64 * 64;
     if (chunk * g.ldy * 2 >= (1ll << 31) || chunk * g.ldx * 2 >= (1ll << 31)) return AUM_E_UNSUPPORTED;   // 32-bit buffer offsets inside a split

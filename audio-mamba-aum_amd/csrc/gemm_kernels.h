@@ -552,4 +552,101 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_wgrad(AumGemmWArgs g) {
         for (int f = 0; f < 4; ++f) *reinterpret_cast<f4v*>(c_base + (int64_t)fn * 16 * g.k + f * 16) = acc[fn][f];
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The same product with a SKINNY second operand (round 4): k = 48 or 80 columns -- the weight gradients of dt_proj and x_proj,
+//   d W_dt [E][48] = ddelta^T . x_dbl[:, :48]  (SSI:586),      d W_x^T [E][80] = conv_out^T . dx_dbl  (SSI:589, stored transposed),
+// one 100 MB activation tensor streamed against 3 / 5 MB.  As strided batched library GEMMs they ran at a third of the copy rate
+// (52 / 55 us for 16 us of traffic).  Arrangement: a workgroup owns a 256-channel slab of y and a token split; the y stages are the big
+// kernel's ([32 tokens][256 columns], swizzled 512-byte rows), the x stage is [32 tokens][16 chunks] with the same swizzle in 256-byte rows
+// (6 / 10 chunks are real, the DMA lanes of the others fetch chunk 0 again: 3 % of the traffic); a wave multiplies its 32 channels (two
+// fragments) by all XC = 3 / 5 column fragments of x.  Three DMA pieces per wave and K-step, four stages in flight.
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int W_XSTAGE_S = 32 * 256;          // bytes of one skinny x stage
+
+template <bool BF16, int XC>
+__global__ __launch_bounds__(THREADS, 1) void k_gemm_wgrad_skinny(AumGemmWArgs g) {
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ntn = g.n / 256;
+    const int nitems = ntn * g.splits, per = (nitems + 7) / 8;         // split-major items, one contiguous run per XCD (see k_gemm_wgrad)
+    const int item = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (((int)blockIdx.x >> 3) >= per || item >= nitems) return;
+    const int s = item / ntn;
+    const int n0 = (item - s * ntn) * 256;
+    const int64_t chunk = ((((int64_t)g.t + g.splits - 1) / g.splits) + 63) / 64 * 64;
+    const int64_t t0 = (int64_t)s * chunk;
+    const int rows = (int)(t0 >= g.t ? 0 : (g.t - t0 < chunk ? g.t - t0 : chunk));
+    const int nk = (rows + 31) / 32;
+
+    const char* y_base = static_cast<const char*>(g.y) + (t0 * g.ldy + n0) * 2;
+    const char* x_base = static_cast<const char*>(g.x) + (t0 * g.ldx) * 2;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(y_base), 0, rows > 0 ? (int)((int64_t)(rows - 1) * g.ldy * 2 + 512) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x_base), 0, rows > 0 ? (int)((int64_t)(rows - 1) * g.ldx * 2 + XC * 32) : 0, 0x00020000);
+
+    // y: piece c = jj * 8 + w is tokens 2 c, 2 c + 1 of the K-step (as in k_gemm_wgrad); x: piece w is tokens 4 w .. 4 w + 3, lane l fills
+    // physical chunk l & 15 of token 4 w + (l >> 4) with logical chunk (l & 15) ^ swizzle(token), or with chunk 0 where that is past the row
+    const int trow = 2 * w + (lane >> 5);
+    const int csrc = (lane & 31) ^ (2 * ((trow & 3) + 4 * ((trow >> 3) & 1)));
+    const int voff_y = trow * (int)g.ldy * 2 + csrc * 16;
+    const int step_y = 16 * (int)g.ldy * 2;
+    const int xrow = 4 * w + (lane >> 4);
+    const int xc_l = (lane & 15) ^ (2 * ((xrow & 3) + 4 * ((xrow >> 3) & 1)));
+    const int voff_x = xrow * (int)g.ldx * 2 + (xc_l < 2 * XC ? xc_l : 0) * 16;
+    const int step_x = 32 * (int)g.ldx * 2;
+    auto stage_w = [&](int kstep, int st) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) wg_dma16(ry, lds + W_YOFF + st * W_STAGE + (jj * 8 + w) * 1024, voff_y, (kstep * 2 + jj) * step_y);
+        wg_dma16(rx, lds + W_XOFF + st * W_XSTAGE_S + w * 1024, voff_x, kstep * step_x);
+    };
+
+    const int gq = lane >> 4, j = (lane >> 2) & 3, q = lane & 3;
+    const int swz = 2 * j + 8 * (gq & 1);
+    const int lane_y = (8 * gq + j) * 512 + (q >> 1) * 16 + (q & 1) * 8;
+    const int lane_x = (8 * gq + j) * 256 + (q >> 1) * 16 + (q & 1) * 8;
+    int ay[2], ax[XC];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) ay[m] = W_YOFF + lane_y + (((4 * w + 2 * m) ^ swz) * 16);
+#pragma unroll
+    for (int f = 0; f < XC; ++f) ax[f] = W_XOFF + lane_x + (((2 * f) ^ swz) * 16);
+
+    f4v acc[2][XC];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int f = 0; f < XC; ++f) acc[m][f] = f4v{0.f, 0.f, 0.f, 0.f};
+    auto frag = [&](int addr, int tok4) -> s8v {
+        const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(lds + addr));
+        const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(lds + addr + tok4));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+#pragma unroll
+    for (int p = 0; p < W_NST - 1; ++p)
+        if (p < nk) stage_w(p, p);
+    for (int t = 0; t < nk; ++t) {
+        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + W_NST - 1 < nk) stage_w(t + W_NST - 1, (t + W_NST - 1) & (W_NST - 1));
+        const int sy = (t & (W_NST - 1)) * W_STAGE, sx = (t & (W_NST - 1)) * W_XSTAGE_S;
+        s8v xf[XC], yf[2];
+#pragma unroll
+        for (int f = 0; f < XC; ++f) xf[f] = frag(ax[f] + sx, 4 * 256);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) yf[m] = frag(ay[m] + sy, 4 * 512);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int f = 0; f < XC; ++f) acc[m][f] = mfma<BF16>(xf[f], yf[m], acc[m][f]);
+    }
+    // lane (gq, i = lane & 15) holds C[n0 + 32 w + 16 m + i][16 f + 4 gq + r], r = 0..3
+    float* c_base = g.part + ((int64_t)s * g.n + n0 + 32 * w + (lane & 15)) * g.k + 4 * gq;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int f = 0; f < XC; ++f) *reinterpret_cast<f4v*>(c_base + (int64_t)m * 16 * g.k + f * 16) = acc[m][f];
+}
+
 }  // namespace aumg

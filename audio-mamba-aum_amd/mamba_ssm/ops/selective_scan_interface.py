@@ -355,6 +355,7 @@ def _mm_rows(a, b, bit):
 # 67.0-70.1 (N = 768 is two tiles per CU: tile quantisation).  The default ("auto") therefore sends the two N >= 1536 shapes
 # to the kernel; AUM_DEBUG=1 AUM_GEMM=hip sends all four, AUM_GEMM=lib none, AUM_GEMM_SHAPES="NxK,..." another set (A/B runs).  The weight
 # gradients (token-contiguous operands) and everything that does not qualify stay library GEMMs.
+_XDT_BWD_HIP = _dbg_env("AUM_XDT_BWD_LIB", "0") != "1"      # AUM_DEBUG=1 AUM_XDT_BWD_LIB=1: the x_proj / dt_proj gradients as five library calls (A/B)
 _XDT_HIP = _dbg_env("AUM_XDT_LIB", "0") != "1"              # AUM_DEBUG=1 AUM_XDT_LIB=1: x_proj as a library GEMM + the dt projection kernel (A/B)
 _DTPROJ_HIP = _dbg_env("AUM_DTPROJ_LIB", "0") != "1"        # AUM_DEBUG=1 AUM_DTPROJ_LIB=1: the dt projection back on the library GEMM (A/B)
 _GEMM_MODE = _dbg_env("AUM_GEMM", "auto")
@@ -490,6 +491,7 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
       place (SSI:473-493) -> one selective-scan launch, both directions (SSI:499-507) -> out_proj (SSI:517)."""
     act = _autocast_dtype()
     ctx.out_proj_wdtype = out_proj_weight.dtype if out_proj_weight is not None else None
+    x_proj_param, delta_proj_param = x_proj_weight, delta_proj_weight
     x_proj_weight, delta_proj_weight = _cast(x_proj_weight, act), _cast(delta_proj_weight, act)
     out_proj_param = out_proj_weight
     out_proj_weight, out_proj_bias = _cast(out_proj_weight, act), _cast(out_proj_bias, act)
@@ -520,6 +522,12 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
     x3 = x_dbl.view(Bsz, L, R + 2 * N)
     Bm, Cm = x3[:, :, R:R + N], x3[:, :, R + N:]                                            # SSI:479  views, no copies
     need_bwd = any(ctx.needs_input_grad)
+    # the backward's row pass (aum_xdt_tm_bwd) multiplies by the two small weights the other way round: their transposes, from the
+    # step cache when the model filled it
+    w_x_t = w_dt_t = None
+    if need_bwd and _XDT_BWD_HIP and conv2d.is_cuda and R + 2 * N == aum_hip.XDT_COLS and R == aum_hip.XDT_COLS - 32 and E % 256 == 0 \
+            and E <= aum_hip.XDT_MAX_DIM and conv2d.dtype in (torch.bfloat16, torch.float16):
+        w_x_t, w_dt_t = _cast_t(x_proj_param, conv2d.dtype), _cast_t(delta_proj_param, conv2d.dtype)
     ckpt = aum_hip.scan_tm_ckpt(Bsz, L, E, N, A_b is not None, xz.device, dtype=conv_out.dtype) if need_bwd else None
     waves = Bsz * (E // 64) * (2 if A_b is not None else 1)
     cut = waves < (-(-_TM_MIN_WAVES * 4 // 3) if need_bwd else _TM_MIN_WAVES)
@@ -532,7 +540,7 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
     ctx.has_out_proj = out_proj_weight is not None
     ctx.out_proj_bias_is_None = out_proj_bias is None
     ctx.save_for_backward(xz, conv_w, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, A_b, D,
-                          delta_bias, out_pre, out_z, ckpt, out_proj_wt)
+                          delta_bias, out_pre, out_z, ckpt, out_proj_wt, w_x_t, w_dt_t)
     if out_proj_weight is None:
         return out_z.transpose(1, 2)                                                         # SSI:224  (B, E, L) logical
     out = _gemm_rows(out_z.view(Bsz * L, E), out_proj_weight.to(out_z.dtype), 2)             # SSI:517
@@ -543,7 +551,7 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
 
 def _inner_backward_tm(ctx, dout):
     (xz, conv_w, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, A_b, D, delta_bias, out_pre,
-     out_z, ckpt, out_proj_wt) = ctx.saved_tensors
+     out_z, ckpt, out_proj_wt, w_x_t, w_dt_t) = ctx.saved_tensors
     xz_t = xz.transpose(1, 2)
     Bsz, L, two_e = xz_t.shape
     E = two_e // 2
@@ -566,13 +574,22 @@ def _inner_backward_tm(ctx, dout):
                             ckpt, ctx.delta_softplus, ctx.reverse if A_b is None else False, A_b=A_b, dz_out=dz,
                             segments=tm_segments(Bsz, E, L, A_b is not None, True) if ctx.tm_cut else 1)   # SSI:541-561
     du2, ddelta2 = g["du"].view(Bsz * L, E), g["ddelta"].view(Bsz * L, E)
-    dx_dbl = torch.empty_like(x_dbl)
-    dx_dbl[:, R:].copy_(g["dBC"].view(Bsz * L, 2 * N))                                       # SSI:570-574
-    dx_dbl[:, :R].copy_(torch.matmul(ddelta2, delta_proj_weight.to(ddelta2.dtype)))          # SSI:587
-    splits = _pick_splits(Bsz * L, _WGRAD_SPLITS[1])
-    ddelta_proj_weight = split_k_wgrad(ddelta2.t(), x_dbl[:, :R], splits, torch.float32)     # SSI:586
-    dx_proj_weight = split_k_wgrad(dx_dbl.t(), conv_out.view(Bsz * L, E), splits, torch.float32)   # SSI:589
-    du2.addmm_(dx_dbl, x_proj_weight.to(dx_dbl.dtype))                                       # SSI:590
+    dbc2 = g["dBC"].view(Bsz * L, 2 * N)
+    conv2d = conv_out.view(Bsz * L, E)
+    if w_x_t is not None and aum_hip.xdt_tm_bwd_supported(ddelta2, dbc2, w_dt_t, w_x_t, du2):
+        # SSI:570-574, 587, 590 in one pass over ddelta and du (aum_xdt_tm_bwd); the two weight gradients on the skinny form of the
+        # weight-gradient kernel (aum_gemm_wgrad, k = 48 / 80): every activation tensor is read once per product
+        dx_dbl = aum_hip.xdt_tm_bwd(ddelta2, dbc2, w_dt_t, w_x_t, du2)
+        ddelta_proj_weight = aum_hip.gemm_wgrad(ddelta2, x_dbl[:, :R])                       # SSI:586  (E, R) fp32
+        dx_proj_weight = aum_hip.gemm_wgrad(conv2d, dx_dbl).t().contiguous()                 # SSI:589  (R + 2N, E) fp32
+    else:
+        dx_dbl = torch.empty_like(x_dbl)
+        dx_dbl[:, R:].copy_(dbc2)                                                            # SSI:570-574
+        dx_dbl[:, :R].copy_(torch.matmul(ddelta2, delta_proj_weight.to(ddelta2.dtype)))      # SSI:587
+        splits = _pick_splits(Bsz * L, _WGRAD_SPLITS[1])
+        ddelta_proj_weight = split_k_wgrad(ddelta2.t(), x_dbl[:, :R], splits, torch.float32)     # SSI:586
+        dx_proj_weight = split_k_wgrad(dx_dbl.t(), conv2d, splits, torch.float32)            # SSI:589
+        du2.addmm_(dx_dbl, x_proj_weight.to(dx_dbl.dtype))                                   # SSI:590
     _, dconv_w, dconv_b = aum_hip.conv1d_tm_bwd(x, conv_w, conv1d_bias, g["du"], True, ctx.reverse, dx_out=dx)   # SSI:594
     return dict(dxz=dxz_t.transpose(1, 2), dconv_w=dconv_w.reshape(E, 1, -1), dconv_b=dconv_b, dx_proj_w=dx_proj_weight,
                 ddt_proj_w=ddelta_proj_weight, dout_proj_w=dout_proj_weight, dout_proj_b=dout_proj_bias,

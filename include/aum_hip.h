@@ -440,7 +440,7 @@ int aum_gemm_tn(const AumGemmArgs* args, void* stream);
  *   y: (t, n) rows of pitch ldy (the output gradient);  x: (t, k) rows of pitch ldx (the layer's input) -- pitches in ELEMENTS, both `dtype`
  *   (AUM_BF16 / AUM_F16; else AUM_E_DTYPE);  part: (splits, n, k) fp32, contiguous: the caller sums the splits in a fixed order (aum_sum_rows).
  *   Split s takes tokens [s c, min(t, (s + 1) c)) with c = ceil(ceil(t / splits) / 64) * 64 (a split may be empty: its tile is zero).
- *   n % 256 == 0, k % 256 == 0, splits <= 64, pitches % 8 == 0, 16-byte aligned pointers, c * pitch * 2 < 2 GiB (else AUM_E_UNSUPPORTED: callers
+ *   n % 256 == 0, k % 256 == 0 or k in {48, 80} (the skinny operands of the dt_proj / x_proj weight gradients, SSI:586, 589), splits <= 64, pitches % 8 == 0, 16-byte aligned pointers, c * pitch * 2 < 2 GiB (else AUM_E_UNSUPPORTED: callers
  *   use a library GEMM).  fp32 accumulation; no atomics: the result is bitwise repeatable.
  */
 typedef struct AumGemmWArgs {
@@ -489,6 +489,27 @@ typedef struct AumXdtArgs {
     int32_t dtype;
 } AumXdtArgs;
 int aum_xdt_tm_fwd(const AumXdtArgs* args, void* stream);
+
+/*
+ * The token-parallel pieces of the x_proj / dt_proj gradients in one pass (ABI 10; selective_scan_interface.py:570-574, :587, :590):
+ *   dx_dbl[:, :rank] = ddelta . dt_proj.weight  (rounded to `dtype`),  dx_dbl[:, rank:] = dB | dC (the scan backward's fp32 rows),
+ *   du += dx_dbl . x_proj.weight  (in place).
+ *   ddelta: (ntok, dim) pitch ldd;  dbc: (ntok, ncols - rank) fp32 pitch lddbc;  wdt_t: dt_proj.weight TRANSPOSED, (rank, dim) pitch ldwdt;
+ *   wx_t: x_proj.weight TRANSPOSED, (dim, ncols) pitch ldwx;  du (in / out): (ntok, dim) pitch ldu;  dx_dbl (out): (ntok, ncols) pitch ldx.
+ *   Built for ncols == 80, rank == 48 (AuM-Base), dim % 256 == 0, dim <= 1536, pitches % 8 == 0 (lddbc % 4 == 0), 16-byte aligned pointers;
+ *   anything else AUM_E_UNSUPPORTED (callers use the three library calls).
+ */
+typedef struct AumXdtBwdArgs {
+    const void *ddelta;
+    const float *dbc;
+    const void *wdt_t, *wx_t;
+    void *du, *dx_dbl;
+    int64_t ntok;
+    int32_t dim, rank, ncols;
+    int32_t ldd, lddbc, ldwdt, ldwx, ldu, ldx;
+    int32_t dtype;
+} AumXdtBwdArgs;
+int aum_xdt_tm_bwd(const AumXdtBwdArgs* args, void* stream);
 
 /*
  * Streaming inference, one token per call (ABI 10; mamba_simple.py:313-358 `Mamba.step`).  The caches are fp32, contiguous, updated in place.

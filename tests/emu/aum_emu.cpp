@@ -105,6 +105,36 @@ extern "C" int aum_xdt_tm_fwd(const AumXdtArgs* p, void*) {
     return AUM_OK;
 }
 
+// aum_xdt_tm_bwd on host pointers: dx_dbl = [ddelta . W_dt rounded | dB | dC], du += dx_dbl . W_x from the ROUNDED dx_dbl
+extern "C" int aum_xdt_tm_bwd(const AumXdtBwdArgs* p, void*) {
+    const int rc = aumx::xdt_bwd_check(p);
+    if (rc != AUM_OK) return rc;
+    auto run = [&](auto tag) {
+        using T = decltype(tag);
+        const T* dd = static_cast<const T*>(p->ddelta);
+        const T* wd = static_cast<const T*>(p->wdt_t);
+        const T* wx = static_cast<const T*>(p->wx_t);
+        T* du = static_cast<T*>(p->du);
+        T* dx = static_cast<T*>(p->dx_dbl);
+        for (int64_t t = 0; t < p->ntok; ++t) {
+            for (int r = 0; r < p->rank; ++r) {
+                float acc = 0.f;
+                for (int e = 0; e < p->dim; ++e) acc += aum::elem_to_f32(dd[t * p->ldd + e]) * aum::elem_to_f32(wd[(int64_t)r * p->ldwdt + e]);
+                aum::f32_to_elem(acc, dx[t * p->ldx + r]);
+            }
+            for (int c = p->rank; c < p->ncols; ++c) aum::f32_to_elem(p->dbc[t * p->lddbc + c - p->rank], dx[t * p->ldx + c]);
+            for (int e = 0; e < p->dim; ++e) {
+                float acc = 0.f;
+                for (int c = 0; c < p->ncols; ++c) acc += aum::elem_to_f32(dx[t * p->ldx + c]) * aum::elem_to_f32(wx[(int64_t)e * p->ldwx + c]);
+                aum::f32_to_elem(acc + aum::elem_to_f32(du[t * p->ldu + e]), du[t * p->ldu + e]);
+            }
+        }
+    };
+    if (p->dtype == AUM_BF16) run(aum::bf16_t{});
+    else run(aum::f16_t{});
+    return AUM_OK;
+}
+
 // the per-token decode kernels on host pointers: shared argument rules (decode_args.h), the arithmetic of csrc/decode_kernels.h as plain loops
 #include "../../audio-mamba-aum_amd/csrc/decode_args.h"
 extern "C" int aum_causal_conv1d_update(const AumConvUpdateArgs* p, void*) {

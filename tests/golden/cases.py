@@ -330,7 +330,9 @@ GEMM_CASES = [
 ]
 # aum_gemm_wgrad: (tokens, n, k, splits, pad_y, pad_x) -- one K-step, ragged last step, empty splits, both operands slices of wider rows
 GEMM_WGRAD_CASES = [(64, 256, 256, 1, 0, 0), (65, 256, 256, 1, 0, 0), (200, 256, 512, 2, 0, 0), (513, 512, 256, 3, 8, 16), (130, 256, 256, 7, 0, 8),
-                    (1026, 768, 256, 4, 768, 0)]
+                    (1026, 768, 256, 4, 768, 0),
+                    # the skinny second operand (k = 48 / 80: dt_proj's and x_proj's weight gradients; x = the first 48 of 80-column rows)
+                    (64, 256, 48, 1, 0, 32), (65, 256, 80, 1, 0, 0), (513, 512, 48, 3, 8, 32), (130, 256, 80, 7, 0, 0), (1026, 768, 80, 4, 768, 16)]
 # (the GPU-only sizes below also cover more items than CUs: several tiles per workgroup, odd and even step counts)
 # on the GPU only (the host build's triple loop would take minutes): the bench's own GEMMs, (m, n, k) of in_proj / out_proj forward and
 # data gradient at 64 x 513 tokens and at 3 x 513 tokens
@@ -341,4 +343,6 @@ GEMM_FULL_CASES = [(70000, 512, 192), (64 * 513, 3072, 768), (64 * 513, 768, 153
 DTPROJ_CASES = [(1, 64, 8, 40), (33, 96, 24, 56), (129, 256, 48, 80), (513, 1536, 48, 80), (200, 768, 24, 56), (70, 128, 64, 96), (31, 32, 16, 48)]
 
 # aum_xdt_tm_fwd (ABI 9): (ntok, dim, dt_rank) -- ragged token tiles (128 per workgroup, 32 per wave), one and two dt K-steps, every dim class
+# (ntok, dim, pad columns behind the ddelta / du rows): aum_xdt_tm_bwd; 2052 and 2305 tokens: 9 waves per workgroup on 256 CUs, ragged last workgroup
+XDT_BWD_CASES = [(1, 256, 0), (33, 256, 8), (127, 512, 0), (145, 768, 16), (513, 1536, 0), (300, 1024, 8), (2305, 1536, 0)]
 XDT_CASES = [(1, 256, 8), (33, 256, 24), (127, 512, 48), (129, 768, 32), (513, 1536, 48), (300, 1024, 64)]

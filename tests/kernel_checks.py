@@ -581,6 +581,32 @@ def check_dtproj(lib, dev, ntok, dim, rank, ncols, dtype):
     assert out.shape == (ntok, dim) and err <= 1.01 * ulp * ref.abs().max().item() + 1e-30, (ntok, dim, rank, err)
 
 
+def check_xdt_bwd(lib, dev, ntok, dim, dtype, pad=0):
+    """aum_xdt_tm_bwd (ABI 10; SSI:570-574, 587, 590): dx_dbl[:, :48] against an fp64 product of the 16-bit operands (one rounding),
+    dx_dbl[:, 48:] = the fp32 dB | dC rows rounded, du against fp64 (du_in + the kernel's OWN rounded dx_dbl . W_x) rounded once -- what
+    the reference's GEMM, copy and addmm compute.  pad: extra columns behind ddelta / du rows (pitch > dim)."""
+    g = torch.Generator().manual_seed(ntok * 5 + dim)
+    R, C = 48, 80
+    ddf = torch.randn(ntok, dim + pad, generator=g).to(dtype).to(dev)
+    duf = torch.randn(ntok, dim + pad, generator=g).to(dtype).to(dev)
+    ddelta, du = ddf[:, :dim], duf[:, :dim]
+    dbc = torch.randn(ntok, C - R, generator=g).to(dev)
+    wdt_t = (torch.randn(R, dim, generator=g) / dim ** 0.5).to(dtype).to(dev)
+    wx_t = (torch.randn(dim, C, generator=g) / C ** 0.5).to(dtype).to(dev)
+    du_in = du.double().cpu()
+    tail_in = duf[:, dim:].clone()
+    dx = aum_hip.xdt_tm_bwd(ddelta, dbc, wdt_t, wx_t, du, lib=lib)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    ref_r = ddelta.double().cpu() @ wdt_t.double().cpu().t()
+    er = (dx[:, :R].double().cpu() - ref_r).abs().max().item()
+    assert dx.shape == (ntok, C) and er <= 1.01 * ulp * ref_r.abs().max().item(), ("dx_dbl dt block", ntok, dim, er)
+    assert torch.equal(dx[:, R:].cpu(), dbc.to(dtype).cpu()), "dx_dbl B | C block"
+    ref_u = du_in + dx.double().cpu() @ wx_t.double().cpu().t()
+    eu = (du.double().cpu() - ref_u).abs().max().item()
+    assert eu <= 1.01 * ulp * ref_u.abs().max().item(), ("du", ntok, dim, eu)
+    assert torch.equal(duf[:, dim:], tail_in), "columns behind the du rows were written"
+
+
 def check_xdt(lib, dev, ntok, dim, rank, dtype):
     """aum_xdt_tm_fwd (ABI 9; SSI:467-468): x_dbl against an fp64 product of the 16-bit operands (one rounding), delta against an fp64
     product of the kernel's OWN rounded x_dbl (what two separate GEMMs compute)"""

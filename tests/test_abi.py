@@ -59,6 +59,8 @@ def test_struct_layouts_match_header(tmp_path):
                                                "dtype", "flags"]),
         "AumDtProjArgs": (aum_hip.DtProjArgs, ["x", "w", "out", "ntok", "dim", "rank", "ldx", "ldw", "ldo", "dtype"]),
         "AumXdtArgs": (aum_hip.XdtArgs, ["u", "wx", "wdt", "x_dbl", "delta", "ntok", "dim", "rank", "ncols", "ldu", "ldwx", "ldwdt", "ldx", "ldd", "dtype"]),
+        "AumXdtBwdArgs": (aum_hip.XdtBwdArgs, ["ddelta", "dbc", "wdt_t", "wx_t", "du", "dx_dbl", "ntok", "dim", "rank", "ncols", "ldd", "lddbc", "ldwdt", "ldwx",
+                                               "ldu", "ldx", "dtype"]),
         "AumGemmArgs": (aum_hip.GemmArgs, ["a", "b", "c", "m", "n", "k", "lda", "ldb", "ldc", "dtype", "flags"]),
         "AumGemmWArgs": (aum_hip.GemmWArgs, ["y", "x", "part", "t", "ldy", "ldx", "n", "k", "splits", "dtype"]),
         "AumScanTmSegFwdArgs": (aum_hip.ScanTmSegFwdArgs, ["base", "carry", "carry_bytes", "segments"]),

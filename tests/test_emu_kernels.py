@@ -271,6 +271,11 @@ def test_xdt_tm_contract(emu):
     KC.check_xdt(emu, "cpu", 33, 256, 24, torch.bfloat16)
 
 
+def test_xdt_tm_bwd_contract(emu):
+    """the host build's aum_xdt_tm_bwd (plain loops behind the shared argument rules): dx_dbl rounded once, du from the rounded dx_dbl, in place"""
+    KC.check_xdt_bwd(emu, "cpu", 33, 256, torch.bfloat16, 8)
+
+
 def test_scan_tm_grid_small(emu):
     """the whole-launch oracle check of test_gpu_kernels.py::test_scan_tm_headline_grid_b64 (sampled rows, whole-entry dB | dC, batch-
     summed parameter gradients, batch splits) on a launch small enough for the lane-array build: 5 entries x 3 channel groups = 15
@@ -286,7 +291,7 @@ def test_scan_tm_grid_small_segments(emu):
     KC.check_scan_tm_grid(emu, "cpu", 3, 75, 192, rows, (0, 2), [0, 63, 64, 191], 1, segments=(4, 3))
 
 
-@pytest.mark.parametrize("case", cases.GEMM_WGRAD_CASES[:4], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", cases.GEMM_WGRAD_CASES[:4] + cases.GEMM_WGRAD_CASES[6:8], ids=lambda c: "x".join(map(str, c)))
 def test_gemm_wgrad_contract(emu, case):
     """the host twin of aum_gemm_wgrad (tests/emu/aum_emu.cpp: shared argument rules and split boundaries): what the host-side dispatch
     tests run against; the device kernel's own parity is test_gpu_kernels.py::test_gemm_wgrad*"""

@@ -508,7 +508,7 @@ def test_gemm_wgrad_full_size(lib):
     """the bench's two weight-gradient GEMMs (64 x 513 tokens; d W_in = dxz^T . hidden: 36 tiles x 7 splits, d W_out = dout^T . out_z: 18 x 14)
     against fp64 on sampled rows of the result, with the operands laid out as the block has them, bitwise repeatable"""
     t = 64 * 513
-    for n, k in ((3072, 768), (768, 1536)):
+    for n, k in ((3072, 768), (768, 1536), (1536, 48), (1536, 80)):          # the last two: the skinny kernel (dt_proj / x_proj weight gradients)
         torch.manual_seed(n + k)
         y = (torch.randn(t, n, device="cuda") * 0.1).to(torch.bfloat16)
         x = torch.randn(t, k, device="cuda").to(torch.bfloat16)
@@ -612,6 +612,34 @@ def test_gemm_tn_random_shapes(lib):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_xdt_tm(lib, case, dtype):
     KC.check_xdt(lib, "cuda", *case, dtype)
+
+
+@pytest.mark.parametrize("case", cases.XDT_BWD_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_xdt_tm_bwd(lib, case, dtype):
+    KC.check_xdt_bwd(lib, "cuda", case[0], case[1], dtype, case[2])
+
+
+def test_xdt_tm_bwd_headline_shape(lib):
+    """aum_xdt_tm_bwd at the bench's own launch (64 x 513 tokens, d_inner 1536): dx_dbl and du of every token against fp32 products of
+    the same operands (the three library calls it replaces: SSI:570-574, 587, 590), bitwise repeatable"""
+    torch.manual_seed(8)
+    M, E = 64 * 513, 1536
+    ddelta = torch.randn(M, E, device="cuda").bfloat16()
+    du0 = torch.randn(M, E, device="cuda").bfloat16()
+    dbc = torch.randn(M, 32, device="cuda")
+    wdt_t = (torch.randn(48, E, device="cuda") / E ** 0.5).bfloat16()
+    wx_t = (torch.randn(E, 80, device="cuda") / 80 ** 0.5).bfloat16()
+    du = du0.clone()
+    dx = aum_hip.xdt_tm_bwd(ddelta, dbc, wdt_t, wx_t, du, lib=lib)
+    rr = ddelta.float() @ wdt_t.float().t()
+    assert (dx[:, :48].float() - rr).abs().max().item() <= 1.01 * 2.0 ** -8 * rr.abs().max().item()
+    assert torch.equal(dx[:, 48:], dbc.bfloat16())
+    ru = du0.float() + dx.float() @ wx_t.float().t()
+    assert (du.float() - ru).abs().max().item() <= 1.01 * 2.0 ** -8 * ru.abs().max().item()
+    du2 = du0.clone()
+    dx2 = aum_hip.xdt_tm_bwd(ddelta, dbc, wdt_t, wx_t, du2, lib=lib)
+    assert torch.equal(dx, dx2) and torch.equal(du, du2)
 
 
 def test_xdt_tm_headline_shape(lib):

@@ -55,9 +55,19 @@ rows = [
     ("e  du += dx_dbl @ W_x", lambda: du.addmm_(dx_dbl, w_x), M * E * 4),
     ("f  forward: x_dbl, delta = xdt(conv_out)", lambda: aum_hip.xdt_tm_fwd(conv_out, w_x, w_dt), M * E * 4),
 ]
+w_dt_t, w_x_t = w_dt.t().contiguous(), w_x.t().contiguous()
+rows += [
+    ("P  aum_xdt_tm_bwd (a + b + e in one pass)", lambda: aum_hip.xdt_tm_bwd(ddelta, dBC, w_dt_t, w_x_t, du), M * E * 6),
+    ("Qc aum_gemm_wgrad k=48 (c) incl. partial sums", lambda: aum_hip.gemm_wgrad(ddelta, x_dbl[:, :R]), M * E * 2),
+    ("Qd aum_gemm_wgrad k=80 (d) incl. partial sums", lambda: aum_hip.gemm_wgrad(conv_out, dx_dbl), M * E * 2),
+    ("Qc kernel alone (partials kept)", lambda: aum_hip.gemm_wgrad(ddelta, x_dbl[:, :R], partials=True), M * E * 2),
+    ("Qd kernel alone (partials kept)", lambda: aum_hip.gemm_wgrad(conv_out, dx_dbl, partials=True), M * E * 2),
+]
+for sp in (6, 12, 21, 42):
+    rows.append((f"Qd kernel alone, {sp} splits", (lambda sp=sp: aum_hip.gemm_wgrad(conv_out, dx_dbl, splits=sp, partials=True)), M * E * 2))
 tot = 0.0
 for name, fn, nbytes in rows:
     t = timed(fn)
-    tot += t if not name.startswith("f") else 0
+    tot += t if name[0] in "abcde" and name[1] == " " else 0
     print(f"{name:45s} {t:8.1f} us   HBM bound {nbytes / 6.29e6:6.1f} us (6.29 TB/s copy rate)", flush=True)
 print(f"backward pieces a-e together: {tot:.1f} us per layer; HBM bound (ddelta, conv_out once; du read + write): {M * E * 8 / 6.29e6:.1f} us")
