@@ -1299,33 +1299,7 @@ AUM_DEV void wave_sum_mfma_add16(WaveSumAcc& acc, int tile, const WaveSumSel& se
     acc.d[4 * tile + 2] = d[2];
     acc.d[4 * tile + 3] = d[3];
 }
-#ifndef AUM_WSUM_BUILTIN
-#define AUM_WSUM_BUILTIN 0
-#endif
-// lane l <- lane l ^ 4 of its 16-lane row: two bank-masked DPP moves
-AUM_DEV vf wsum_xor4(vf m) {
-    int t = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m), __builtin_bit_cast(int, m), 0x104, 0xf, 0x5, false);       // banks 0, 2 <- lane + 4
-    t = __builtin_amdgcn_update_dpp(t, __builtin_bit_cast(int, m), 0x114, 0xf, 0xa, false);                                    // banks 1, 3 <- lane - 4
-    return __builtin_bit_cast(float, t);
-}
-// one tile's four registers -> lane l: total of value 4 (l >> 4) + bit3 + 2 bit2, every instruction visible to the compiler (the hazard
-// recogniser places the matrix-result and DPP wait states itself)
-AUM_DEV vf wsum_finish_tile(vf r0, vf r1, vf r2, vf r3) {
-    const unsigned lane = threadIdx.x & 63u;
-    const bool b3 = (lane & 8u) != 0, b2 = (lane & 4u) != 0;
-    const vf m = b3 ? r1 + dpp_row_ror<8>(r1) : r0 + dpp_row_ror<8>(r0);
-    const vf z = b3 ? r3 + dpp_row_ror<8>(r3) : r2 + dpp_row_ror<8>(r2);
-    vf v = b2 ? z + wsum_xor4(z) : m + wsum_xor4(m);
-    v = v + dpp_mov<0x4E>(v, v);        // quad_perm [2,3,0,1]
-    v = v + dpp_mov<0xB1>(v, v);        // quad_perm [1,0,3,2]
-    return v;
-}
 AUM_DEV void wave_sum_mfma_finish(WaveSumAcc& acc, bool fresh, vf& s0, vf& s1) {
-#if AUM_WSUM_BUILTIN
-    s0 = wsum_finish_tile(acc.d[0], acc.d[1], acc.d[2], acc.d[3]);
-    s1 = wsum_finish_tile(acc.d[4], acc.d[5], acc.d[6], acc.d[7]);
-    return;
-#endif
     // `fresh`: the tiles may have been written by a matrix instruction within the last 12 issue slots
     if (fresh) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     // levels over lane bits 3 and 2 inside a 16-lane row (masked DPP adds: bank_mask write-enables the lanes whose bit selects the

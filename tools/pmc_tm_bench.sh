@@ -5,7 +5,7 @@
 #   harness tools/tm_time.py -- roofline.traffic in the bench line is then a measurement of the timed kernels themselves
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export PYTHONPATH=$PWD/audio-mamba-aum_amd:$PYTHONPATH
-OUT=gpurun_out/pmc_tmb
+OUT=${AUM_PMC_OUT:-gpurun_out/pmc_tmb}
 rm -rf $OUT; mkdir -p $OUT
 CMD="python tools/tm_time.py default"
 if [ "$1" = "bench" ]; then CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"; export AUM_PMC_SOURCE="python bench.py --steps 2 --warmup 1 (the bench's own launches)"; fi

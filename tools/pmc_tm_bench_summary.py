@@ -13,7 +13,9 @@ out = sys.argv[1]
 NAMES = [("k_scant_bwd<aum::bf16_t, true, true, true>", "scan_tm_bwd_bidir"), ("k_scant_fwd<aum::bf16_t, true, true, true, true>", "scan_tm_fwd_bidir"),
          ("k_scant_bwd<aum::bf16_t, false, true, true>", "scan_tm_bwd_bidir_nosp"), ("k_scant_fwd<aum::bf16_t, false, true, true, true>", "scan_tm_fwd_bidir_nosp"),
          ("k_scant_fwd<aum::bf16_t, false, true, false, true>", "scan_tm_fwd_bidir_inference"),
-         ("k_scant_bwd_reduce", "scan_tm_bwd_reduce"), ("k_convt_fwd<aum::bf16_t", "conv_tm_fwd"), ("k_convt_bwd<aum::bf16_t", "conv_tm_bwd")]
+         ("k_scant_bwd_reduce", "scan_tm_bwd_reduce"), ("k_convt_fwd<aum::bf16_t", "conv_tm_fwd"), ("k_convt_bwd<aum::bf16_t", "conv_tm_bwd"),
+         ("k_xdt_tm_bwd<true", "xdt_tm_bwd"), ("k_xdt_tm_fwd<true", "xdt_tm_fwd"), ("k_gemm_wgrad_skinny<true, 3>", "gemm_wgrad_k48"),
+         ("k_gemm_wgrad_skinny<true, 5>", "gemm_wgrad_k80"), ("k_gemm_wgrad<true>", "gemm_wgrad"), ("k_gemm_tn_persistent<true>", "gemm_tn")]
 stamp = {"_commit": os.environ.get("AUM_COMMIT", "unknown"), "_date": datetime.date.today().isoformat()}
 SRC = os.environ.get("AUM_PMC_SOURCE", "tools/tm_time.py")
 
