@@ -473,7 +473,9 @@ def tm_segments(batch, d_inner, seqlen, bidirectional, training):
 
 def token_major_preferred(batch, d_inner, bidirectional, training=None, seqlen=None):
     training = torch.is_grad_enabled() if training is None else training
-    need = -(-_TM_MIN_WAVES * 4 // 3) if training else _TM_MIN_WAVES
+    # (the 4/3 applies to the Fo-Bi backward -- three direction pairs per workgroup in three stages; a one-direction launch of 1536 waves
+    # trains faster token-major: Fo-Fo AuM-Base at batch 64, 54.7 ms against 60.4 ms channel-major, profiles/r03 / r04_variants_bench.json)
+    need = -(-_TM_MIN_WAVES * 4 // 3) if training and bidirectional else _TM_MIN_WAVES
     if batch * (d_inner // 64) * (2 if bidirectional else 1) >= need:
         return True
     return tm_segments(batch, d_inner, seqlen, bidirectional, training) > 1
@@ -530,7 +532,7 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
         w_x_t, w_dt_t = _cast_t(x_proj_param, conv2d.dtype), _cast_t(delta_proj_param, conv2d.dtype)
     ckpt = aum_hip.scan_tm_ckpt(Bsz, L, E, N, A_b is not None, xz.device, dtype=conv_out.dtype) if need_bwd else None
     waves = Bsz * (E // 64) * (2 if A_b is not None else 1)
-    cut = waves < (-(-_TM_MIN_WAVES * 4 // 3) if need_bwd else _TM_MIN_WAVES)
+    cut = waves < (-(-_TM_MIN_WAVES * 4 // 3) if need_bwd and A_b is not None else _TM_MIN_WAVES)
     out_z, out_pre = aum_hip.scan_tm_fwd(conv_out, delta.view(Bsz, L, E), A, Bm, Cm, D, z, delta_bias, delta_softplus,
                                          reverse if A_b is None else False, A_b=A_b, want_out_pre=need_bwd, ckpt=ckpt,
                                          segments=tm_segments(Bsz, E, L, A_b is not None, False) if cut else 1)

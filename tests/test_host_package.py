@@ -339,6 +339,7 @@ def test_token_major_module_matches_channel_major(monkeypatch):
     assert ssi.tm_segments(64, 1536, 4097, True, True) == 1 and ssi.tm_segments(1, 1536, 513, True, False) == 1
     # AuM-Small at batch 64 is 1536 waves: enough for the forward alone, not when a backward follows
     assert ssi.token_major_preferred(64, 768, True, training=False) and not ssi.token_major_preferred(64, 768, True, training=True)
+    assert ssi.token_major_preferred(64, 1536, False, training=True)          # one direction (Fo-Fo): 1536 waves train token-major
     torch.manual_seed(3)
     for btype in ("v1", "none", "v2"):
         m = Mamba(64, bimamba_type=btype, if_devide_out=btype == "v2")
