@@ -826,6 +826,7 @@ def dtproj_tm_fwd(x_dbl, rank, w, lib=None):
 
 
 XDT_COLS, XDT_MAX_DIM = 80, 1536
+XDT_COLS_FWD = (80, 56)        # x_dbl widths aum_xdt_tm_fwd is built for (AuM-Base, AuM-Small)
 
 
 def xdt_tm_supported(u, wx, wdt):
@@ -835,7 +836,8 @@ def xdt_tm_supported(u, wx, wdt):
         return False
     dim, rank = u.shape[1], wdt.shape[1]
     ok_t = lambda t: t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
-    return (wx.shape == (XDT_COLS, dim) and wdt.shape[0] == dim and dim % 256 == 0 and dim <= XDT_MAX_DIM and rank % 8 == 0 and rank <= 64
+    return (wx.shape[0] in XDT_COLS_FWD and wx.shape[1] == dim and wdt.shape[0] == dim and dim % 256 == 0 and dim <= XDT_MAX_DIM and rank % 8 == 0
+            and rank <= 64 and rank <= wx.shape[0]
             and ok_t(u) and ok_t(wx) and ok_t(wdt))
 
 
@@ -879,12 +881,13 @@ def xdt_tm_fwd(u, wx, wdt, lib=None):
         raise RuntimeError(f"xdt_tm_fwd: unsupported operands {tuple(u.shape)} {u.dtype}, {tuple(wx.shape)}, {tuple(wdt.shape)}")
     ntok, dim = u.shape
     rank = wdt.shape[1]
-    x_dbl = torch.empty((ntok, XDT_COLS), dtype=u.dtype, device=u.device)
+    ncols = wx.shape[0]
+    x_dbl = torch.empty((ntok, ncols), dtype=u.dtype, device=u.device)
     delta = torch.empty((ntok, dim), dtype=u.dtype, device=u.device)
     a = XdtArgs()
     a.u, a.wx, a.wdt, a.x_dbl, a.delta = _ptr(u), _ptr(wx), _ptr(wdt), _ptr(x_dbl), _ptr(delta)
-    a.ntok, a.dim, a.rank, a.ncols = ntok, dim, rank, XDT_COLS
-    a.ldu, a.ldwx, a.ldwdt, a.ldx, a.ldd, a.dtype = u.stride(0), wx.stride(0), wdt.stride(0), XDT_COLS, dim, _DT[u.dtype]
+    a.ntok, a.dim, a.rank, a.ncols = ntok, dim, rank, ncols
+    a.ldu, a.ldwx, a.ldwdt, a.ldx, a.ldd, a.dtype = u.stride(0), wx.stride(0), wdt.stride(0), ncols, dim, _DT[u.dtype]
     _launch(lib.c.aum_xdt_tm_fwd, a, u, lib, "xdt_tm_fwd", (ntok, dim, rank))
     return x_dbl, delta
 

@@ -101,13 +101,17 @@ static int cu_count() {
     return ncu;
 }
 
-template <int NW> static void xdt_launch(const AumXdtArgs& g, hipStream_t s) {
+template <int NW, int NC> static void xdt_launch_nc(const AumXdtArgs& g, hipStream_t s) {
     const dim3 grid((unsigned)((g.ntok + NW * XDT_TOK_W - 1) / (NW * XDT_TOK_W))), block(NW * 64);
     const bool bf = g.dtype == AUM_BF16, one = g.rank <= 32;
-    if (bf && one) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<true, 1, NW>), grid, block, 0, s, g);
-    else if (bf) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<true, 2, NW>), grid, block, 0, s, g);
-    else if (one) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<false, 1, NW>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<false, 2, NW>), grid, block, 0, s, g);
+    if (bf && one) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<true, 1, NW, NC>), grid, block, 0, s, g);
+    else if (bf) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<true, 2, NW, NC>), grid, block, 0, s, g);
+    else if (one) hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<false, 1, NW, NC>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((aumx::k_xdt_tm_fwd<false, 2, NW, NC>), grid, block, 0, s, g);
+}
+template <int NW> static void xdt_launch(const AumXdtArgs& g, hipStream_t s) {
+    if (g.ncols == XDT_COLS) xdt_launch_nc<NW, XDT_COLS>(g, s);
+    else xdt_launch_nc<NW, XDT_COLS_SMALL>(g, s);
 }
 
 extern "C" int aum_xdt_tm_fwd(const AumXdtArgs* p, void* stream) {

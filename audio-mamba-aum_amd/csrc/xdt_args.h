@@ -5,7 +5,8 @@
 
 #include "../../include/aum_hip.h"
 
-#define XDT_COLS 80          // columns of x_dbl = dt_rank + 2 d_state the kernel is built for (AuM-Base: 48 + 32)
+#define XDT_COLS 80          // columns of x_dbl = dt_rank + 2 d_state the kernels are built for (AuM-Base: 48 + 32)
+#define XDT_COLS_SMALL 56    // ... and the forward kernel also for AuM-Small's 24 + 32
 #ifndef XDT_TOK_W
 #define XDT_TOK_W 16         // tokens per wave
 #endif
@@ -21,7 +22,7 @@ inline int xdt_check(const AumXdtArgs* p) {
         g.ldd < g.dim)
         return AUM_E_SHAPE;
     if (g.dtype != AUM_BF16 && g.dtype != AUM_F16) return AUM_E_DTYPE;
-    if (g.ncols != XDT_COLS || g.rank % 8 || g.rank > 64 || g.rank > g.ncols || g.dim % 256 || g.dim > XDT_MAX_DIM) return AUM_E_UNSUPPORTED;
+    if ((g.ncols != XDT_COLS && g.ncols != XDT_COLS_SMALL) || g.rank % 8 || g.rank > 64 || g.rank > g.ncols || g.dim % 256 || g.dim > XDT_MAX_DIM) return AUM_E_UNSUPPORTED;
     if (g.ldu % 8 || g.ldwx % 8 || g.ldwdt % 8 || g.ldx % 8 || g.ldd % 8) return AUM_E_UNSUPPORTED;
     if (((uintptr_t)g.u | (uintptr_t)g.wx | (uintptr_t)g.wdt | (uintptr_t)g.x_dbl | (uintptr_t)g.delta) & 15u) return AUM_E_UNSUPPORTED;
     return AUM_OK;

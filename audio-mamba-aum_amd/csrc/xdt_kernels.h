@@ -89,8 +89,14 @@ __device__ __forceinline__ void stage_rows(char* dst, int dst_pitch, const char*
 
 // NW waves of 16 tokens per workgroup, one workgroup per CU.  The token count decides NW (xdt_waves): 64 x 513 tokens are 2052 fragments of
 // 16 -- 8 waves make 257 workgroups, a second round for ONE workgroup on 256 CUs (97 us, cold caches); 9 waves make 228 of them (one round).
-template <bool BF16, int KS, int NW>
+// NC = columns of x_dbl: 80 (AuM-Base: dt_rank 48 + 2 x 16) or 56 (AuM-Small: 24 + 32).  56 is three and a half column fragments: the
+// fourth fragment multiplies eight weight rows that do not exist (whatever the slab holds behind row 55) -- their products are columns 56..63
+// of the wave's tile, inside the row's padding, which nothing reads.
+template <bool BF16, int KS, int NW, int NC>
 __global__ __launch_bounds__(NW * 64, 1) void k_xdt_tm_fwd(AumXdtArgs g) {
+    constexpr int NCF = (NC + 15) / 16;
+    constexpr int XP = NC == 80 ? 176 : 144;             // bytes per tile row: an odd number of 16-byte chunks (conflict-free fragment reads)
+    static_assert(NC % 8 == 0 && NCF * 32 <= XP && XP <= aumx::XP, "tile row holds every fragment column");
     __shared__ __attribute__((aligned(16))) char lds[lds_bytes(XDT_MAX_DIM, NW)];       // 143 KB at 8 waves: one workgroup per CU
     const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int rho = lane & 15, kg = lane >> 4;
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_xdt_tm_fwd(AumXdtArgs g) {
             const int s = s0 + j;
             if (s == 0 || s == nsteps) {                      // a K-half of W_x through LDS
                 __syncthreads();                              // everybody is done with the previous contents of the slab
-                stage_rows<NW * 64>(slab, SP, static_cast<const char*>(g.wx) + (int64_t)(s / nsteps) * KH * 2, (int64_t)g.ldwx * 2, XDT_COLS, KH / 8, tid);
+                stage_rows<NW * 64>(slab, SP, static_cast<const char*>(g.wx) + (int64_t)(s / nsteps) * KH * 2, (int64_t)g.ldwx * 2, NC, KH / 8, tid);
                 __syncthreads();
             }
             const int sl = s >= nsteps ? s - nsteps : s;
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_xdt_tm_fwd(AumXdtArgs g) {
     __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0): the wave's own LDS writes have landed (nobody else reads this tile)
     {
         char* xo = static_cast<char*>(g.x_dbl);
-        constexpr int PIECES = XDT_COLS * 2 / 16;                    // 10 per token row
+        constexpr int PIECES = NC * 2 / 16;                          // 10 / 7 per token row
         for (int idx = lane; idx < XDT_TOK_W * PIECES; idx += 64) {
             const int tk = idx / PIECES, pc = idx - tk * PIECES;
             if (t0 + tk < g.ntok)

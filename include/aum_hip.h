@@ -476,7 +476,7 @@ int aum_dtproj_tm_fwd(const AumDtProjArgs* args, void* stream);
  * transposes): x_dbl = u . x_proj.weight^T, delta = x_dbl[:, :rank] . dt_proj.weight^T (bias and softplus stay in the scan).
  *   u: (ntok, dim) rows of pitch ldu (conv_out);  wx: (ncols, dim) pitch ldwx;  wdt: (dim, rank) pitch ldwdt;
  *   x_dbl (out): (ntok, ncols) pitch ldx;  delta (out): (ntok, dim) pitch ldd.  Pitches in ELEMENTS, all tensors `dtype` (AUM_BF16 / AUM_F16).
- *   Built for ncols == 80 (dt_rank + 2 d_state of AuM-Base), dim % 256 == 0, dim <= 1536, rank % 8 == 0, rank <= 64, pitches % 8 == 0,
+ *   Built for ncols == 80 or 56 (dt_rank + 2 d_state of AuM-Base / AuM-Small), dim % 256 == 0, dim <= 1536, rank % 8 == 0, rank <= 64, pitches % 8 == 0,
  *   16-byte aligned pointers; anything else AUM_E_UNSUPPORTED (callers use a GEMM for x_dbl and aum_dtproj_tm_fwd).  delta is computed from
  *   the ROUNDED x_dbl, as the two separate products do.
  */

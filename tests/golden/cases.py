@@ -345,4 +345,6 @@ DTPROJ_CASES = [(1, 64, 8, 40), (33, 96, 24, 56), (129, 256, 48, 80), (513, 1536
 # aum_xdt_tm_fwd (ABI 9): (ntok, dim, dt_rank) -- ragged token tiles (128 per workgroup, 32 per wave), one and two dt K-steps, every dim class
 # (ntok, dim, pad columns behind the ddelta / du rows): aum_xdt_tm_bwd; 2052 and 2305 tokens: 9 waves per workgroup on 256 CUs, ragged last workgroup
 XDT_BWD_CASES = [(1, 256, 0), (33, 256, 8), (127, 512, 0), (145, 768, 16), (513, 1536, 0), (300, 1024, 8), (2305, 1536, 0)]
-XDT_CASES = [(1, 256, 8), (33, 256, 24), (127, 512, 48), (129, 768, 32), (513, 1536, 48), (300, 1024, 64)]
+XDT_CASES = [(1, 256, 8), (33, 256, 24), (127, 512, 48), (129, 768, 32), (513, 1536, 48), (300, 1024, 64),
+             # 56-column x_dbl rows (AuM-Small: dt rank 24 + 2 x 16): (ntok, dim, rank, ncols)
+             (1, 256, 24, 56), (145, 768, 24, 56), (2305, 768, 24, 56), (300, 512, 16, 56)]

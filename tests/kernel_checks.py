@@ -607,18 +607,18 @@ def check_xdt_bwd(lib, dev, ntok, dim, dtype, pad=0):
     assert torch.equal(duf[:, dim:], tail_in), "columns behind the du rows were written"
 
 
-def check_xdt(lib, dev, ntok, dim, rank, dtype):
+def check_xdt(lib, dev, ntok, dim, rank, dtype, ncols=80):
     """aum_xdt_tm_fwd (ABI 9; SSI:467-468): x_dbl against an fp64 product of the 16-bit operands (one rounding), delta against an fp64
-    product of the kernel's OWN rounded x_dbl (what two separate GEMMs compute)"""
-    g = torch.Generator().manual_seed(ntok * 7 + dim + rank)
+    product of the kernel's OWN rounded x_dbl (what two separate GEMMs compute).  ncols: 80 (AuM-Base rows) or 56 (AuM-Small)."""
+    g = torch.Generator().manual_seed(ntok * 7 + dim + rank + ncols)
     u = torch.randn(ntok, dim, generator=g).to(dtype).to(dev)
-    wx = (torch.randn(80, dim, generator=g) / dim ** 0.5).to(dtype).to(dev)
+    wx = (torch.randn(ncols, dim, generator=g) / dim ** 0.5).to(dtype).to(dev)
     wdt = (torch.randn(dim, rank, generator=g) / rank ** 0.5).to(dtype).to(dev)
     x_dbl, delta = aum_hip.xdt_tm_fwd(u, wx, wdt, lib=lib)
     ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     ref_x = u.double().cpu() @ wx.double().cpu().t()
     ex = (x_dbl.double().cpu() - ref_x).abs().max().item()
-    assert x_dbl.shape == (ntok, 80) and ex <= 1.01 * ulp * ref_x.abs().max().item(), ("x_dbl", ntok, dim, rank, ex)
+    assert x_dbl.shape == (ntok, ncols) and ex <= 1.01 * ulp * ref_x.abs().max().item(), ("x_dbl", ntok, dim, rank, ex)
     ref_d = x_dbl[:, :rank].double().cpu() @ wdt.double().cpu().t()
     ed = (delta.double().cpu() - ref_d).abs().max().item()
     assert delta.shape == (ntok, dim) and ed <= 1.01 * ulp * ref_d.abs().max().item(), ("delta", ntok, dim, rank, ed)

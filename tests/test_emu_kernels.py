@@ -269,6 +269,7 @@ def test_dtproj_tm_contract(emu, case):
 def test_xdt_tm_contract(emu):
     """the host build's aum_xdt_tm_fwd (plain loops behind the shared argument rules): x_dbl rounded once, delta from the rounded x_dbl"""
     KC.check_xdt(emu, "cpu", 33, 256, 24, torch.bfloat16)
+    KC.check_xdt(emu, "cpu", 33, 256, 24, torch.bfloat16, 56)
 
 
 def test_xdt_tm_bwd_contract(emu):

@@ -425,9 +425,9 @@ def test_scan_tm_longform_grid_b8(lib):
 
 def test_scan_tm_small_inference_grid_b64(lib):
     """BASELINE config 2 at its bench batch on the dispatch the bench takes: AuM-Small, B = 64, E = 768, bf16,
-    forward only -- token-major, 56-column x_dbl rows (dt rank 24 | B | C), which xdt_tm_supported refuses, so delta comes from
-    aum_dtproj_tm_fwd and the scan runs without out_pre / checkpoints.  dt projection vs an fp64 product at that shape; sampled rows
-    of the Fo-Bi scan output vs the fp64 oracle."""
+    forward only -- token-major, 56-column x_dbl rows (dt rank 24 | B | C): x_dbl and delta from the fused aum_xdt_tm_fwd (round 4: its
+    56-column form; before, a library GEMM + aum_dtproj_tm_fwd, still checked here), the scan without out_pre / checkpoints.  Both
+    projection paths vs fp64 products at that shape; sampled rows of the Fo-Bi scan output vs the fp64 oracle."""
     O = KC.O
     torch.manual_seed(6)
     Bsz, L, E, N, R = 64, 513, 768, 16, 24
@@ -438,7 +438,13 @@ def test_scan_tm_small_inference_grid_b64(lib):
     x_dbl = bf(torch.randn(Bsz, L, R + 2 * N, device=dev))
     w_dt = bf(torch.randn(E, R, device=dev) / R ** 0.5 * 0.5)
     w_x = bf(torch.randn(R + 2 * N, E, device=dev) / E ** 0.5)
-    assert not aum_hip.xdt_tm_supported(u.reshape(-1, E), w_x, w_dt), "the fused x/dt kernel is not expected to take AuM-Small's shape"
+    u2 = u.reshape(-1, E)
+    assert aum_hip.xdt_tm_supported(u2, w_x, w_dt), "the fused x/dt kernel takes AuM-Small's 56-column rows"
+    xf, df = aum_hip.xdt_tm_fwd(u2, w_x, w_dt, lib=lib)
+    rx = u2.double() @ w_x.double().t()
+    assert xf.shape == (Bsz * L, R + 2 * N) and (xf.double() - rx).abs().max().item() <= 1.01 * 2.0 ** -8 * rx.abs().max().item()
+    rd = xf[:, :R].double() @ w_dt.double().t()
+    assert (df.double() - rd).abs().max().item() <= 1.01 * 2.0 ** -8 * rd.abs().max().item()
     x2 = x_dbl.reshape(-1, R + 2 * N)
     assert aum_hip.dtproj_tm_supported(x2, R, w_dt)
     dl = aum_hip.dtproj_tm_fwd(x2, R, w_dt, lib=lib).reshape(Bsz, L, E)
@@ -611,7 +617,7 @@ def test_gemm_tn_random_shapes(lib):
 @pytest.mark.parametrize("case", cases.XDT_CASES, ids=lambda c: "x".join(map(str, c)))
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_xdt_tm(lib, case, dtype):
-    KC.check_xdt(lib, "cuda", *case, dtype)
+    KC.check_xdt(lib, "cuda", *case[:3], dtype, *case[3:])
 
 
 @pytest.mark.parametrize("case", cases.XDT_BWD_CASES, ids=lambda c: "x".join(map(str, c)))
