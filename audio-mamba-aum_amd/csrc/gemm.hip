@@ -6,6 +6,20 @@
 #include "xdt_kernels.h"
 #include "decode_kernels.h"
 
+// CU count of the CURRENT device (one process may drive several devices from several threads): a small per-device cache, filled with
+// relaxed atomics -- racing fillers write the same value
+static int cu_count() {
+    static std::atomic<int> ncu_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int ncu = ncu_of[dev].load(std::memory_order_relaxed);
+    if (!ncu) {
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) return 0;
+        ncu_of[dev].store(ncu, std::memory_order_relaxed);
+    }
+    return ncu;
+}
+
 extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
     const int rc = aumg::gemm_check(p);
     if (rc != AUM_OK) return rc;
@@ -51,6 +65,54 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
     return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
 }
 
+// split-tail geometry for (m, n) on `ncu` CUs: grid (a multiple of 8 workgroups), complete rounds, tail tiles; applies when the tail is
+// at least half a round (every tile then has at most SK_SLOTS + 1 contributors)
+static bool sk_geometry(int64_t m, int n, int ncu, int* grid, int* rounds, int* tail) {
+    if (m <= 0 || n <= 0 || n % aumg::BN) return false;
+    const int g8 = ncu / 8 * 8;
+    if (g8 < 8) return false;
+    const int64_t tiles = (m + aumg::BM - 1) / aumg::BM * (n / aumg::BN);
+    *grid = g8;
+    *rounds = (int)(tiles / g8);
+    *tail = (int)(tiles - (int64_t)*rounds * g8);
+    return *tail * 2 >= g8 && *tail < g8;
+}
+static int64_t sk_flag_bytes(int tail) { return ((int64_t)(tail * aumg::SK_SLOTS + 1) * 4 + 255) / 256 * 256; }
+
+extern "C" int64_t aum_gemm_tn_sk_workspace_bytes(int64_t m, int32_t n) {
+    const int ncu = cu_count();
+    int grid, rounds, tail;
+    if (ncu <= 0 || !sk_geometry(m, n, ncu, &grid, &rounds, &tail)) return 0;
+    return sk_flag_bytes(tail) + (int64_t)tail * aumg::SK_SLOTS * aumg::BM * aumg::BN * 4;
+}
+
+extern "C" int aum_gemm_tn_sk(const AumGemmSkArgs* p, void* stream) {
+    if (!p) return AUM_E_NULL;
+    const int rc = aumg::gemm_check(&p->base);
+    if (rc != AUM_OK) return rc;
+    if (!p->workspace || !p->epoch) return AUM_E_NULL;
+    const AumGemmArgs& g = p->base;
+    const int ncu = cu_count();
+    int grid, rounds, tail;
+    if (ncu <= 0) return AUM_E_LAUNCH;
+    if (!sk_geometry(g.m, g.n, ncu, &grid, &rounds, &tail)) return AUM_E_UNSUPPORTED;
+    const int64_t fb = sk_flag_bytes(tail);
+    if (((uintptr_t)p->workspace & 255u) || p->workspace_bytes < fb + (int64_t)tail * aumg::SK_SLOTS * aumg::BM * aumg::BN * 4) return AUM_E_WORKSPACE;
+    aumg::GemmSkLaunch L;
+    L.g = g;
+    L.err = static_cast<uint32_t*>(p->workspace);                  // word 0: set when a bounded wait ran out; flags behind it
+    L.flags = L.err + 1;
+    L.part = reinterpret_cast<float*>(static_cast<char*>(p->workspace) + fb);
+    L.epoch = p->epoch;
+    L.rounds = rounds;
+    L.tail = tail;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    if (g.dtype == AUM_BF16) hipLaunchKernelGGL(aumg::k_gemm_tn_sk<true>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
+    else hipLaunchKernelGGL(aumg::k_gemm_tn_sk<false>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
+    return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
+}
+
 extern "C" int aum_gemm_wgrad(const AumGemmWArgs* p, void* stream) {
     const int rc = aumg::gemm_wgrad_check(p);
     if (rc != AUM_OK) return rc;
@@ -87,19 +149,6 @@ extern "C" int aum_dtproj_tm_fwd(const AumDtProjArgs* p, void* stream) {
     return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
 }
 
-// CU count of the CURRENT device (one process may drive several devices from several threads): a small per-device cache, filled with
-// relaxed atomics -- racing fillers write the same value
-static int cu_count() {
-    static std::atomic<int> ncu_of[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    int ncu = ncu_of[dev].load(std::memory_order_relaxed);
-    if (!ncu) {
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) return 0;
-        ncu_of[dev].store(ncu, std::memory_order_relaxed);
-    }
-    return ncu;
-}
 
 template <int NW, int NC> static void xdt_launch_nc(const AumXdtArgs& g, hipStream_t s) {
     const dim3 grid((unsigned)((g.ntok + NW * XDT_TOK_W - 1) / (NW * XDT_TOK_W))), block(NW * 64);

@@ -393,6 +393,180 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_persistent(GemmLaunch L)
 
 
 // ------------------------------------------------------------------------------------------------------------------------------------
+// Split tail (round 4; aum_gemm_tn_sk).  N = 768 at 64 x 513 tokens is 387 tiles on 256 CUs: a second round in which half of the CUs idle
+// (75 % of the chip over the launch), and the reason the two N = 768 GEMMs stayed with the library.  Here the complete rounds run as whole
+// tiles (one workgroup per CU, tile = blockIdx + round * grid) and the remaining `tail` tiles are split ALONG K between the workgroups:
+// the tail's K-steps (tail tiles x K / 64) are dealt out in equal contiguous ranges -- XCD x takes tiles [x T / 8, (x + 1) T / 8), its 32
+// workgroups equal shares of their K-steps -- so a workgroup computes the end of one tile and the beginning of the next.  The workgroup that
+// holds a tile's FIRST K-step finishes the tile: every workgroup walks its range upwards, so that part is the last thing it computes, while
+// the other contributors (one or two: ranges are at least a third of a tile) computed theirs first, wrote fp32 partial tiles to the workspace
+// (write-through stores: visible to every XCD) and raised a flag.  The finisher adds the partials to its accumulators and stores the tile.
+// Flags carry the launch's epoch (the host counts launches per workspace): nothing is cleared between launches.  No workgroup waits for
+// one that waits (contributors never wait), every workgroup is resident (grid <= CUs, one per CU), the wait is bounded all the same.
+// MEASURED (profiles/r04_gemm_split_tail.txt), parity-green and NOT faster: N = 768, K = 1536 / 3072: 113 / 187 us against 87 / 160 us for
+// whole tiles.  Ablations: the complete round alone 50 / 104 us; + the finishers' half tiles and their stores 88 / 152 us; + the hand-over
+// 113 / 187 us -- writing 256 KB per contributor, the flag, and reading it back is a serial chain of ~25 us behind half a tile's MFMAs, more
+// than the idle half round it replaces.  Kept as an opt-in entry point (aum_gemm_tn_sk) with its tests; the default stays whole tiles.
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int SK_SLOTS = 2;
+#ifndef AUM_SK_ABL
+#define AUM_SK_ABL 0        // timing experiments only (wrong results): 1 no partial exchange, 2 no tail at all, 3 no stores of finished tail tiles either
+#endif
+#ifndef AUM_SK_AUX
+#define AUM_SK_AUX 16       // cache policy of the partial-tile exchange: 16 = sc1 (agent scope: through the L2 to the memory side), 17 = system scope, 0 = plain
+#endif
+struct GemmSkLaunch {
+    AumGemmArgs g;
+    float* part;           // [tail][SK_SLOTS][BM * BN] fp32
+    uint32_t* flags;       // [tail][SK_SLOTS]
+    uint32_t* err;         // set to 1 when a wait ran out (the result is then incomplete)
+    uint32_t epoch;
+    int rounds;            // complete rounds of whole tiles: tiles [0, rounds * grid)
+    int tail;              // tiles after them
+};
+
+template <bool BF16>
+__global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_sk(GemmSkLaunch L) {
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const AumGemmArgs& g = L.g;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = w >> 2, wc = w & 3;
+    const int ntn = g.n / BN, grid = (int)gridDim.x, nk = g.k / BK;
+    const int srow = w * 8 + (lane >> 3);
+    const int f_a = ((w & 1) * 4 + (lane >> 4)) & 7;
+    const int f_b = ((w & 3) << 1) | ((lane >> 4) & 1);
+    const int voff_a = srow * g.lda * 2 + (((lane & 7) ^ f_a) << 4);
+    const int voff_b = srow * g.ldb * 2 + (((lane & 7) ^ f_b) << 4);
+    const int rowstep_a = 64 * g.lda * 2, rowstep_b = 64 * g.ldb * 2;
+    const int rho = lane & 15, kg = lane >> 4;
+    const int a_rd = (wr * 128 + rho) * 128 + ((kg ^ ((lane >> 1) & 7)) << 4);
+    const int b_row = wc * 64 + (rho >> 2) * 8 + (rho & 3);
+    const int b_rd = TILE_BYTES + b_row * 128 + ((kg ^ ((((rho >> 2) & 3) << 1) | ((rho >> 1) & 1))) << 4);
+    int par = 0;
+
+    f4v acc[8][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+    };
+    // K-steps [k0, k1) of tile `tile` into acc
+    auto run = [&](int tile, int k0, int k1) {
+        const int tm = tile / ntn, m0 = tm * BM, n0 = (tile - tm * ntn) * BN;
+        const int rows = g.m - m0 < BM ? g.m - m0 : BM;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(g.a) + (int64_t)m0 * g.lda * 2), 0,
+                                                                            rows * g.lda * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(g.b) + (int64_t)n0 * g.ldb * 2), 0,
+                                                                            BN * g.ldb * 2, 0x00020000);
+        // (the buffer written here was last read two steps ago: every wave has passed the barrier of the step in between)
+        stage(ra, rb, voff_a, voff_b, k0 * (BK * 2), rowstep_a, rowstep_b, lds + (par & 1) * STAGE_BYTES, w);
+        for (int t = k0; t < k1; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < k1) stage(ra, rb, voff_a, voff_b, (t + 1) * (BK * 2), rowstep_a, rowstep_b, lds + ((par + 1) & 1) * STAGE_BYTES, w);
+            const char* st = lds + (par & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                s8v bf[4], af[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = lds_frag(st, (b_rd ^ (kk * 64)) + b_joff(j));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af[i] = lds_frag(st, (a_rd ^ (kk * 64)) + i * 2048);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(bf[j], af[i], acc[i][j]);
+            }
+            par ^= 1;
+        }
+    };
+    auto store_tile = [&](int tile) {
+        const int tm = tile / ntn, m0 = tm * BM, n0 = (tile - tm * ntn) * BN;
+        const int rows = g.m - m0 < BM ? g.m - m0 : BM;
+        char* c_rows = static_cast<char*>(g.c) + ((int64_t)m0 * g.ldc + n0 + wc * 64 + kg * 8) * 2;
+        gemm_store<BF16, 8>(acc, c_rows, (int64_t)g.ldc * 2, wr * 128 + rho, rows);
+    };
+    // this lane's piece of an fp32 partial tile: row wr * 128 + 16 i + rho, columns wc * 64 + 32 (j >> 1) + 8 kg + 4 (j & 1) .. + 3
+    const int p_lane = ((wr * 128 + rho) * BN + wc * 64 + kg * 8) * 4;
+    auto part_rsrc = [&](int tt, int slot) {
+        return __builtin_amdgcn_make_buffer_rsrc(L.part + ((int64_t)tt * SK_SLOTS + slot) * (BM * BN), 0, BM * BN * 4, 0x00020000);
+    };
+
+    // ---- complete rounds: whole tiles; the 32 workgroups of an XCD take 32 consecutive tiles of a round (A rows shared in its L2) ----
+    for (int r = 0; r < L.rounds; ++r) {
+        const int tile = r * grid + ((int)blockIdx.x & 7) * (grid >> 3) + ((int)blockIdx.x >> 3);
+        zero_acc();
+        run(tile, 0, nk);
+        store_tile(tile);
+    }
+    if (L.tail <= 0 || AUM_SK_ABL == 2) return;
+    // ---- the tail, split along K ------------------------------------------------------------------------------------------------
+    const int x = (int)blockIdx.x & 7, c = (int)blockIdx.x >> 3, cpx = grid >> 3;
+    const int tx0 = x * L.tail / 8, tx1 = (x + 1) * L.tail / 8;
+    const int S = (tx1 - tx0) * nk;                     // K-steps of this XCD's tail tiles
+    const int q = (S + cpx - 1) / cpx;                  // per workgroup
+    int pos = c * q;
+    const int end = pos + q < S ? pos + q : S;
+    const int tile0 = L.rounds * grid;
+    while (pos < end) {
+        const int tl = pos / nk, k0 = pos - tl * nk;
+        const int k1 = k0 + (end - pos) < nk ? k0 + (end - pos) : nk;
+        const int tt = tx0 + tl, tile = tile0 + tt;
+        zero_acc();
+        run(tile, k0, k1);
+        if (k0 == 0) {
+            // finisher: the other contributors are the workgroups c + 1 .. c_last of this XCD
+            const int c_last = ((tl + 1) * nk - 1) / q;
+            const int ncontrib = c_last - c < SK_SLOTS ? c_last - c : SK_SLOTS;
+            for (int sl = 0; sl < (AUM_SK_ABL ? 0 : ncontrib); ++sl) {
+                if (threadIdx.x == 0) {
+                    const uint32_t* f = L.flags + (int64_t)tt * SK_SLOTS + sl;
+                    int it = 0;
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != L.epoch) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++it > (1 << 22)) {          // seconds: something is wrong -- report it instead of hanging the queue
+                            __hip_atomic_store(L.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_barrier();
+                const __amdgpu_buffer_rsrc_t rp = part_rsrc(tt, sl);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const u4v v = __builtin_amdgcn_raw_buffer_load_b128(rp, p_lane + (i * 16 * BN + (j >> 1) * 32 + (j & 1) * 4) * 4, 0, AUM_SK_AUX);
+                        acc[i][j] = acc[i][j] + __builtin_bit_cast(f4v, v);
+                    }
+            }
+            if (AUM_SK_ABL != 3) store_tile(tile);
+        } else {
+            // contributor: slot = position among the workgroups behind the finisher
+            const int c_first = (tl * nk) / q;
+            const int sl = c - c_first - 1;
+            if (AUM_SK_ABL) {
+            } else if (sl >= 0 && sl < SK_SLOTS) {
+                const __amdgpu_buffer_rsrc_t rp = part_rsrc(tt, sl);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, acc[i][j]), rp, p_lane + (i * 16 * BN + (j >> 1) * 32 + (j & 1) * 4) * 4, 0, AUM_SK_AUX);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (threadIdx.x == 0) __hip_atomic_store(L.flags + (int64_t)tt * SK_SLOTS + sl, L.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (threadIdx.x == 0) {
+                __hip_atomic_store(L.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // more contributors than slots: the host's split rule was violated
+            }
+        }
+        pos += k1 - k0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
 // Weight-gradient GEMM (round 4; ABI 10, aum_gemm_wgrad):   C[n][k] = sum over tokens t of Y[t][n] * X[t][k]
 // -- dW_in = dxz^T . hidden (autograd of MS:185-189), dW_out = dout^T . out_z (SSI:563).  Both operands are token-major, i.e. the
 // contraction index is the ROW index of both stored matrices: the MFMA wants 8 consecutive t per lane, memory has them a row pitch apart.

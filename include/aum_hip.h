@@ -434,6 +434,28 @@ typedef struct AumGemmArgs {
 int aum_gemm_tn(const AumGemmArgs* args, void* stream);
 
 /*
+ * aum_gemm_tn with a SPLIT TAIL (ABI 10): the same product for shapes whose tile count leaves a half-empty last round of workgroups
+ * (n = 768 at 64 x 513 tokens: 387 tiles of 256 x 256 on 256 CUs).  Complete rounds run as whole tiles; the remaining tiles are split along
+ * K between the workgroups, partial tiles are exchanged through `workspace` and summed by the workgroup that owns a tile's first K-step
+ * (fp32; the order of the at most three partial sums of a tile is fixed by the split, so results are bitwise repeatable for a given
+ * device).  workspace: aum_gemm_tn_sk_workspace_bytes(m, n) bytes, ZERO-FILLED once by the caller and then reused; epoch: a number the
+ * caller increases with every launch that uses the workspace (never 0).  Launches sharing a workspace must be ordered (one stream).
+ * aum_gemm_tn_sk_workspace_bytes returns 0 where the split does not apply (no tail, a tail under half a round, n / k outside aum_gemm_tn's
+ * limits): callers use aum_gemm_tn there.  Error AUM_E_WORKSPACE: workspace too small or not 256-byte aligned.  Word 0 of the workspace
+ * becomes nonzero if a workgroup's (bounded) wait for a partial tile ran out -- the result is then incomplete; it never happens when all
+ * workgroups of the launch are resident, which the launch geometry guarantees on an otherwise idle device.
+ */
+typedef struct AumGemmSkArgs {
+    AumGemmArgs base;
+    void* workspace;
+    int64_t workspace_bytes;
+    uint32_t epoch;
+    uint32_t reserved;
+} AumGemmSkArgs;
+int aum_gemm_tn_sk(const AumGemmSkArgs* args, void* stream);
+int64_t aum_gemm_tn_sk_workspace_bytes(int64_t m, int32_t n);
+
+/*
  * Weight-gradient GEMM of the in / out projections on token-major operands (ABI 10; autograd of mamba_simple.py:185-189 and
  * selective_scan_interface.py:563: d W = d out^T . input):
  *   part[s][n][k] = sum over the tokens t of split s of  y[t][n] * x[t][k]          s = 0 .. splits - 1

@@ -62,6 +62,7 @@ def test_struct_layouts_match_header(tmp_path):
         "AumXdtBwdArgs": (aum_hip.XdtBwdArgs, ["ddelta", "dbc", "wdt_t", "wx_t", "du", "dx_dbl", "ntok", "dim", "rank", "ncols", "ldd", "lddbc", "ldwdt", "ldwx",
                                                "ldu", "ldx", "dtype"]),
         "AumGemmArgs": (aum_hip.GemmArgs, ["a", "b", "c", "m", "n", "k", "lda", "ldb", "ldc", "dtype", "flags"]),
+        "AumGemmSkArgs": (aum_hip.GemmSkArgs, ["base", "workspace", "workspace_bytes", "epoch"]),
         "AumGemmWArgs": (aum_hip.GemmWArgs, ["y", "x", "part", "t", "ldy", "ldx", "n", "k", "splits", "dtype"]),
         "AumScanTmSegFwdArgs": (aum_hip.ScanTmSegFwdArgs, ["base", "carry", "carry_bytes", "segments"]),
         "AumScanTmSegBwdArgs": (aum_hip.ScanTmSegBwdArgs, ["base", "segments"]),

@@ -504,6 +504,37 @@ def test_gemm_tn(lib, case, dtype, sched):
     KC.check_gemm(lib, "cuda", case, dtype, flags={"auto": 0, "persistent": aum_hip.GEMM_PERSISTENT, "lockstep": aum_hip.GEMM_LOCKSTEP, "staggered": aum_hip.GEMM_STAGGERED}[sched])
 
 
+@pytest.mark.parametrize("shape", [(64 * 513, 768, 1536), (64 * 513, 768, 3072), (50000, 512, 192), (33000, 768, 64)], ids=lambda c: "x".join(map(str, c)))
+def test_gemm_tn_split_tail(lib, shape):
+    """aum_gemm_tn_sk: the complete rounds as whole tiles, the tail tiles split along K between the workgroups (partial tiles through
+    the workspace, flags by launch epoch): every row of the result against fp64 (one 16-bit rounding of an fp32 sum), bitwise repeatable
+    over launches that reuse the workspace, nothing written outside the result, the bounded wait never ran out.  The two N = 768 GEMMs
+    of the bench (out_proj forward, in_proj data gradient), a two-column-tile shape, and a single K-step (every tail tile whole)."""
+    m, n, k = shape
+    if not int(lib.c.aum_gemm_tn_sk_workspace_bytes(m, n)):
+        pytest.skip("the split tail does not apply to this shape on this device")
+    torch.manual_seed(m + n + k)
+    a = torch.randn(m, k, device="cuda").bfloat16()
+    b = (torch.randn(n, k, device="cuda") / k ** 0.5).bfloat16()
+    buf = torch.full((m + 7, n + 16), 3.0, device="cuda", dtype=torch.bfloat16)
+    out = buf[:m, 8:8 + n]
+    aum_hip.gemm_tn(a, b, out=out, lib=lib, split_tail=True)
+    assert aum_hip.gemm_tn_sk_error("cuda:0", lib=lib) == 0
+    assert bool((buf[m:] == 3.0).all()) and bool((buf[:, :8] == 3.0).all()) and bool((buf[:, 8 + n:] == 3.0).all())
+    ref = a.float() @ b.float().t()                       # fp32 product of the same operands: the comparison below allows its rounding too
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 1.5 * 2.0 ** -8 * ref.abs().max().item(), err
+    rows = torch.cat([torch.arange(0, 300, device="cuda"), torch.randint(0, m, (300,), device="cuda"), torch.arange(m - 300, m, device="cuda")])
+    ref64 = a[rows].double() @ b.double().t()
+    assert (out[rows].double() - ref64).abs().max().item() <= 1.01 * 2.0 ** -8 * ref64.abs().max().item()
+    first = out.clone()
+    for _ in range(3):
+        aum_hip.gemm_tn(a, b, out=out, lib=lib, split_tail=True)
+        assert torch.equal(out, first)
+    plain = aum_hip.gemm_tn(a, b, lib=lib, split_tail=False)
+    assert (plain.float() - first.float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()      # same sums, re-associated where a tile was split
+
+
 @pytest.mark.parametrize("case", cases.GEMM_WGRAD_CASES, ids=lambda c: "x".join(map(str, c)))
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gemm_wgrad(lib, case, dtype):
@@ -551,8 +582,9 @@ def test_gemm_tn_full_size(lib, shape):
     assert (out[rows].double() - ref).abs().max().item() <= 1.01 * 2.0 ** -8 * ref.abs().max().item()
     for _ in range(3):
         assert torch.equal(out, aum_hip.gemm_tn(a, b, lib=lib))
+    whole = aum_hip.gemm_tn(a, b, lib=lib, split_tail=False)         # (N = 768: the default splits the tail tiles along K -- test_gemm_tn_split_tail)
     for fl in (aum_hip.GEMM_LOCKSTEP, aum_hip.GEMM_STAGGERED, aum_hip.GEMM_PERSISTENT):                               # every schedule: the same sums in the same order
-        assert torch.equal(out, aum_hip.gemm_tn(a, b, lib=lib, flags=fl))
+        assert torch.equal(whole, aum_hip.gemm_tn(a, b, lib=lib, flags=fl))
 
 
 def test_norm_headline_shape(lib):
