@@ -39,9 +39,10 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
     (void)hipGetLastError();        // a stale error of an earlier, unrelated launch must not be reported as this one's
     // Which kernel: the persistent one pays off when a CU gets several tiles (cheap ragged row block, next tile prefetched under the stores:
     // 774 / 1548 tiles at N = 1536 / 3072: 84.6 vs 94.2 us, 158.6 vs 169.1 us); with at most two tiles per CU (N = 768: 387 tiles) one
-    // workgroup per tile is as fast or faster (84.3 vs 87.4 us, 159.4 vs 162.2 us).  profiles/r03_gemm_probe.txt
+    // workgroup per tile is as fast or faster (84.3 vs 87.4 us, 159.4 vs 162.2 us; profiles/r03_gemm_probe.txt) -- since round 4 with the
+    // software-pipelined K loop (SCHED 2: 74.6 / 134.7 us on the box where the persistent kernel took 82.7 / 154.2)
     uint32_t flags = g.flags;
-    if (!(flags & (AUM_GEMM_LOCKSTEP | AUM_GEMM_STAGGERED | AUM_GEMM_PERSISTENT))) flags |= tiles > 2 * ncu ? AUM_GEMM_PERSISTENT : AUM_GEMM_LOCKSTEP;
+    if (!(flags & (AUM_GEMM_LOCKSTEP | AUM_GEMM_STAGGERED | AUM_GEMM_PERSISTENT | AUM_GEMM_PIPELINED))) flags |= tiles > 2 * ncu ? AUM_GEMM_PERSISTENT : AUM_GEMM_PIPELINED;
     if (flags & AUM_GEMM_PERSISTENT) {
         aumg::GemmLaunch L;
         L.g = g;
@@ -55,6 +56,11 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
         return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
     }
     const bool lockstep = (flags & AUM_GEMM_LOCKSTEP) != 0;
+    if (flags & AUM_GEMM_PIPELINED) {
+        if (g.dtype == AUM_BF16) hipLaunchKernelGGL((aumg::k_gemm_tn<true, 2>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
+        else hipLaunchKernelGGL((aumg::k_gemm_tn<false, 2>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
+        return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
+    }
     if (g.dtype == AUM_BF16) {
         if (lockstep) hipLaunchKernelGGL((aumg::k_gemm_tn<true, 0>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
         else hipLaunchKernelGGL((aumg::k_gemm_tn<true, 1>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);

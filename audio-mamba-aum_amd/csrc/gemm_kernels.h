@@ -152,6 +152,58 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
                     for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(bf[j], af[i], acc[i][j]);
             }
         }
+    } else if constexpr (SCHED == 2) {
+        // SCHED 2 (round 4, AUM_GEMM_PIPELINED; the default where a CU gets at most two tiles): same box, us, lockstep -> pipelined:
+        //   N x K = 3072 x 768: 165.0 -> 156.5, 768 x 1536: 81.4 -> 74.6, 1536 x 768: 93.3 -> 87.4, 768 x 3072: 145.6 -> 134.7 (bitwise the same
+        //   results).  The same loop inside the persistent kernel needs 243 registers and ran 2-18 % SLOWER than its 170-register loop: not kept.
+        // The fragments of the NEXT half K-step are read while the current half's 32 MFMAs
+        // run (two register sets), so the matrix pipe does not wait out a fragment read at the head of every half step; the barrier of
+        // a K-step sits between its halves, where the next step's pieces are needed, and the pieces of step t + 2 are issued right behind it
+        s8v bf[2][4], af[2][8];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // step 0 is in LDS
+        if (1 < nk) stage(ra, rb, voff_a, voff_b, BK * 2, rowstep_a, rowstep_b, lds + STAGE_BYTES, w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[0][j] = lds_frag(lds, b_rd + b_joff(j));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[0][i] = lds_frag(lds, a_rd + i * 2048);
+        for (int t = 0; t < nk; ++t) {
+            const char* st = lds + (t & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[1][j] = lds_frag(st, (b_rd ^ 64) + b_joff(j));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[1][i] = lds_frag(st, (a_rd ^ 64) + i * 2048);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(bf[0][j], af[0][i], acc[i][j]);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {                         // one fragment read per two MFMAs, the remaining eight MFMAs behind them
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            if (t + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's pieces of step t + 1 landed, its reads of step t returned
+                __builtin_amdgcn_s_barrier();                                    // ... everybody's
+                if (t + 2 < nk) stage(ra, rb, voff_a, voff_b, (t + 2) * (BK * 2), rowstep_a, rowstep_b, lds + (t & 1) * STAGE_BYTES, w);
+                const char* sn = lds + ((t + 1) & 1) * STAGE_BYTES;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[0][j] = lds_frag(sn, b_rd + b_joff(j));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af[0][i] = lds_frag(sn, a_rd + i * 2048);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(bf[1][j], af[1][i], acc[i][j]);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
+        }
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // step 0 is in LDS

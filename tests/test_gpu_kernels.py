@@ -499,9 +499,10 @@ def test_conv_tm_headline_shape(lib):
 
 @pytest.mark.parametrize("case", cases.GEMM_CASES, ids=lambda c: c[0])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("sched", ["auto", "persistent", "lockstep", "staggered"])
+@pytest.mark.parametrize("sched", ["auto", "persistent", "lockstep", "staggered", "pipelined"])
 def test_gemm_tn(lib, case, dtype, sched):
-    KC.check_gemm(lib, "cuda", case, dtype, flags={"auto": 0, "persistent": aum_hip.GEMM_PERSISTENT, "lockstep": aum_hip.GEMM_LOCKSTEP, "staggered": aum_hip.GEMM_STAGGERED}[sched])
+    KC.check_gemm(lib, "cuda", case, dtype, flags={"auto": 0, "persistent": aum_hip.GEMM_PERSISTENT, "lockstep": aum_hip.GEMM_LOCKSTEP, "staggered": aum_hip.GEMM_STAGGERED,
+                                                          "pipelined": aum_hip.GEMM_PIPELINED}[sched])
 
 
 @pytest.mark.parametrize("shape", [(64 * 513, 768, 1536), (64 * 513, 768, 3072), (50000, 512, 192), (33000, 768, 64)], ids=lambda c: "x".join(map(str, c)))
@@ -583,7 +584,7 @@ def test_gemm_tn_full_size(lib, shape):
     for _ in range(3):
         assert torch.equal(out, aum_hip.gemm_tn(a, b, lib=lib))
     whole = aum_hip.gemm_tn(a, b, lib=lib, split_tail=False)         # (N = 768: the default splits the tail tiles along K -- test_gemm_tn_split_tail)
-    for fl in (aum_hip.GEMM_LOCKSTEP, aum_hip.GEMM_STAGGERED, aum_hip.GEMM_PERSISTENT):                               # every schedule: the same sums in the same order
+    for fl in (aum_hip.GEMM_LOCKSTEP, aum_hip.GEMM_STAGGERED, aum_hip.GEMM_PERSISTENT, aum_hip.GEMM_PIPELINED):                            # every schedule: the same sums in the same order
         assert torch.equal(whole, aum_hip.gemm_tn(a, b, lib=lib, flags=fl))
 
 
@@ -642,7 +643,7 @@ def test_gemm_tn_random_shapes(lib):
         m = rnd.choice([rnd.randint(1, 1500), 256 * rnd.randint(1, 5) + rnd.choice([0, 1, 64, 127, 128, 129, 255])])
         n, k = 256 * rnd.randint(1, 4), 64 * rnd.randint(1, 8)
         pad_a, pad_c = 8 * rnd.randint(0, 3), 8 * rnd.randint(0, 3)
-        flags = rnd.choice([0, aum_hip.GEMM_PERSISTENT, aum_hip.GEMM_LOCKSTEP, aum_hip.GEMM_STAGGERED])
+        flags = rnd.choice([0, aum_hip.GEMM_PERSISTENT, aum_hip.GEMM_LOCKSTEP, aum_hip.GEMM_STAGGERED, aum_hip.GEMM_PIPELINED])
         KC.check_gemm(lib, "cuda", (f"rnd{it}_{m}_{n}_{k}", m, n, k, pad_a, pad_c), torch.bfloat16, flags=flags)
 
 
