@@ -744,6 +744,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_wgrad(AumGemmWArgs g) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) yf[f] = frag(ay[half * 4 + f] + st + ks * 32 * 512);
     };
+    // (Round 4 also tried the software pipeline of aum_gemm_tn's SCHED 2 here -- next step's x / first-half y fragments read under the second
+    // half's MFMAs, 80 fragment registers: 155.2 vs 154.1 us for dW_in, 91.2 vs 89.3 us for dW_out, the step 63.57 vs 63.54 ms, and 196 bytes
+    // of spills at the joins of its tail.  Not the limit of this loop: not kept.)
     // Memory operations retire in issue order: with the four pieces of each of the next two stages behind them, the pieces of stage t have
     // landed when at most 8 are outstanding (fewer stages were requested near the end: wait for everything there).
 #pragma unroll
@@ -769,6 +772,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_wgrad(AumGemmWArgs g) {
 #pragma unroll
                 for (int f = 0; f < 4; ++f) acc[half * 4 + fn][f] = mfma<BF16>(xf[f], yf[half][fn], acc[half * 4 + fn][f]);
     }
+
 
     // store the fp32 partial tile: lane (gq, i = lane & 15) holds C[n0 + wr * 128 + fn * 16 + i][k0 + wc * 64 + f * 16 + 4 gq + r], r = 0..3
     float* c_base = g.part + ((int64_t)s * g.n + n0 + wr * 128 + (lane & 15)) * g.k + k0 + wc * 64 + 4 * gq;
