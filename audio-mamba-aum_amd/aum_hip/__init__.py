@@ -83,7 +83,7 @@ class ScanTmBwdArgs(C.Structure):
                 + [(n, _i64) for n in ("workspace_bytes", "u_bs", "u_ts", "delta_bs", "delta_ts", "z_bs", "z_ts", "B_bs", "B_ts",
                                        "C_bs", "C_ts", "dout_bs", "dout_ts", "pre_bs", "pre_ts", "du_bs", "du_ts", "ddelta_bs",
                                        "ddelta_ts", "dz_bs", "dz_ts")]
-                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32)])
+                + [(n, _i32) for n in ("batch", "dim", "len", "dstate", "dtype")] + [("flags", _u32), ("dA_xA", _vp), ("dA_b_xA", _vp)])
 
 
 class ScanTmSegFwdArgs(C.Structure):
@@ -615,7 +615,7 @@ def scan_tm_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softpl
 
 
 def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_softplus=False, reverse=False, A_b=None, dz_out=None,
-                lib=None, segments=1):
+                lib=None, segments=1, want_dA_xA=False):
     """Backward of scan_tm_fwd (same tensor conventions; ckpt: the tensor scan_tm_fwd filled).  Returns dict(du, ddelta, dz (batch, len,
     dim) in u's dtype, dBC (batch, len, 2 * dstate) fp32 = dB | dC, dA, dA_b (dim, dstate), dD, ddelta_bias (dim) fp32)."""
     lib = lib or get()
@@ -653,6 +653,9 @@ def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_
     dA_b = torch.empty((dim, dstate), **f32) if bidir else None
     dD = torch.empty((dim,), **f32) if D is not None else None
     dbias = torch.empty((dim,), **f32) if delta_bias is not None else None
+    # want_dA_xA: dA .* A (and dA_b .* A_b) from the same partial-sum launch -- the gradient of A_log where A = -exp(A_log)
+    dA_xA = torch.empty((dim, dstate), **f32) if want_dA_xA else None
+    dA_b_xA = torch.empty((dim, dstate), **f32) if want_dA_xA and bidir else None
     if segments > 1:
         ws_bytes = int(lib.c.aum_scan_tm_seg_workspace_bytes(batch, dim, length, dstate, int(bidir), int(segments)))
         if ws_bytes <= 0:
@@ -665,6 +668,7 @@ def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_
     a.A, a.A_b, a.D, a.delta_bias, a.ckpt = _ptr(A), _ptr(A_b), _ptr(D), _ptr(delta_bias), _ptr(ckpt)
     a.du, a.ddelta, a.dz = _ptr(du), _ptr(ddelta), _ptr(dz)
     a.dA, a.dA_b, a.dBC, a.dD, a.ddelta_bias = map(_ptr, (dA, dA_b, dBC, dD, dbias))
+    a.dA_xA, a.dA_b_xA = _ptr(dA_xA), _ptr(dA_b_xA)
     a.workspace, a.workspace_bytes = _ptr(ws), ws_bytes
     a.u_bs, a.u_ts = _tm3(u, "u", dim)
     a.delta_bs, a.delta_ts = _tm3(delta, "delta", dim)
@@ -687,7 +691,7 @@ def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_
                 (batch, dim, length, dstate, u.element_size(), True, int(segments)))
     else:
         _launch(lib.c.aum_scan_tm_bwd, a, u, lib, "scan_tm_bwd_bidir" if bidir else "scan_tm_bwd", (batch, dim, length, dstate, u.element_size(), True))
-    return dict(du=du, ddelta=ddelta, dz=dz, dBC=dBC, dA=dA, dA_b=dA_b, dD=dD, ddelta_bias=dbias, _ws=ws)
+    return dict(du=du, ddelta=ddelta, dz=dz, dBC=dBC, dA=dA, dA_b=dA_b, dD=dD, ddelta_bias=dbias, dA_xA=dA_xA, dA_b_xA=dA_b_xA, _ws=ws)
 
 
 GEMM_BN, GEMM_BK = 256, 64
@@ -975,7 +979,7 @@ def conv1d_tm_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, li
     dx = dx_out if dx_out is not None else torch.empty((batch, length, dim), dtype=x.dtype, device=x.device)
     nparts = int(lib.c.aum_conv1d_tm_nparts(batch, length))
     f32 = dict(dtype=torch.float32, device=x.device)
-    dw_part = torch.empty((nparts, width, dim), **f32)
+    dw_part = torch.empty((nparts, dim, width), **f32)
     db_part = torch.empty((nparts, dim), **f32) if bias is not None else None
     a = ConvTmArgs()
     a.x, a.dy, a.weight, a.bias, a.dx, a.dw_part, a.db_part = map(_ptr, (x, dy, weight, bias, dx, dw_part, db_part))
@@ -985,7 +989,7 @@ def conv1d_tm_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, li
     a.batch, a.dim, a.len, a.width, a.dtype = batch, dim, length, width, _DT[x.dtype]
     a.flags = (CONV_SILU if silu else 0) | (CONV_REVERSE if reverse else 0)
     _launch(lib.c.aum_conv1d_tm_bwd, a, x, lib, "conv_tm_bwd", (batch, dim, length, x.element_size()))
-    dweight = sum_rows(dw_part, lib=lib).t().contiguous()
+    dweight = sum_rows(dw_part, lib=lib)                       # (dim, width): the partial rows are in the weight's own layout
     dbias = sum_rows(db_part, lib=lib) if db_part is not None else None
     return dx, dweight, dbias
 

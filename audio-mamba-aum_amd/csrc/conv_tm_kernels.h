@@ -7,7 +7,7 @@
 //                                           dw[k] = sum_{b,t} dpre[t] x[t - (W-1) + k];  dbias = sum_{b,t} dpre[t]
 // AUM_CONV_REVERSE: the same on the time-reversed sequence (flip(conv(flip(x))) without the copies) -- the wave walks time the other way.
 // A wave takes CONVT_TC steps of one batch entry; the backward walks them from the last to the first (dx[t] needs dpre[t .. t+3], known
-// by then) and leaves ONE partial row of dw / dbias per wave: [part][k][dim] and [part][dim] fp32, summed by aum_sum_rows in a fixed
+// by then) and leaves ONE partial row of dw / dbias per wave: [part][dim][k] and [part][dim] fp32, summed by aum_sum_rows in a fixed
 // order (no atomics: bitwise repeatable).
 #pragma once
 #include "wave.h"
@@ -250,14 +250,15 @@ AUM_DEV void convt_bwd_wave(const AumConvTmArgs& a, int wg) {
             }
         }
     }
-    // partial rows of this wave: dw_part[part][k][dim], db_part[part][dim]
+    // partial rows of this wave: dw_part[part][dim][k] (the weight's own layout: a lane's 8 channels x 4 taps are 128 contiguous bytes, and the
+    // sum over the parts is the gradient as it is -- round 3 wrote [part][k][dim] and paid a transposing copy per layer), db_part[part][dim]
     const int part = b * nch + ch;
     AUM_UNROLL
     for (int v = 0; v < V; ++v) {
         AUM_UNROLL
         for (int k = 0; k < CONVT_W; ++k) {
             const int kk = k - (CONVT_W - a.width);
-            if (kk >= 0) gstore(a.dw_part + ((int64_t)part * a.width + kk) * a.dim, ln.c0 + v, dw[k][v], ln.live);
+            if (kk >= 0) gstore(a.dw_part + (int64_t)part * a.dim * a.width + kk, (ln.c0 + v) * a.width, dw[k][v], ln.live);
         }
         if (a.db_part) gstore(a.db_part + (int64_t)part * a.dim, ln.c0 + v, db[v], ln.live);
     }

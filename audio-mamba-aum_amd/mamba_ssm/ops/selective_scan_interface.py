@@ -80,6 +80,7 @@ def step_cache(mixers, dtype):
                 groups.setdefault((want_t, tuple(lin.weight.shape), lin.weight.device), []).append(lin.weight)
         a_logs += [p for p in (getattr(m, "A_log", None), getattr(m, "A_b_log", None)) if p is not None]
     mine = []
+    _DA_XA.clear()
     with torch.no_grad():
         for (want_t, shape, dev), ps in groups.items():
             bank = torch.empty((len(ps),) + shape, dtype=dtype, device=dev)
@@ -119,8 +120,16 @@ def _cast_t(w, dtype):
     return (w if dtype is None else w.to(dtype)).t().contiguous()
 
 
+# d A_log = d A .* A.  The token-major scan backward writes that product next to d A in its partial-sum launch (aum_scan_tm_bwd: dA_xA);
+# it is handed over here, keyed by the STORAGE of the d A tensor the block returned -- the entry holds that tensor, so the address cannot
+# be reused while the entry lives; a gradient that is not that very tensor (summed with another use of A, copied) misses and is
+# multiplied as before.  Entries nobody claimed are dropped when the next forward opens its cache.
+_DA_XA = {}
+
+
 class _NegExpFn(torch.autograd.Function):
-    """A = -exp(A_log) with the value taken from the cache: d A / d A_log = A, one launch in the backward"""
+    """A = -exp(A_log) with the value taken from the cache: d A / d A_log = A (one launch in the backward, none when the scan backward
+    already formed the product)"""
 
     @staticmethod
     def forward(ctx, A_log, A):
@@ -129,6 +138,10 @@ class _NegExpFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        ent = _DA_XA.pop(g.data_ptr(), None)
+        if ent is not None and ent[0].data_ptr() == g.data_ptr() and ent[0].shape == g.shape and ent[0].dtype == g.dtype \
+                and ent[2].data_ptr() == ctx.saved_tensors[0].data_ptr():
+            return ent[1], None
         return g * ctx.saved_tensors[0], None
 
 
@@ -537,6 +550,7 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
                                          reverse if A_b is None else False, A_b=A_b, want_out_pre=need_bwd, ckpt=ckpt,
                                          segments=tm_segments(Bsz, E, L, A_b is not None, False) if cut else 1)
     ctx.tm_cut = cut
+    ctx.A_cached = bool(_STEP_CACHE) and need_bwd and A.dtype == torch.float32 and A.is_contiguous() and (A_b is None or A_b.is_contiguous())
     ctx.tm = True
     ctx.delta_softplus, ctx.reverse = delta_softplus, reverse
     ctx.has_out_proj = out_proj_weight is not None
@@ -574,7 +588,12 @@ def _inner_backward_tm(ctx, dout):
     x3 = x_dbl.view(Bsz, L, R + 2 * N)
     g = aum_hip.scan_tm_bwd(conv_out, delta.view(Bsz, L, E), A, x3[:, :, R:R + N], x3[:, :, R + N:], D, z, delta_bias, dout_z, out_pre,
                             ckpt, ctx.delta_softplus, ctx.reverse if A_b is None else False, A_b=A_b, dz_out=dz,
-                            segments=tm_segments(Bsz, E, L, A_b is not None, True) if ctx.tm_cut else 1)   # SSI:541-561
+                            segments=tm_segments(Bsz, E, L, A_b is not None, True) if ctx.tm_cut else 1,
+                            want_dA_xA=ctx.A_cached)                                           # SSI:541-561
+    if ctx.A_cached:            # A came out of the forward's cache (neg_exp): its d A_log is ready (see _NegExpFn)
+        _DA_XA[g["dA"].data_ptr()] = (g["dA"], g["dA_xA"], A)
+        if A_b is not None:
+            _DA_XA[g["dA_b"].data_ptr()] = (g["dA_b"], g["dA_b_xA"], A_b)
     du2, ddelta2 = g["du"].view(Bsz * L, E), g["ddelta"].view(Bsz * L, E)
     dbc2 = g["dBC"].view(Bsz * L, 2 * N)
     conv2d = conv_out.view(Bsz * L, E)

@@ -352,6 +352,9 @@ typedef struct AumScanTmBwdArgs {
     int32_t batch, dim, len, dstate;
     int32_t dtype;
     uint32_t flags;
+    /* ABI 10, optional (NULL: not written): dA .* A and dA_b .* A_b, (dim, dstate) fp32 -- the gradient with respect to A_log when
+       A = -exp(A_log) (mamba_simple.py:190, 204), written by the same partial-sum launch that writes dA / dA_b */
+    float *dA_xA, *dA_b_xA;
 } AumScanTmBwdArgs;
 int aum_scan_tm_bwd(const AumScanTmBwdArgs* args, void* stream);
 int64_t aum_scan_tm_workspace_bytes(int32_t batch, int32_t dim, int32_t len, int32_t dstate, int32_t bidirectional);
@@ -392,7 +395,7 @@ int64_t aum_scan_tm_seg_workspace_bytes(int32_t batch, int32_t dim, int32_t len,
  * channel contiguous -- the layout of the in_proj output rows [x | z] and of the time-serial scan's operands, so x / dx may be the
  * first half of a (batch, len, 2 dim) tensor (strides in ELEMENTS: *_bs batch, *_ts token; channel stride 1).
  *   x, y, dy, dx in `dtype`; weight (dim, width) fp32, width <= 4; bias (dim) fp32 or NULL; flags: AUM_CONV_SILU, AUM_CONV_REVERSE.
- *   backward: dx written; dw_part [nparts][width][dim] and db_part [nparts][dim] (NULL without bias) fp32 are per-wave partial sums
+ *   backward: dx written; dw_part [nparts][dim][width] (the weight's layout) and db_part [nparts][dim] (NULL without bias) fp32 are per-wave partial sums
  *   (nparts = aum_conv1d_tm_nparts(batch, len)) that the caller adds up in a fixed order (aum_sum_rows): no atomics.
  * Limits: dim % (16 / sizeof(dtype)) == 0, 16-byte aligned pointers (weight and bias included) and row strides.
  */

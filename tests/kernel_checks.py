@@ -322,7 +322,9 @@ def check_scan_tm(lib, dev, case, dtype=torch.float32, reverse=False, bidir=Fals
     pairs["out_nopre"] = (cm(out2), ref_out)
     if backward:
         g = aum_hip.scan_tm_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, out_pre if has_z else None, ck, softplus, reverse, T(A_b, dev), lib=lib,
-                                segments=segments)
+                                segments=segments, want_dA_xA=True)
+        # the optional products d A .* A (the gradient of A_log) come out of the same partial-sum launch: exactly dA * A in fp32
+        assert torch.equal(g["dA_xA"], g["dA"] * A) and (not bidir or torch.equal(g["dA_b_xA"], g["dA_b"] * T(A_b, dev)))
         gr = O.scan_bwd(q["u"], q["delta"], d["A"], q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus, reverse, "f64")
         if bidir:
             gb = O.scan_bwd(q["u"], q["delta"], A_b, q["B"], q["C"], d["D"], q["z"], d["delta_bias"], q["dout"], softplus, True, "f64")

@@ -54,7 +54,7 @@ def test_struct_layouts_match_header(tmp_path):
         "AumScanTmFwdArgs": (aum_hip.ScanTmFwdArgs, ["u", "C", "A", "delta_bias", "out", "out_pre", "ckpt", "u_bs", "C_ts", "pre_ts", "batch",
                                                      "dstate", "dtype", "flags"]),
         "AumScanTmBwdArgs": (aum_hip.ScanTmBwdArgs, ["u", "dout", "out_pre", "A", "ckpt", "du", "dz", "dA", "dBC", "ddelta_bias", "workspace",
-                                                     "workspace_bytes", "u_bs", "pre_ts", "du_bs", "dz_ts", "batch", "dtype", "flags"]),
+                                                     "workspace_bytes", "u_bs", "pre_ts", "du_bs", "dz_ts", "batch", "dtype", "flags", "dA_xA", "dA_b_xA"]),
         "AumConvTmArgs": (aum_hip.ConvTmArgs, ["x", "dy", "weight", "bias", "y", "dx", "dw_part", "db_part", "x_bs", "dx_ts", "batch", "width",
                                                "dtype", "flags"]),
         "AumDtProjArgs": (aum_hip.DtProjArgs, ["x", "w", "out", "ntok", "dim", "rank", "ldx", "ldw", "ldo", "dtype"]),

@@ -386,6 +386,38 @@ def test_token_major_segments_module(monkeypatch):
             assert rel_err(res[0][2][k].numpy(), res[1][2][k].numpy()) < 2e-4, (btype, k)
 
 
+def test_dA_log_product_comes_from_the_scan_backward(monkeypatch):
+    """A = -exp(A_log) from the forward's cache: the token-major scan backward writes d A .* A next to d A (aum_scan_tm_bwd: dA_xA) and
+    _NegExpFn.backward hands it on instead of multiplying -- every A / A_b of the model, same A_log gradients as the multiplying path,
+    nothing left in the hand-over table; a block used on its own (no cache) multiplies as before."""
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    from aum.model import build_aum
+    hits = {"product": 0, "multiply": 0}
+    orig = ssi._NegExpFn.backward
+
+    def counting(ctx, g):
+        before = len(ssi._DA_XA)
+        r = orig(ctx, g)
+        hits["product" if len(ssi._DA_XA) < before else "multiply"] += 1
+        return r
+    monkeypatch.setattr(ssi._NegExpFn, "backward", staticmethod(counting))
+    monkeypatch.setattr(ssi, "_TM_MIN_WAVES", 0)
+    torch.manual_seed(0)
+    m = build_aum("small", depth=2, num_classes=5, bimamba_type="v1", spectrogram_size=(128, 64))
+    x = torch.randn(2, 64, 128)
+    m(x).sum().backward()
+    assert hits == {"product": 4, "multiply": 0} and not ssi._DA_XA, (hits, len(ssi._DA_XA))
+    fused = {k: p.grad.clone() for k, p in m.named_parameters() if "A_" in k}
+    m.zero_grad()
+    monkeypatch.setattr(ssi, "_TM_MIN_WAVES", 10 ** 9)          # channel-major block: no product from the kernel
+    hits.update(product=0, multiply=0)
+    m(x).sum().backward()
+    assert hits == {"product": 0, "multiply": 4}
+    for k, p in m.named_parameters():
+        if "A_" in k:
+            assert rel_err(fused[k].numpy(), p.grad.numpy()) < 2e-4, k
+
+
 def test_time_reversed_block_equals_flip_sandwich(monkeypatch):
     """Mamba.forward(h, time_reversed=True) == flip(forward(flip(h))) for the three block types in both activation layouts -- outputs,
     input gradient and every parameter gradient (the odd layers of an `if_bidirectional` model, MM:623-638, run without the four flipped
