@@ -8,6 +8,7 @@ result (MS:229-246); single-token decoding (`step`, inference caches, MS:313-400
 (bimamba_type="none") as the reference's element-wise composition -- AuM itself never passes inference_params
 (MM:620-622).
 """
+import contextlib
 import math
 
 import torch
@@ -123,14 +124,25 @@ class Mamba(nn.Module):
                                        delta_softplus=True, reverse=time_reversed)
             elif self.bimamba_type == "v2":
                 A_b = neg_exp(self.A_b_log)
+                # Bi-Bi's two pipelines are independent until their outputs are added; each is one-direction launches of 1 536 waves at
+                # the bench shape (half of what the time-serial kernels hold), so the second runs on a side stream next to the first
+                # (forward here; autograd runs each pipeline's backward on the stream its forward ran on).  AUM_V2_STREAMS=0: in line.
+                two = tm and ssi.v2_two_streams() and xz.is_cuda
+                if two:
+                    main, side = torch.cuda.current_stream(xz.device), ssi.side_stream(xz.device)
+                    side.wait_stream(main)
                 out_f = mamba_inner_fn_no_out_proj(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                                    self.dt_proj.weight, A, None, None, self.D.float(),
                                                    delta_bias=self.dt_proj.bias.float(), delta_softplus=True,
                                                    reverse=time_reversed)
-                out_b = mamba_inner_fn_no_out_proj(xz, self.conv1d_b.weight, self.conv1d_b.bias,
-                                                   self.x_proj_b.weight, self.dt_proj_b.weight, A_b, None, None,
-                                                   self.D_b.float(), delta_bias=self.dt_proj_b.bias.float(),
-                                                   delta_softplus=True, reverse=not time_reversed)
+                with (torch.cuda.stream(side) if two else contextlib.nullcontext()):
+                    out_b = mamba_inner_fn_no_out_proj(xz, self.conv1d_b.weight, self.conv1d_b.bias,
+                                                       self.x_proj_b.weight, self.dt_proj_b.weight, A_b, None, None,
+                                                       self.D_b.float(), delta_bias=self.dt_proj_b.bias.float(),
+                                                       delta_softplus=True, reverse=not time_reversed)
+                if two:
+                    main.wait_stream(side)
+                    out_b.record_stream(main)          # allocated on the side stream, consumed on the main one
                 y = out_f + out_b                                          # (B, E, L) logical, both in xz's storage order
                 if self.if_devide_out:
                     y = y / 2

@@ -368,6 +368,26 @@ def _mm_rows(a, b, bit):
 # 67.0-70.1 (N = 768 is two tiles per CU: tile quantisation).  The default ("auto") therefore sends the two N >= 1536 shapes
 # to the kernel; AUM_DEBUG=1 AUM_GEMM=hip sends all four, AUM_GEMM=lib none, AUM_GEMM_SHAPES="NxK,..." another set (A/B runs).  The weight
 # gradients (token-contiguous operands) and everything that does not qualify stay library GEMMs.
+_V2_STREAMS = _dbg_env("AUM_V2_STREAMS", "1") != "0"        # Bi-Bi: the second pipeline on a side stream (mamba_simple.py); 0: in line (A/B)
+_side_streams = {}
+
+
+def v2_two_streams():
+    """Bi-Bi's second pipeline on a side stream?  Not under data parallelism: DistributedDataParallel's reducer orders a bucket's all-reduce
+    behind the stream of the LAST gradient hook only, and with two backward streams a bucket holds gradients of both."""
+    if not _V2_STREAMS:
+        return False
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
+def side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 _XDT_BWD_HIP = _dbg_env("AUM_XDT_BWD_LIB", "0") != "1"      # AUM_DEBUG=1 AUM_XDT_BWD_LIB=1: the x_proj / dt_proj gradients as five library calls (A/B)
 _XDT_HIP = _dbg_env("AUM_XDT_LIB", "0") != "1"              # AUM_DEBUG=1 AUM_XDT_LIB=1: x_proj as a library GEMM + the dt projection kernel (A/B)
 _DTPROJ_HIP = _dbg_env("AUM_DTPROJ_LIB", "0") != "1"        # AUM_DEBUG=1 AUM_DTPROJ_LIB=1: the dt projection back on the library GEMM (A/B)
