@@ -33,28 +33,47 @@ def spec_augment(fbank, freqm, timem, fill=0.0, generator=None):
     return fbank
 
 
+def pack_augmentation(n_time, n_mel, freqm, timem, u_fv=None, u_fm=None, u_tv=None, u_tm=None, u_amp=None, field=None, shift=None):
+    """The log-mel kernel's per-clip augmentation table from the raw draws (each a (batch,) tensor of uniform [0, 1) numbers; `shift`
+    integers in [-10, 10); `field` the (batch, n_time, n_mel) uniform noise field): the band limits by torchaudio's mask_along_axis rule
+    (DL:206-217), the noise amplitude u / 10 and the roll (DL:226-228).  Column 0 -- the frame count -- is left at -1."""
+    ref = next(t for t in (u_fv, u_tv, u_amp) if t is not None)
+    aug = torch.zeros((ref.shape[0], 8), dtype=torch.float32, device=ref.device)
+    aug[:, 0] = -1.0
+
+    def band(size, param, u_v, u_m):
+        value = u_v * param
+        lo = (u_m * (size - value)).long()
+        return lo.float(), (lo + value.long()).float()
+    if freqm:
+        aug[:, 1], aug[:, 2] = band(n_mel, freqm, u_fv, u_fm)
+    if timem:
+        aug[:, 3], aug[:, 4] = band(n_time, timem, u_tv, u_tm)
+    if u_amp is not None:
+        aug[:, 6] = u_amp / 10
+        aug[:, 5] = shift.float()
+    return aug, field
+
+
 def draw_augmentation(batch, n_time, n_mel, freqm, timem, noise, device, generator=None):
     """The random numbers of spec_augment + noise_roll for one batch, in THEIR draw order (so a seeded generator gives the same
     augmentation either way), packed for the log-mel kernel's fused epilogue (aum_hip.fbank_fwd aug= / noise=):
     returns (aug (batch, 8) fp32 with column 0 -- the frame count -- left at -1, noise (batch, n_time, n_mel) or None)."""
-    aug = torch.zeros((batch, 8), dtype=torch.float32, device=device)
-    aug[:, 0] = -1.0
-
-    def band(size, param):
-        value = torch.rand(batch, device=device, generator=generator) * param
-        start = torch.rand(batch, device=device, generator=generator) * (size - value)
-        lo = start.long()
-        return lo.float(), (lo + value.long()).float()
+    u = lambda: torch.rand(batch, device=device, generator=generator)
+    kw = {}
     if freqm:
-        aug[:, 1], aug[:, 2] = band(n_mel, freqm)
+        kw["u_fv"], kw["u_fm"] = u(), u()
     if timem:
-        aug[:, 3], aug[:, 4] = band(n_time, timem)
-    nz = None
+        kw["u_tv"], kw["u_tm"] = u(), u()
     if noise:
-        aug[:, 6] = torch.rand(batch, 1, 1, device=device, generator=generator).flatten() / 10
-        nz = torch.rand((batch, n_time, n_mel), device=device, generator=generator)
-        aug[:, 5] = torch.randint(-10, 10, (batch,), device=device, generator=generator).float()
-    return aug, nz
+        kw["u_amp"] = torch.rand(batch, 1, 1, device=device, generator=generator).flatten()
+        kw["field"] = torch.rand((batch, n_time, n_mel), device=device, generator=generator)
+        kw["shift"] = torch.randint(-10, 10, (batch,), device=device, generator=generator)
+    if not kw:
+        aug = torch.zeros((batch, 8), dtype=torch.float32, device=device)
+        aug[:, 0] = -1.0
+        return aug, None
+    return pack_augmentation(n_time, n_mel, freqm, timem, **kw)
 
 
 def noise_roll(fbank, generator=None):

@@ -95,14 +95,15 @@ class Block(nn.Module):
         self.mixer = mixer
         self.norm = RMSNorm(dim, eps=eps)
 
-    def forward(self, hidden_states, residual=None, time_reversed=False):
-        """time_reversed: the block on the time-reversed sequence, reversed back (the odd layers of `if_bidirectional`) -- add + norm
-        is token-wise, the mixer takes the flag: no flipped copies of hidden_states / residual."""
+    def forward(self, hidden_states, residual=None, inference_params=None, *, time_reversed=False):
+        """MM:58-99 (the third positional slot is the reference's inference_params).  time_reversed (keyword only): the block on the
+        time-reversed sequence, reversed back (the odd layers of `if_bidirectional`) -- add + norm is token-wise, the mixer takes the
+        flag: no flipped copies of hidden_states / residual."""
         hidden_states, residual = rms_norm_fn(hidden_states, self.norm.weight, self.norm.bias, residual=residual,
                                               prenorm=True, residual_in_fp32=True, eps=self.norm.eps)
         if time_reversed:
-            return self.mixer(hidden_states, time_reversed=True), residual
-        return self.mixer(hidden_states), residual
+            return self.mixer(hidden_states, inference_params=inference_params, time_reversed=True), residual
+        return self.mixer(hidden_states, inference_params=inference_params), residual
 
 
 class AudioMamba(nn.Module):

@@ -126,8 +126,20 @@ class Dist:
         self.device = torch.device("cuda", self.dev_index) if self.cuda else torch.device("cpu")
         if self.cuda:
             torch.cuda.set_device(self.device)
-        if self.world > 1 and not dist.is_initialized():
-            dist.init_process_group(os.environ.get("AUM_DIST_BACKEND", "nccl" if self.cuda else "gloo"))
+        # AUM_FORCE_DDP=1: the data-parallel machinery (process group, DistributedDataParallel reducer, bucket views, the gradient
+        # exchange hook, the MIN-reduced finite flag) also at world size 1 -- how the RCCL path is exercised on a one-GPU box
+        self.ddp = self.world > 1 or os.environ.get("AUM_FORCE_DDP", "0") == "1"
+        if self.ddp and not dist.is_initialized():
+            if self.world == 1:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29533")
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
+            backend = os.environ.get("AUM_DIST_BACKEND", "nccl" if self.cuda else "gloo")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.device)
+            else:
+                dist.init_process_group(backend)
         self.main = self.rank == 0
 
     def print(self, *a):
@@ -166,12 +178,14 @@ def build_model(args):
 
 
 def compress_gradients(ddp, kind):
-    """Optional 16-bit gradient exchange: each fp32 bucket is cast, all-reduced (RCCL ring over xGMI: per-link bound, so half the
-    bytes is close to half the exchange time) and cast back into the bucket view; master weights and Adam stay fp32."""
-    if kind == "no":
-        return
+    """The gradient exchange of a DistributedDataParallel model (TT:39, TT:168).  kind "bf16" / "fp16": each fp32 bucket is cast,
+    all-reduced (RCCL ring over xGMI: per-link bound, so half the bytes is close to half the exchange time) and cast back into the
+    bucket view; master weights and Adam stay fp32.  "no": the plain fp32 all-reduce + mean.  In every case the bucket goes through
+    ssi.ddp_join_streams_hook first: Bi-Bi's two backward streams are joined before the collective is ordered behind one of them."""
+    from mamba_ssm.ops import selective_scan_interface as ssi
     from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-    ddp.register_comm_hook(None, default_hooks.bf16_compress_hook if kind == "bf16" else default_hooks.fp16_compress_hook)
+    inner = {"no": None, "bf16": default_hooks.bf16_compress_hook, "fp16": default_hooks.fp16_compress_hook}[kind]
+    ddp.register_comm_hook(None, ssi.ddp_join_streams_hook(inner))
 
 
 class Frontend:
@@ -326,7 +340,7 @@ def train(model, train_loader, val_loader, args, D):
     if args.optim_path:
         optimizer.load_state_dict(torch.load(args.optim_path, map_location="cpu"))
     net = model
-    if D.world > 1:
+    if D.ddp:
         net = nn.parallel.DistributedDataParallel(model, device_ids=[D.dev_index] if D.cuda else None,
                                                   gradient_as_bucket_view=True, static_graph=bool(args.if_nan2num), bucket_cap_mb=100)
         compress_gradients(net, args.grad_compress)
@@ -372,7 +386,7 @@ def train(model, train_loader, val_loader, args, D):
                 # a rank that skipped alone would leave the others waiting in the gradient all-reduce -- so the finite flag is
                 # reduced (MIN) first.  This is the only per-step host sync of the loop and it is off by default.
                 finite = torch.isfinite(loss.detach()).to(torch.float32)
-                if D.world > 1:
+                if D.ddp:
                     dist.all_reduce(finite, op=dist.ReduceOp.MIN)
                 if finite.item() == 0.0:
                     if args.if_continue_inf:
@@ -448,7 +462,7 @@ def _sync_loss(loss_acc, D):
     """(sum, count) of the running training loss over all ranks: one all-reduce + one device->host copy, called every
     --n-print-steps steps and at the end of an epoch -- never per step."""
     t = loss_acc.clone()
-    if D.world > 1:
+    if D.ddp:
         dist.all_reduce(t)
     HOST_SYNCS["loss_syncs"] += 1
     v = t.tolist()
@@ -510,7 +524,7 @@ def main(argv=None):
         D.print(f"Now starting evaluation on {args.dataset} dataset!")
         os.makedirs(args.exp_dir, exist_ok=True)
         evaluate(model, val_loader, args, D, "eval")
-    if D.world > 1:
+    if D.ddp and dist.is_initialized():
         dist.destroy_process_group()
 
 

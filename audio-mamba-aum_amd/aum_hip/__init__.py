@@ -540,7 +540,7 @@ def scan_tm_ckpt(batch, length, dim, dstate, bidir, device, lib=None, dtype=torc
 SCAN_TM_MAX_SEGMENTS = 32
 
 
-def scan_tm_segments(batch, dim, length, bidir, training=False, nsimd=1024):
+def scan_tm_segments(batch, dim, length, bidir, training=False, nsimd=None):
     """time segments a token-major launch of this shape is cut into (1: not cut).  One wave per (batch entry, 64 channels, direction)
     leaves most SIMDs idle at a small batch while every wave walks the whole row; segments multiply the waves at the price of one
     carry pass (the recurrence once more, without outputs).  Rows are cut only when they are long (>= 1024 steps) and the uncut launch is
@@ -548,6 +548,7 @@ def scan_tm_segments(batch, dim, length, bidir, training=False, nsimd=1024):
     launch of its own), ranges no shorter than 128 steps.  Measured at B = 8, L = 4097, E = 1536 (profiles/r04_seg_time.json): 16
     ranges are the fastest cut for the forward (three resident waves per SIMD: one round) AND for the backward (two resident: 11 or
     12 ranges leave a tail round, 16 is 1.5 rounds of shorter waves) -- 0.68 / 1.39 ms against 1.29 / 5.03 ms uncut."""
+    nsimd = 4 * cu_count() if nsimd is None else nsimd          # MI355X: 256 CUs x 4 SIMDs
     per_dir = batch * (dim // 64)
     waves = per_dir * (2 if bidir else 1)
     if per_dir <= 0 or waves * 2 > nsimd or length < 1024:
@@ -697,32 +698,56 @@ def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_
 GEMM_BN, GEMM_BK = 256, 64
 
 
-def gemm_wgrad_supported(y, x):
-    """shapes aum_gemm_wgrad takes (include/aum_hip.h, ABI 10): 16-bit 2-D token-major operands (rows = tokens, unit column stride), y's
-    width a multiple of 256, x's a multiple of 256 or one of the skinny widths 48 / 80"""
-    return (y.dim() == 2 and x.dim() == 2 and y.dtype == x.dtype and y.dtype in (torch.bfloat16, torch.float16) and y.shape[0] == x.shape[0]
-            and y.stride(1) == 1 and x.stride(1) == 1 and y.shape[1] % 256 == 0 and (x.shape[1] % 256 == 0 or x.shape[1] in (48, 80))
-            and y.stride(0) % 8 == 0
-            and x.stride(0) % 8 == 0 and y.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and y.shape[0] > 0)
+_dev_cu = {}
 
 
-def gemm_wgrad_splits(n, k, ncu=256):
+def cu_count(device=None):
+    """compute units of the device the kernels run on (MI355X: 256; a partitioned or different part reports its own) -- the host-side
+    dispatch rules (time segments, token splits) are stated in CUs / SIMDs and must agree with what the library sees (csrc: cu_count())"""
+    if not torch.cuda.is_available():
+        return 256
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    n = _dev_cu.get(idx)
+    if n is None:
+        n = _dev_cu[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+    return n
+
+
+def gemm_wgrad_splits(n, k, ncu=None):
     """token splits that give every CU one workgroup: (n / 256) (k / 256) output tiles x splits ~ the CU count"""
+    ncu = cu_count() if ncu is None else ncu
     tiles = (n // 256) * max(1, k // 256)          # a skinny operand (k = 48 / 80) is one column tile
     return max(1, min(64, ncu // max(tiles, 1)))
+
+
+def gemm_wgrad_supported(y, x, splits=None):
+    """shapes aum_gemm_wgrad takes (include/aum_hip.h, ABI 10; the C side's gemm_wgrad_check, rule for rule): 16-bit 2-D token-major
+    operands (rows = tokens, unit column stride), y's width a multiple of 256, x's a multiple of 256 or one of the skinny widths 48 / 80,
+    at most 64 token splits, and a split's rows within 32-bit byte offsets of both operands"""
+    if not (y.dim() == 2 and x.dim() == 2 and y.dtype == x.dtype and y.dtype in (torch.bfloat16, torch.float16) and y.shape[0] == x.shape[0]
+            and y.stride(1) == 1 and x.stride(1) == 1 and y.shape[1] % 256 == 0 and (x.shape[1] % 256 == 0 or x.shape[1] in (48, 80))
+            and y.stride(0) % 8 == 0 and y.stride(0) >= y.shape[1] and x.stride(0) >= x.shape[1]
+            and x.stride(0) % 8 == 0 and y.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and y.shape[0] > 0):
+        return False
+    splits = splits or gemm_wgrad_splits(y.shape[1], x.shape[1])
+    if not 0 < splits <= 64:
+        return False
+    chunk = (-(-y.shape[0] // splits) + 63) // 64 * 64
+    return chunk * y.stride(0) * 2 < (1 << 31) and chunk * x.stride(0) * 2 < (1 << 31)
 
 
 def gemm_wgrad(y, x, splits=None, lib=None, partials=False):
     """dW (n, k) fp32 = y (t, n)^T @ x (t, k): the weight gradient of a projection from token-major operands (aum_gemm_wgrad: hand-written
     MFMA kernel with transposing LDS reads, fp32 partial tiles over `splits` token ranges summed in a fixed order by aum_sum_rows)."""
     lib = lib or get()
-    if not gemm_wgrad_supported(y, x):
-        raise RuntimeError("gemm_wgrad: operands outside the kernel's limits (see gemm_wgrad_supported)")
-    lib.check_tensor(y)
-    lib.check_tensor(x)
     t, n = y.shape
     k = x.shape[1]
     splits = splits or gemm_wgrad_splits(n, k)
+    if not gemm_wgrad_supported(y, x, splits):
+        raise RuntimeError("gemm_wgrad: operands outside the kernel's limits (see gemm_wgrad_supported)")
+    lib.check_tensor(y)
+    lib.check_tensor(x)
     part = torch.empty((splits, n, k), dtype=torch.float32, device=y.device)
     a = GemmWArgs()
     a.y, a.x, a.part = _ptr(y), _ptr(x), _ptr(part)

@@ -601,6 +601,19 @@ struct ScanTBwdOut {
 // instruction occupies the SIMD's issue for its 8 passes: four per pass cost what 32 DPP adds saved.  Default 0: the butterflies.
 #define AUM_SCANT_MSUM 0
 #endif
+#ifndef AUM_SCANT_LSUM
+// 1 (opt-in builds, -DAUM_SCANT_LSUM=1 [-DAUM_LSUM_PUT_ASM=1]; round 5): 16-bit activations: the dB / dC channel sums of a pass through a
+// per-wave LDS tile (wave.h, lsum_*) instead of two transposing butterflies -- the butterflies are 58 half-rate DPP instructions of a
+// pass's 189 on the pipe that bounds the kernel, the LDS route costs the vector ALU 28 (4 rounds of 8 values: 3 packed adds + 1 add +
+// 3 DPP adds) and moves the transposition to ds_write_b32 / ds_write2st64_b32 + ds_read_b128 (154 vector-ALU instructions per pass
+// instead of 192, 263 instructions in all instead of 275).  The tile is the half of the entry-state strip that 16-bit checkpoints leave
+// unused (fp32 activations keep the butterflies: their checkpoints fill the strip).  Built, parity-green (emulator + 166 GPU tests of
+// the asm-put build) and measured: SLOWER -- same box, B = 64 bf16 Fo-Bi + softplus: butterflies 1.015 ms, LDS route 1.165 ms
+// (1.126 ms with the row pairs as one ds_write2st64_b32), bench 999 vs 958-962 clips/s; the ablation with no sums at all is 0.828 ms
+// (profiles/r05_ab_lsum.txt).  44 more LDS instructions per pass cost ~8 cycles of a wave's issue each and the in-order LDS queue puts
+// every fetch behind the row writes in front of it: with two waves per SIMD that is not hidden.  Default 0: the butterflies.
+#define AUM_SCANT_LSUM 0
+#endif
 #ifndef AUM_SCANT_TAIL2
 #define AUM_SCANT_TAIL2 1     // 0 (A/B builds): each butterfly complete where its terms exist, as in round 3
 #endif
@@ -672,6 +685,24 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     // 16-bit activations: the 64-channel sums of the dB / dC products go through the matrix pipe (wave.h, wave_sum_mfma_*): lane l
     // ends up with value 2 s + h = wave_sum_mfma_value_of_lane(l) -> step s = 2 bit4 + 4 bit5 + bit2, state 2 j + h with h = bit3
     constexpr bool MSUM = AUM_SCANT_MSUM && sizeof(T) == 2 && !(AUM_SCANT_BABL & 1);
+    // the sums through LDS: lane l ends up with value l >> 3 of a round's eight = (step 4 r + (l >> 4), state 2 j + bit3(l))
+#ifdef AUM_SCANT_CK_F32
+    constexpr bool LSUM = false;
+#else
+    constexpr bool LSUM = AUM_SCANT_LSUM && sizeof(T) == 2 && !MSUM && !(AUM_SCANT_BABL & 1);
+#endif
+    float* t_x = t_ck + CKR * WAVE;            // 8 x 64 floats: rows CKR .. 2 CKR - 1 of the entry-state strip
+    static_assert(!LSUM || (CKR * WAVE + LSUM_TILE_FLOATS <= N * WAVE), "the transposition tile is the unused half of the entry-state strip");
+    const vi lsum_slot = (lane >> 4) * SCANT_BC_ROW + ((lane >> 3) & 1);
+    const unsigned lsum_addr = lsum_put_addr(t_x);
+    auto lsum_put2_step = [&](int s, const vf2& p) {       // s is an unrolled loop counter: the row pair is a compile-time offset
+        switch (s & 3) {
+            case 0: lsum_put2<0>(t_x, lsum_addr, p); break;
+            case 1: lsum_put2<2>(t_x, lsum_addr, p); break;
+            case 2: lsum_put2<4>(t_x, lsum_addr, p); break;
+            default: lsum_put2<6>(t_x, lsum_addr, p); break;
+        }
+    };
     const vi dbc_slot_m = (((lane >> 4) & 1) * 2 + ((lane >> 5) & 1) * 4 + ((lane >> 2) & 1)) * SCANT_BC_ROW + ((lane >> 3) & 1);
     const WaveSumSel wsel = wave_sum_mfma_sel();
     WaveSumAcc wacc;
@@ -890,6 +921,13 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) a[s] = (AUM_SCANT_BABL & 2) ? bc_lo(P[s]) * A2j : vexp2_2(bc_lo(P[s]) * A2j);
             // forward sweep: steps 0 .. s_hi-1
+            LsumRaw rawA, rawB, rawC, rawD;        // LSUM: the four rounds of a pass (dC steps 0-3, 4-7; dB steps 4-7, 0-3)
+            // LSUM: the entry rows this pass reads (above) make room for the next block's HERE -- behind the sweep, as below, the request
+            // (a conditional LDS-DMA) would sit between the sweeps' LDS writes, the pass would be two basic blocks, and the packed-operand
+            // broadcasts of the second one are not folded (48 moves per pass).  Without LDS traffic in the sweep the compiler hoists it itself.
+            if constexpr (LSUM) {
+                if (cknext) request_entry(blk - 1, RPP * j, RPP * j + RPP);
+            }
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) {
                 if (!FULL) {
@@ -897,28 +935,37 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                     pb[2 * s] = pb[2 * s + 1] = splat(0.f);
                     pc2[s] = pb2[s] = spl2(splat(0.f));
                 }
+                vf2 pcs = spl2(splat(0.f));
                 if (FULL || s < s_hi) {
                     w[s] = a[s] * x;
                     x = vfma2(bc_hi(P[s]), mk2(qb[s][0], qb[s][1]), w[s]);
                     if (FULL || s >= s_lo) {
-                        const vf2 pcs = ((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1])) * x;
+                        pcs = ((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1])) * x;
                         if constexpr (MSUM) {
                             pc2[s] = pcs;
-                        } else {
+                        } else if constexpr (!LSUM) {
                             pc[2 * s] = lo2(pcs);
                             pc[2 * s + 1] = hi2(pcs);
                         }
                     }
                 }
+                if constexpr (LSUM) {
+                    lsum_put2_step(s, pcs);
+                    if (s == 3) rawA = lsum_fetch(t_x);
+                    if (s == 7) rawB = lsum_fetch(t_x);
+                }
             }
             // the entry rows this pass consumed make room for the next block's
-            if (cknext) request_entry(blk - 1, RPP * j, RPP * j + RPP);
+            if constexpr (!LSUM) {
+                if (cknext) request_entry(blk - 1, RPP * j, RPP * j + RPP);
+            }
             AUM_SCHED_FENCE();
             AUM_TMB_STAMP(3);
             vf dCsum = splat(0.f);
             if constexpr (MSUM) wave_sum_mfma_add16(wacc, 0, wsel, pc2);
             vf hc[4], hb[4];
-            if constexpr (!MSUM) {
+            if constexpr (LSUM) lds_write(t_dbc, lsum_slot + 2 * j + N, lsum_total(rawA));
+            if constexpr (!MSUM && !LSUM) {
                 // the dC butterfly's 24 independent levels now (16 term registers -> 4); its serial tail runs after the reverse sweep,
                 // interleaved with the dB butterfly's (wave.h, wave_sum16_tail2)
                 if (AUM_SCANT_BABL & 1) hc[0] = pc[0] + pc[5];
@@ -930,12 +977,13 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             // reverse sweep: steps s_hi-1 .. s_lo
             AUM_UNROLL
             for (int s = SCANT_CK - 1; s >= 0; --s) {
+                vf2 pbs = spl2(splat(0.f));
                 if (FULL || (s >= s_lo && s < s_hi)) {
                     const vf2 g = vfma2((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1]), mk2(qc[s][0], qc[s][1]), hj);
-                    const vf2 pbs = g * bc_hi(P[s]);
+                    pbs = g * bc_hi(P[s]);
                     if constexpr (MSUM) {
                         pb2[s] = pbs;
-                    } else {
+                    } else if constexpr (!LSUM) {
                         pb[2 * s] = lo2(pbs);
                         pb[2 * s + 1] = hi2(pbs);
                     }
@@ -944,6 +992,14 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                     S2[s] = vfma2(A2j, r, S2[s]);
                     dAj = vfma2(bc_lo(P[s]), r, dAj);
                     hj = a[s] * g;
+                }
+                if constexpr (LSUM) {
+                    lsum_put2_step(s, pbs);
+                    if (s == 4) {       // dB of steps 4-7 is on its way; dC of steps 4-7 (fetched at the end of the forward sweep) has arrived
+                        rawC = lsum_fetch(t_x);
+                        lds_write(t_dbc, lsum_slot + 4 * SCANT_BC_ROW + 2 * j + N, lsum_total(rawB));
+                    }
+                    if (s == 0) rawD = lsum_fetch(t_x);
                 }
             }
             AUM_SCHED_FENCE();
@@ -961,7 +1017,11 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                 AUM_SCHED_FENCE();
                 wave_sum_mfma_add16(wacc, 1, wsel, pb2);
             }
-            if constexpr (!MSUM) {
+            if constexpr (LSUM) {
+                lds_write(t_dbc, lsum_slot + 4 * SCANT_BC_ROW + 2 * j, lsum_total(rawC));
+                lds_write(t_dbc, lsum_slot + 2 * j, lsum_total(rawD));
+            }
+            if constexpr (!MSUM && !LSUM) {
                 vf dBsum;
                 if (AUM_SCANT_BABL & 1) {
                     dBsum = pb[0] + pb[7];

@@ -1203,6 +1203,96 @@ AUM_DEV vf wave_sum32(vf (&v)[32]) {
 #endif
 
 // ------------------------------------------------------------------------------------------------
+// Sums over the 64 lanes THROUGH LDS (round 5).  A transposing butterfly is two vector-ALU instructions per value, each a half-rate DPP
+// add (profiles/r04_valu_probe.txt: 2.3 SIMD-ns against 1.2 for a plain add), on the pipe that bounds the time-serial backward scan.
+// The same transposition through a per-wave LDS tile costs the vector ALU 7 instructions per EIGHT values:
+//   put     a lane parks value v of its own channel at float index v * 64 + lane (value-major: a ds_write_b32 whose 64 lanes are 256
+//           contiguous bytes -- conflict-free; two values 256 bytes apart leave as one ds_write2st64_b32);
+//   fetch   lane l takes value l >> 3, channels 8 (l & 7) .. + 7: the 32 contiguous bytes at l * 32, as two ds_read_b128.  A 16-byte read
+//           is served 16 lanes at a time over 64 banks; lanes i and i + 8 of a service group would meet in the same four banks, so lanes
+//           with bit 3 set read their halves in the opposite order (every service group then covers all 64 banks exactly once);
+//   total   3 packed adds + 1 add inside the lane, then three DPP adds inside the 8-lane group (quad_perm xor 1, xor 2,
+//           row_half_mirror): all 8 lanes of group v hold the 64-channel total of value v.
+// The LDS executes a wave's instructions in order, so a tile is reused as soon as its fetch has been ISSUED.  Tile: 8 x 64 floats.
+// ------------------------------------------------------------------------------------------------
+constexpr int LSUM_TILE_FLOATS = 8 * WAVE;
+struct LsumRaw { vf f[8]; };
+#ifdef AUM_EMU
+inline unsigned lsum_put_addr(float*) { return 0; }
+template <int V> inline void lsum_put2(float* tile, unsigned, const vf2& p) {
+    AUM_LANES { tile[V * WAVE + l] = p.x.v[l]; tile[(V + 1) * WAVE + l] = p.y.v[l]; }
+}
+inline LsumRaw lsum_fetch(const float* tile) {
+    LsumRaw r;
+    AUM_LANES {
+        const int first = ((l >> 3) & 1) * 4;
+        for (int k = 0; k < 4; ++k) {
+            r.f[k].v[l] = tile[l * 8 + first + k];
+            r.f[4 + k].v[l] = tile[l * 8 + (first ^ 4) + k];
+        }
+    }
+    return r;
+}
+inline vf lsum_total(const LsumRaw& r) {
+    const vf a0 = r.f[0] + r.f[2], a1 = r.f[1] + r.f[3], b0 = r.f[4] + r.f[6], b1 = r.f[5] + r.f[7];
+    const vf t = (a0 + b0) + (a1 + b1);
+    vf t1, t2, t3;
+    AUM_LANES t1.v[l] = t.v[l] + t.v[l ^ 1];
+    AUM_LANES t2.v[l] = t1.v[l] + t1.v[l ^ 2];
+    AUM_LANES t3.v[l] = t2.v[l] + t2.v[(l & ~7) | (7 - (l & 7))];
+    return t3;
+}
+#else
+#ifndef AUM_LSUM_PUT_ASM
+#define AUM_LSUM_PUT_ASM 0
+#endif
+// addr: the LDS byte address of this lane's float in row 0 of the tile (lsum_put_addr), used by the assembly form only
+AUM_DEV unsigned lsum_put_addr(float* tile) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)tile + (threadIdx.x & 63u));
+#else
+    return 0;
+#endif
+}
+template <int V> AUM_DEV void lsum_put2(float* tile, unsigned addr, vf2 p) {
+#ifdef __HIP_DEVICE_COMPILE__
+    if (AUM_LSUM_PUT_ASM) {
+        // one ds_write2st64_b32 (rows 256 bytes apart).  Written out: hipcc leaves the pair as two ds_write_b32 in this kernel (it merges
+        // the same pair in a small one).  The compiler does not count this in lgkmcnt: its own waits then cover at least what they name.
+        asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(p.x), "v"(p.y), "n"(V), "n"(V + 1) : "memory");
+    } else {
+        const int l = (int)(threadIdx.x & 63u);
+        tile[V * WAVE + l] = p.x;
+        tile[(V + 1) * WAVE + l] = p.y;
+    }
+#endif
+}
+template <int CTRL> AUM_DEV vf dpp_take(vf x) {      // every lane has a source lane under CTRL
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+AUM_DEV LsumRaw lsum_fetch(const float* tile) {
+    const int l = (int)(threadIdx.x & 63u);
+    const int first = l * 32 + ((l >> 3) & 1) * 16;
+    const aum_f4 a = *reinterpret_cast<const aum_f4*>(reinterpret_cast<const char*>(tile) + first);
+    const aum_f4 b = *reinterpret_cast<const aum_f4*>(reinterpret_cast<const char*>(tile) + (first ^ 16));
+    LsumRaw r;
+    r.f[0] = a.x; r.f[1] = a.y; r.f[2] = a.z; r.f[3] = a.w;
+    r.f[4] = b.x; r.f[5] = b.y; r.f[6] = b.z; r.f[7] = b.w;
+    return r;
+}
+AUM_DEV vf lsum_total(const LsumRaw& r) {
+    const vf2 a = mk2(r.f[0], r.f[1]) + mk2(r.f[2], r.f[3]), b = mk2(r.f[4], r.f[5]) + mk2(r.f[6], r.f[7]);
+    const vf2 c = a + b;
+    vf t = lo2(c) + hi2(c);
+    // (old = 0 with bound_ctrl: the form the compiler folds into ONE v_add_f32_dpp; with old = src it stays a move + DPP move + add)
+    t = t + dpp_take<0xB1>(t);         // quad_perm [1,0,3,2]
+    t = t + dpp_take<0x4E>(t);         // quad_perm [2,3,0,1]
+    t = t + dpp_take<0x141>(t);        // row_half_mirror: the other quad of the 8-lane group (its four lanes hold the same sum)
+    return t;
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // Sums over the 64 lanes on the MATRIX pipe (round 4).  The time-serial backward scan is bound by the vector ALU and a quarter of its
 // instructions were the two transposing butterflies of a pass (wave_sum16: 2 instructions per value + the serial tail through the
 // swaps); the matrix pipe of the SIMD idles.  v_mfma_f32_16x16x32_bf16 computes D[i][j] = sum_k A[i][k] B[k][j] with k = 8 g + e spread

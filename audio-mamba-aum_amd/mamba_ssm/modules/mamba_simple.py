@@ -84,8 +84,8 @@ class Mamba(nn.Module):
         return p
 
     # ---- forward (MS:169-311) ---------------------------------------------------------------------
-    def forward(self, hidden_states, inference_params=None, time_reversed=False):
-        """MS:169.  `time_reversed` (extension, keyword only in practice): the block applied to the time-reversed sequence and reversed
+    def forward(self, hidden_states, inference_params=None, *, time_reversed=False):
+        """MS:169.  `time_reversed` (extension, keyword only): the block applied to the time-reversed sequence and reversed
         back, flip(forward(flip(h))), without the copies -- the odd layers of an `if_bidirectional` model (MM:623-638): every stage but
         the conv and the scan is token-wise, and those two take a direction flag."""
         conv_state = ssm_state = None
@@ -127,7 +127,7 @@ class Mamba(nn.Module):
                 # Bi-Bi's two pipelines are independent until their outputs are added; each is one-direction launches of 1 536 waves at
                 # the bench shape (half of what the time-serial kernels hold), so the second runs on a side stream next to the first
                 # (forward here; autograd runs each pipeline's backward on the stream its forward ran on).  AUM_V2_STREAMS=0: in line.
-                two = tm and ssi.v2_two_streams() and xz.is_cuda
+                two = tm and xz.is_cuda and ssi.v2_two_streams((self.conv1d_b.weight, self.x_proj_b.weight, self.dt_proj_b.weight))
                 if two:
                     main, side = torch.cuda.current_stream(xz.device), ssi.side_stream(xz.device)
                     side.wait_stream(main)

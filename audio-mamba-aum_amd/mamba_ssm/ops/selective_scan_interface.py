@@ -79,7 +79,7 @@ def step_cache(mixers, dtype):
                     and _hip_gemm_ok(lin.weight.new_empty(0, dtype=dtype), lin.weight.shape[1], lin.weight.shape[0]))
                 groups.setdefault((want_t, tuple(lin.weight.shape), lin.weight.device), []).append(lin.weight)
         a_logs += [p for p in (getattr(m, "A_log", None), getattr(m, "A_b_log", None)) if p is not None]
-    mine = []
+    mine, a_ptrs = [], []
     _DA_XA.clear()
     with torch.no_grad():
         for (want_t, shape, dev), ps in groups.items():
@@ -97,11 +97,14 @@ def step_cache(mixers, dtype):
             for i, p in enumerate(ps):
                 _STEP_CACHE[id(p)] = ("A", A[i], None)
                 mine.append(id(p))
+                a_ptrs.append(A[i].data_ptr())
+    _A_CACHE_PTRS.update(a_ptrs)
     try:
         yield
     finally:
         for k in mine:                      # only this context's entries: another model's forward may be open around this one
             _STEP_CACHE.pop(k, None)
+        _A_CACHE_PTRS.difference_update(a_ptrs)
 
 
 def _cast(w, dtype):
@@ -125,6 +128,17 @@ def _cast_t(w, dtype):
 # be reused while the entry lives; a gradient that is not that very tensor (summed with another use of A, copied) misses and is
 # multiplied as before.  Entries nobody claimed are dropped when the next forward opens its cache.
 _DA_XA = {}
+_A_CACHE_PTRS = set()           # storage addresses of the A / A_b tensors the open step caches hold (what neg_exp hands out)
+
+
+def _da_xa_put(dA, prod, A):
+    if not _DA_XA:
+        # unclaimed entries (and the (E, N) tensors they pin) go when this backward pass ends, not when the next forward opens a cache
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_DA_XA.clear)
+        except RuntimeError:
+            pass                 # not inside a backward pass (a test calling the block's backward helper directly): step_cache() clears
+    _DA_XA[dA.data_ptr()] = (dA, prod, A)
 
 
 class _NegExpFn(torch.autograd.Function):
@@ -370,22 +384,52 @@ def _mm_rows(a, b, bit):
 # gradients (token-contiguous operands) and everything that does not qualify stay library GEMMs.
 _V2_STREAMS = _dbg_env("AUM_V2_STREAMS", "1") != "0"        # Bi-Bi: the second pipeline on a side stream (mamba_simple.py); 0: in line (A/B)
 _side_streams = {}
+_main_streams = {}
+_DDP_STREAM_JOIN = False        # set by ddp_join_streams_hook: the gradient exchange waits for BOTH backward streams
 
 
-def v2_two_streams():
-    """Bi-Bi's second pipeline on a side stream?  Not under data parallelism: DistributedDataParallel's reducer orders a bucket's all-reduce
-    behind the stream of the LAST gradient hook only, and with two backward streams a bucket holds gradients of both."""
+def v2_two_streams(params=()):
+    """Bi-Bi's second pipeline on a side stream?  Autograd runs each pipeline's backward on the stream of its forward, so anything that
+    consumes a parameter gradient INSIDE backward sees two producer streams.  DistributedDataParallel's reducer orders a bucket's
+    all-reduce behind the stream of the LAST gradient hook only, and a bucket holds gradients of both pipelines: under an initialised
+    process group (any world size) the side stream is used only when the gradient exchange goes through `ddp_join_streams_hook`
+    (aum.train.compress_gradients and bench.py register it), which makes the exchange wait for both streams.  Parameters that carry
+    post-accumulate-grad hooks (FSDP, user hooks: `params`, the side pipeline's) keep the pipelines in line as well."""
     if not _V2_STREAMS:
         return False
     import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    if dist.is_available() and dist.is_initialized() and not _DDP_STREAM_JOIN:
+        return False
+    return not any(getattr(p_, "_post_accumulate_grad_hooks", None) for p_ in params)
 
 
 def side_stream(device):
     s = _side_streams.get(device)
     if s is None:
         s = _side_streams[device] = torch.cuda.Stream(device=device)
+    _main_streams[device] = torch.cuda.current_stream(device)       # the stream the other pipeline (and its backward) runs on
     return s
+
+
+def ddp_join_streams_hook(hook=None):
+    """A DistributedDataParallel communication hook that first makes the CURRENT stream (the one the reducer orders the bucket's
+    collective behind) wait for the other stream Bi-Bi's backward runs on, then hands the bucket to `hook` (default: the plain
+    all-reduce + mean).  Registering it is what allows v2_two_streams() under a process group.  TT:39, TT:168."""
+    global _DDP_STREAM_JOIN
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    inner = hook or default_hooks.allreduce_hook
+
+    def joined(state, bucket):
+        buf = bucket.buffer()
+        if buf.is_cuda:
+            cur = torch.cuda.current_stream(buf.device)
+            for s in (_side_streams.get(buf.device), _main_streams.get(buf.device)):
+                if s is not None and s != cur:
+                    cur.wait_stream(s)
+        return inner(state, bucket)
+
+    _DDP_STREAM_JOIN = True
+    return joined
 
 
 _XDT_BWD_HIP = _dbg_env("AUM_XDT_BWD_LIB", "0") != "1"      # AUM_DEBUG=1 AUM_XDT_BWD_LIB=1: the x_proj / dt_proj gradients as five library calls (A/B)
@@ -570,7 +614,9 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
                                          reverse if A_b is None else False, A_b=A_b, want_out_pre=need_bwd, ckpt=ckpt,
                                          segments=tm_segments(Bsz, E, L, A_b is not None, False) if cut else 1)
     ctx.tm_cut = cut
-    ctx.A_cached = bool(_STEP_CACHE) and need_bwd and A.dtype == torch.float32 and A.is_contiguous() and (A_b is None or A_b.is_contiguous())
+    # the scan backward forms d A .* A only for an A that neg_exp took out of THIS forward's cache (its _NegExpFn node is the consumer)
+    ctx.A_cached = (need_bwd and A.dtype == torch.float32 and A.is_contiguous() and A.data_ptr() in _A_CACHE_PTRS
+                    and (A_b is None or (A_b.is_contiguous() and A_b.data_ptr() in _A_CACHE_PTRS)))
     ctx.tm = True
     ctx.delta_softplus, ctx.reverse = delta_softplus, reverse
     ctx.has_out_proj = out_proj_weight is not None
@@ -611,9 +657,9 @@ def _inner_backward_tm(ctx, dout):
                             segments=tm_segments(Bsz, E, L, A_b is not None, True) if ctx.tm_cut else 1,
                             want_dA_xA=ctx.A_cached)                                           # SSI:541-561
     if ctx.A_cached:            # A came out of the forward's cache (neg_exp): its d A_log is ready (see _NegExpFn)
-        _DA_XA[g["dA"].data_ptr()] = (g["dA"], g["dA_xA"], A)
+        _da_xa_put(g["dA"], g["dA_xA"], A)
         if A_b is not None:
-            _DA_XA[g["dA_b"].data_ptr()] = (g["dA_b"], g["dA_b_xA"], A_b)
+            _da_xa_put(g["dA_b"], g["dA_b_xA"], A_b)
     du2, ddelta2 = g["du"].view(Bsz * L, E), g["ddelta"].view(Bsz * L, E)
     dbc2 = g["dBC"].view(Bsz * L, 2 * N)
     conv2d = conv_out.view(Bsz * L, E)
@@ -621,8 +667,13 @@ def _inner_backward_tm(ctx, dout):
         # SSI:570-574, 587, 590 in one pass over ddelta and du (aum_xdt_tm_bwd); the two weight gradients on the skinny form of the
         # weight-gradient kernel (aum_gemm_wgrad, k = 48 / 80): every activation tensor is read once per product
         dx_dbl = aum_hip.xdt_tm_bwd(ddelta2, dbc2, w_dt_t, w_x_t, du2)
-        ddelta_proj_weight = aum_hip.gemm_wgrad(ddelta2, x_dbl[:, :R])                       # SSI:586  (E, R) fp32
-        dx_proj_weight = aum_hip.gemm_wgrad(conv2d, dx_dbl).t().contiguous()                 # SSI:589  (R + 2N, E) fp32
+        # (a shape the kernel's own argument check would refuse -- e.g. a token split beyond 32-bit byte offsets -- takes the library's
+        # split-K products instead of raising inside backward)
+        splits = _pick_splits(Bsz * L, _WGRAD_SPLITS[1])
+        ddelta_proj_weight = (aum_hip.gemm_wgrad(ddelta2, x_dbl[:, :R]) if aum_hip.gemm_wgrad_supported(ddelta2, x_dbl[:, :R])
+                              else split_k_wgrad(ddelta2.t(), x_dbl[:, :R], splits, torch.float32))          # SSI:586  (E, R) fp32
+        dx_proj_weight = (aum_hip.gemm_wgrad(conv2d, dx_dbl).t().contiguous() if aum_hip.gemm_wgrad_supported(conv2d, dx_dbl)
+                          else split_k_wgrad(dx_dbl.t(), conv2d, splits, torch.float32))                     # SSI:589  (R + 2N, E) fp32
     else:
         dx_dbl = torch.empty_like(x_dbl)
         dx_dbl[:, R:].copy_(dbc2)                                                            # SSI:570-574

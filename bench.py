@@ -43,8 +43,8 @@ def pmc_record(kind, kernel):
 
 def gemm_probe(dev, ntok, d_model, d_inner, iters=20):
     """the largest GEMM of the step, in_proj forward [ntok, d_model] x [d_model, 2 d_inner] in bf16, timed on the spot (HIP events on
-    the current stream) against the dense MFMA peak: the kernel the step runs (aum_gemm_tn, hand-written MFMA; the library GEMM under
-    default dispatch for this shape) and, next to it, the library GEMM it replaced"""
+    the current stream) against the dense MFMA peak: the kernel the step runs for this shape (aum_gemm_tn, the hand-written MFMA kernel,
+    under the default dispatch) and, next to it, the library GEMM (hipBLASLt with the recorded TunableOp pick) on the same operands"""
     import aum_hip
     import mamba_ssm.ops.selective_scan_interface as ssi
     a = torch.randn(ntok, d_model, device=dev).bfloat16()
@@ -102,7 +102,7 @@ def scan_alg_bytes(meta, backward):
     return 8 * T * s + bc + 2 * batch * dstate * length * 4         # u, delta, z, dout, out_pre, du, ddelta, dz; dB, dC
 
 
-def cpu_baseline(target_seconds=20.0):
+def cpu_baseline(target_seconds=6.0):
     """The oracle (C restatement of the reference's *_ref arithmetic, oracle/) timed on the host cores: one AuM-Base
     Fo-Bi block (fused add+RMSNorm, in_proj, conv, x/dt proj, two scans, out_proj) forward + backward on a few clips,
     scaled by the 24 blocks of the model.  Reported, never a target."""
@@ -149,13 +149,12 @@ def cpu_baseline(target_seconds=20.0):
                       f"(L=513), median of {reps} runs = {t_block:.2f} s/block, scaled x24 blocks"}
 
 
-def cpu_baseline_torch_ref(budget_s=120.0):
+def cpu_baseline_torch_ref(budget_s=30.0):
     """The baseline north_star names: the reference's pure-PyTorch `selective_scan_ref` (SSI:86-152: an O(L) Python loop over a
     materialised [B,E,L,N] tensor) -- here the package's restatement of it, same loop -- on the host cores: BOTH scan directions of one
     AuM-Base Fo-Bi block (all 1536 channels, L = 513, N = 16, one clip), forward + autograd backward, composed as SSI:499-507 composes
-    them (flip, scan, flip, add); scaled by the 24 blocks.  The scans only (no projections, conv, norm).  Thread count: the faster of
-    16 / 32 / all on a quarter-size probe (the loop is ~1500 small ops per pass: beyond a few dozen threads they only add synchronisation);
-    one warm-up, then the median of three runs (fewer if a run exceeds the time budget: said in `sample`)."""
+    them (flip, scan, flip, add); scaled by the 24 blocks.  The scans only (no projections, conv, norm).  16 host threads; one quarter-size
+    warm-up, then the median of up to three full-size runs (as many as fit the time budget: said in `sample`)."""
     import torch as T
     from mamba_ssm.ops.selective_scan_interface import selective_scan_ref
     T.manual_seed(0)
@@ -177,27 +176,24 @@ def cpu_baseline_torch_ref(budget_s=120.0):
         o.sum().backward()
         return time.time() - t0
 
-    probe, best = make(E // 4), None
-    for thr in sorted({min(16, n_thr), min(32, n_thr), n_thr}):
-        T.set_num_threads(thr)
-        t = block(probe)
-        if best is None or t < best[1]:
-            best = (thr, t)
-    T.set_num_threads(best[0])
+    # Frozen since round 4: the same workload and thread rule every round.  16 threads (the loop is ~1500 small ops per
+    # pass: beyond a few dozen threads they only add synchronisation -- 16 was the fastest of 16 / 32 / all on every box of rounds 3-4),
+    # one quarter-size warm-up, then full-size runs while they fit the budget (one run is ~25 s: the default bench stays under a minute).
+    thr = min(16, n_thr)
+    T.set_num_threads(thr)
+    warm = block(make(E // 4))
     d = make(E)
-    warm = block(d)
-    runs = []
-    spent = warm
+    runs, spent = [], warm
     while len(runs) < 3 and (not runs or spent + runs[-1] < budget_s):
         runs.append(block(d))
         spent += runs[-1]
     t_blk = sorted(runs)[len(runs) // 2]
     T.set_num_threads(n_thr)
-    return {"value": round(Bc / (24 * t_blk), 5), "unit": "clips/s", "cores": best[0], "kind": "port",
-            "sample": f"torch selective_scan_ref loop (package restatement of SSI:86-152, fp32, torch {T.__version__}, {best[0]} of {os.cpu_count()} "
-                      f"host threads: fastest of a quarter-size probe): both scan directions of 1 of 24 AuM-Base Fo-Bi blocks, all {E} channels, "
-                      f"forward + autograd backward on {Bc} clip (L=513, N=16): 1 warm-up ({warm:.1f} s) + median of {len(runs)} runs = {t_blk:.2f} s, "
-                      "x24 blocks; scans only (no projections, conv, norm)"}
+    return {"value": round(Bc / (24 * t_blk), 5), "unit": "clips/s", "cores": thr, "kind": "port",
+            "sample": f"torch selective_scan_ref loop (package restatement of SSI:86-152, fp32, torch {T.__version__}, {thr} of {os.cpu_count()} "
+                      f"host threads): both scan directions of 1 of 24 AuM-Base Fo-Bi blocks, all {E} channels, "
+                      f"forward + autograd backward on {Bc} clip (L=513, N=16): quarter-size warm-up ({warm:.1f} s) + median of {len(runs)} full-size "
+                      f"run(s) = {t_blk:.2f} s, x24 blocks; scans only (no projections, conv, norm)"}
 
 
 def step_alg_bytes(batch, length, d_model, depth, s=2):
@@ -246,7 +242,15 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # AUM_BENCH_FORCE_DDP=1: the data-parallel path (RCCL process group, DistributedDataParallel reducer with bucket views, the gradient
+    # exchange hook) at world size 1 -- a one-GPU box then runs everything of the N > 1 step except the wire
+    force_ddp = os.environ.get("AUM_BENCH_FORCE_DDP", "0") == "1"
+    if world == 1 and force_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_ddp:
         import torch.distributed as dist
         backend = os.environ.get("AUM_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm (xGMI within the node); gloo = dry run
         if backend == "nccl":
@@ -262,7 +266,7 @@ def main():
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-7, betas=(0.95, 0.999), eps=1e-8,
                            fused=True)                                         # TT:32-34
     net = model
-    if world > 1:
+    if dist is not None:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], gradient_as_bucket_view=True,
                                                         bucket_cap_mb=64, broadcast_buffers=False)
         from aum.train import compress_gradients
@@ -366,6 +370,14 @@ def main():
             roof["alg_bytes_per_launch"] = alg
             roof["achieved"] = round(alg / (rec["avg_ms"] * 1e-3) / 1e9, 1)
             roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBPS, 4)
+            if "bwd" in dom:
+                # SURVEY.md 8(d)'s own figure for the backward also counts `out` and the state checkpoints (s (9T + 2BNL) + 4 (2BNL) + ckpt =
+                # 926.6 MB at the bench shape); `achieved` above uses the tensors this design's kernel has to touch (no `out`: the gate is
+                # recomputed from out_pre).  Both, so that either definition can be read off the line.
+                batch, dim, length, dstate, es, _ = rec["meta"]
+                alg8d = alg + batch * dim * length * es + batch * dim * ((length + 2047) // 2048) * 2 * dstate * 4
+                roof["alg_bytes_per_launch_survey_8d"] = alg8d
+                roof["frac_survey_8d"] = round(alg8d / (rec["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         roof["traffic"], roof["traffic_provenance"] = pmc_record("pmc_traffic", dom)      # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE passes
         if alg is not None:
             roof["frac_of_measured_copy_rate"] = round(roof["achieved"] / HBM_COPY_GBPS, 4)      # 6.29 TB/s float4 copy (MI355X_MICROARCH.md)
@@ -408,7 +420,7 @@ def main():
                                    "fwd+bwd+Adam, bf16 autocast / fp32 master weights"
                                    + ("" if args.no_frontend else ", input = 160000-sample waveforms through the one-launch HIP frontend (log-mel + 16x16 patch embedding + position rows)"),
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch,
-                       "parallelism": f"dp{world}" + (" (DDP, RCCL all-reduce overlapped with backward)" if world > 1 else "")},
+                       "parallelism": f"dp{world}" + (" (DDP, RCCL all-reduce overlapped with backward)" if dist is not None else "")},
             "roofline": roof,
             "roofline_forward_kernel": fwd_roof,
             "roofline_gemm": gemm_roof,

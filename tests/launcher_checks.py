@@ -35,6 +35,51 @@ def check_fused_augmentation(device):
     assert torch.allclose(wav2fbank_ragged(wave_b, torch.tensor(lens, device=device), tabs, target_length=T_), plain, atol=1e-6)
 
 
+def check_fused_augmentation_vs_oracle(device):
+    """f3 against an INDEPENDENT statement: raw uniform draws from numpy go (i) through
+    aum.augment.pack_augmentation into the log-mel kernel's fused store and (ii) with the un-normalised, un-augmented log-mel of the same
+    clips through oracle/augment.py -- DL:206-228 and torchaudio's mask_along_axis rule restated in numpy, clip by clip.  (Still
+    "unpinned": torchaudio itself is not in the image.)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import augment as OA
+    from aum.frontend import FbankTables, wav2fbank_ragged, AUDIOSET_MEAN, AUDIOSET_STD
+    from aum.augment import pack_augmentation
+    tabs = FbankTables(device)
+    rng = np.random.default_rng(21)
+    lens = [5200, 3000, 4100, 5200, 300, 4800]
+    Bn, T_, F_ = len(lens), 32, 128
+    wave = np.zeros((Bn, 5200), np.float32)
+    for i, n in enumerate(lens):
+        w = rng.standard_normal(n).astype(np.float32) * 0.1
+        wave[i, :n] = w - w.mean()
+    wave_t, lens_t = torch.tensor(wave, device=device), torch.tensor(lens, device=device)
+    plain = wav2fbank_ragged(wave_t, lens_t, tabs, target_length=T_).double().cpu().numpy()       # normalised, padded rows = pad fill
+    raw = plain * (2 * AUDIOSET_STD) + AUDIOSET_MEAN                                               # un-normalised: padded rows -> 0
+    for freqm, timem, noise in ((24, 10, True), (48, 0, False), (0, 20, True), (0, 0, True)):
+        d = {k: rng.random(Bn) for k in ("u_fv", "u_fm", "u_tv", "u_tm", "u_amp")}
+        field, shift = rng.random((Bn, T_, F_)), rng.integers(-10, 10, Bn)
+        tt = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
+        kw = {}
+        if freqm:
+            kw.update(u_fv=tt(d["u_fv"]), u_fm=tt(d["u_fm"]))
+        if timem:
+            kw.update(u_tv=tt(d["u_tv"]), u_tm=tt(d["u_tm"]))
+        if noise:
+            kw.update(u_amp=tt(d["u_amp"]), field=tt(field), shift=torch.tensor(shift, device=device))
+        aug, nz = pack_augmentation(T_, F_, freqm, timem, **kw)
+        got = wav2fbank_ragged(wave_t, lens_t, tabs, target_length=T_, aug=aug, noise=nz).double().cpu().numpy()
+        masked_any = False
+        for b in range(Bn):
+            # the oracle sees the float32 draws the kernel's table was built from (the band limits are floors of products of them)
+            draws = {k: float(np.float32(d[k][b])) for k in d}
+            draws.update(field=field[b].astype(np.float32), shift=int(shift[b]))
+            want = OA.augment_clip(raw[b], draws, freqm, timem, noise, AUDIOSET_MEAN, AUDIOSET_STD)
+            assert np.abs(got[b] - want).max() < 2e-5, (freqm, timem, noise, b, float(np.abs(got[b] - want).max()))
+            masked_any = masked_any or bool(np.abs(want - plain[b]).max() > 0.1)
+        assert masked_any
+
+
 def check_training_loop(tmp_path, monkeypatch):
     """aum.train.train against the reference's own src/traintest.py `train` (golden/launcher.npz, generated by
     tests/golden/make_golden.py::launcher_goldens): Adam with batch-scaled betas / eps (TT:25-33), the warm-up stairs that start

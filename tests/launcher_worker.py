@@ -10,7 +10,8 @@ import aum_hip  # noqa: E402
 import build_emu  # noqa: E402
 
 if __name__ == "__main__":
-    aum_hip._product = aum_hip.Lib(build_emu.build(), host=True)
+    if os.environ.get("AUM_TEST_PRODUCT_LIB") != "1":      # tests/test_gpu_ddp.py runs the same worker on the product library
+        aum_hip._product = aum_hip.Lib(build_emu.build(), host=True)
     import json
     from aum import train
     # tests only: make the loss of rank AUM_TEST_NAN_RANK non-finite at the listed training steps (test_launcher_two_ranks_gloo_nan_steps)

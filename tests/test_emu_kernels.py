@@ -303,3 +303,15 @@ def test_gemm_wgrad_contract(emu, case):
 def test_decode_kernels_contract(emu, dtype):
     """the host twins of the per-token kernels (tests/emu/aum_emu.cpp) against the reference's step arithmetic in fp64"""
     KC.check_decode_kernels(emu, "cpu", dtype)
+
+
+@pytest.mark.skipif(os.environ.get("AUM_TEST_VARIANTS") != "1", reason="opt-in build variant (a second 5-minute lane-array build): AUM_TEST_VARIANTS=1")
+@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
+def test_scan_tm_backward_lds_channel_sums_variant(mode):
+    """-DAUM_SCANT_LSUM=1 (round 5, measured slower and not the default: profiles/r05_ab_lsum.txt): the dB / dC channel sums of the
+    time-serial backward through the per-wave LDS transposition tile (wave.h lsum_*) -- same oracle bars as the butterflies"""
+    import build_emu
+    lib = aum_hip.Lib(build_emu.build(("-DAUM_SCANT_LSUM=1",), "_lsum1"), host=True)
+    for case in cases.SCAN_TM_CASES[:4]:
+        for dt in (torch.bfloat16, torch.float16):
+            KC.check_scan_tm(lib, "cpu", case, dt, reverse=(mode == "rev"), bidir=(mode == "bidir"), xz_layout=True, backward=True)

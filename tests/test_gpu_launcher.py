@@ -33,3 +33,8 @@ def test_checkpoint_regrid_matches_reference_constructor_gpu():
 def test_fused_augmentation_matches_separate_ops_gpu():
     """f3: SpecAug bands, noise and roll inside aum_fbank_fwd's store against the separate torch ops after the kernel"""
     launcher_checks.check_fused_augmentation("cuda")
+
+
+def test_fused_augmentation_matches_independent_oracle_gpu():
+    """f3 against oracle/augment.py (numpy restatement of DL:206-228 + torchaudio's mask_along_axis rule) for fixed raw draws"""
+    launcher_checks.check_fused_augmentation_vs_oracle("cuda")

@@ -433,9 +433,23 @@ def test_aum_base_headline_bench_batch_bf16_vs_reference(gemm_mode, monkeypatch)
     model, d, g = _headline_model(case)
     reps = 64
     x = torch.tensor(d["x"], device=DEV).repeat(reps, 1, 1)
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        lb = model(x)
-    (lb.float() * torch.tensor(d["dlogits"], device=DEV)).sum().backward()
+    import aum_hip
+    aum_hip.timer.reset()
+    aum_hip.timer.only, aum_hip.timer.enabled = {"gemm_tn"}, True
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lb = model(x)
+        n_fwd = aum_hip.timer.summary().get("gemm_tn", {"launches": 0})["launches"]
+        (lb.float() * torch.tensor(d["dlogits"], device=DEV)).sum().backward()
+        n_all = aum_hip.timer.summary().get("gemm_tn", {"launches": 0})["launches"]
+    finally:
+        aum_hip.timer.enabled, aum_hip.timer.only = False, None
+        aum_hip.timer.reset()
+    # the mode really selects the kernel: per block aum_gemm_tn runs in_proj + out_proj forward and both data
+    # gradients under `hip`, the shapes of ssi._HIP_GEMM_FASTER under `auto`, nothing under `lib`
+    per_block_fwd = {"lib": 0, "hip": 2, "auto": sum(1 for sh in ((3072, 768), (768, 1536)) if sh in ssi._HIP_GEMM_FASTER)}[gemm_mode]
+    per_block_bwd = {"lib": 0, "hip": 2, "auto": sum(1 for sh in ((1536, 768), (768, 3072)) if sh in ssi._HIP_GEMM_FASTER)}[gemm_mode]
+    assert n_fwd == depth * per_block_fwd and n_all - n_fwd == depth * per_block_bwd, (gemm_mode, n_fwd, n_all)
     ref = g[name + ".logits"]
     rows = [lb[i:i + 1].float().detach().cpu().numpy() for i in (0, 1, 31, 63)]
     e_rows = [rel_err(r, ref) for r in rows]
@@ -502,3 +516,89 @@ def test_aum_small_headline_forward_bf16_vs_reference():
     assert e32 < 1e-3, e32
     assert e16 < 1.5 * r16, (e16, r16)          # bars: the reference's own bf16-to-fp32 distance (see the Base test above)
     assert p16 < 2.2 * r16, (p16, r16)
+
+
+def _run_block(m, x, w, autocast=True):
+    m.zero_grad()
+    xi = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        y = m(xi)
+    (y.float() * w).sum().backward()
+    torch.cuda.synchronize()
+    return y.detach().float(), xi.grad.detach().float(), {k: p.grad.detach().float().clone() for k, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize("btype", ["v1", "v2", "none"])
+def test_longform_block_dispatch_runs_on_time_segments(btype, monkeypatch):
+    """config 5's block shape through the MODULE: Mamba(768) at B = 8, L = 4097 under bf16 autocast.  The dispatch
+    must cut the rows into time segments (aum_scan_tm_seg_*: carry pass + main pass, checkpoints in the uncut layout handed from the
+    forward launch to the backward launch inside _inner_forward_tm / _inner_backward_tm); output, input gradient and every parameter
+    gradient against the channel-major block (AUM_TM_SEGMENTS=0: the chunk-parallel kernels, a different algorithm) at the bf16 bar, and
+    against the same block in fp32 on the channel-major kernels."""
+    import aum_hip
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    from conftest import rms_err
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(5)
+    B, L, Dm = 8, 4097, 768
+    m = Mamba(Dm, bimamba_type=btype, if_devide_out=btype == "v2").to(DEV)
+    x = torch.randn(B, L, Dm, device=DEV) * 0.5
+    w = torch.randn(B, L, Dm, device=DEV)
+    bidir = btype == "v1"
+    nseg = ssi.tm_segments(B, 2 * Dm, L, bidir, True)
+    assert nseg > 1 and ssi.token_major_preferred(B, 2 * Dm, btype != "none", training=True, seqlen=L)
+    calls = []
+    real_f, real_b = aum_hip.scan_tm_fwd, aum_hip.scan_tm_bwd
+    monkeypatch.setattr(aum_hip, "scan_tm_fwd", lambda *a, **k: (calls.append(("fwd", k.get("segments", 1))), real_f(*a, **k))[1])
+    monkeypatch.setattr(aum_hip, "scan_tm_bwd", lambda *a, **k: (calls.append(("bwd", k.get("segments", 1))), real_b(*a, **k))[1])
+    seg = _run_block(m, x, w)
+    n_pipe = 2 if btype == "v2" else 1
+    assert calls == [("fwd", nseg)] * n_pipe + [("bwd", nseg)] * n_pipe, calls
+    calls.clear()
+    monkeypatch.setattr(ssi, "_TM_SEGMENTS", 0)
+    assert not ssi.token_major_preferred(B, 2 * Dm, btype != "none", training=True, seqlen=L)
+    cm = _run_block(m, x, w)
+    assert calls == []                                                  # the channel-major block does not touch the token-major scans
+    f32 = _run_block(m, x, w, autocast=False)
+    errs = {}
+    for tag, other in (("vs_channel_major_bf16", cm), ("vs_channel_major_fp32", f32)):
+        e = {"y": [rel_err(seg[0].cpu().numpy(), other[0].cpu().numpy()), rms_err(seg[0].cpu().numpy(), other[0].cpu().numpy())],
+             "dx": [rel_err(seg[1].cpu().numpy(), other[1].cpu().numpy()), rms_err(seg[1].cpu().numpy(), other[1].cpu().numpy())]}
+        for k in seg[2]:
+            e[k] = [rel_err(seg[2][k].cpu().numpy(), other[2][k].cpu().numpy()), rms_err(seg[2][k].cpu().numpy(), other[2][k].cpu().numpy())]
+        errs[tag] = e
+    # what bf16 rounding of ONE block costs on the other kernels (the bar for the segmented ones: no worse than 2 x that, per tensor)
+    base = {"y": rms_err(cm[0].cpu().numpy(), f32[0].cpu().numpy()), "dx": rms_err(cm[1].cpu().numpy(), f32[1].cpu().numpy())}
+    base.update({k: rms_err(cm[2][k].cpu().numpy(), f32[2][k].cpu().numpy()) for k in seg[2]})
+    _err_report(f"longform_block.{btype}", {"segments": nseg, **{t: {k: v for k, v in e.items()} for t, e in errs.items()}, "cm_bf16_vs_fp32_rms": base})
+    for k, (mx, rms) in errs["vs_channel_major_fp32"].items():
+        assert rms < max(2.0 * base[k], 4e-3), (btype, k, rms, base[k])
+        assert mx < 8e-2, (btype, k, mx)
+    for k, (mx, rms) in errs["vs_channel_major_bf16"].items():
+        assert rms < max(3.0 * base[k], 6e-3), (btype, k, rms, base[k])
+
+
+def test_bibi_block_two_streams_bit_equal(monkeypatch):
+    """Bi-Bi (v2) at the bench's block shape: the second pipeline on the side stream vs both in line -- the same launches in the same
+    order per pipeline, so output and every gradient are bit-equal (the ordering between the streams rests on this test)."""
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(6)
+    B, L, Dm = 64, 513, 768
+    m = Mamba(Dm, bimamba_type="v2", if_devide_out=True).to(DEV)
+    x = torch.randn(B, L, Dm, device=DEV) * 0.5
+    w = torch.randn(B, L, Dm, device=DEV)
+    assert ssi.token_major_preferred(B, 2 * Dm, True, training=True, seqlen=L)
+    res = []
+    for two in (True, False, True):
+        monkeypatch.setattr(ssi, "_V2_STREAMS", two)
+        assert ssi.v2_two_streams() == two
+        res.append(_run_block(m, x, w))
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
+        for k in res[0][2]:
+            assert torch.equal(res[0][2][k], other[2][k]), k
+    # a parameter with a post-accumulate-grad hook (FSDP-style consumers of gradients inside backward) keeps the pipelines in line
+    h = m.conv1d_b.weight.register_post_accumulate_grad_hook(lambda p_: None)
+    assert not ssi.v2_two_streams((m.conv1d_b.weight,))
+    h.remove()

@@ -133,6 +133,11 @@ def test_fused_augmentation_matches_separate_ops():
     launcher_checks.check_fused_augmentation("cpu")
 
 
+def test_fused_augmentation_matches_independent_oracle():
+    """f3 against oracle/augment.py for fixed raw draws, on the lane-array build (GPU: tests/test_gpu_launcher.py)"""
+    launcher_checks.check_fused_augmentation_vs_oracle("cpu")
+
+
 def test_stats_against_sklearn():
     from sklearn import metrics
     from aum.stats import calculate_stats, summarize, d_prime
@@ -326,6 +331,31 @@ def test_launcher_two_ranks_gloo_nan_steps(toy_dataset, tmp_path):
     for r_ in (0, 1):    # 3 steps per rank, two of them skipped on BOTH ranks
         hs = json.load(open(exp + f"/host_syncs_rank{r_}.json"))
         assert hs["steps"] == 1, hs
+
+
+def test_launcher_forced_ddp_world1_gloo_nan_steps(toy_dataset, tmp_path):
+    """AUM_FORCE_DDP=1: process group, DistributedDataParallel wrapper, gradient-exchange hook and the MIN-reduced finite flag at world
+    size 1 (the form tests/test_gpu_ddp.py runs over RCCL on a one-GPU box), here over gloo on the lane-array build."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp = str(tmp_path / "exp_f")
+    cmd = [sys.executable, os.path.join(root, "tests", "launcher_worker.py"),
+           "--model_type", "tiny", "--depth", "1", "--n_class", "4", "--label-csv", str(toy_dataset / "labels.csv"),
+           "--data-train", str(toy_dataset / "train.json"), "--data-val", str(toy_dataset / "val.json"),
+           "--audio_length", "64", "--num-workers", "0", "-b", "2", "--mixed_precision", "no", "--exp-dir", exp,
+           "--n-epochs", "1", "--metrics", "acc", "--loss", "CE", "--if_nan2num", "False", "--if_continue_inf", "True"]
+    env = dict(os.environ, OMP_NUM_THREADS="2", AUM_FORCE_DDP="1", AUM_TEST_NAN_STEPS="1", AUM_TEST_NAN_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("Loss is not finite on some rank, continuing training") == 1, r.stdout[-2000:]
+    sd = torch.load(exp + "/models/best_audio_model.pth")
+    assert all(k.startswith("module.") for k in sd) and all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+    assert json.load(open(exp + "/host_syncs_rank0.json"))["steps"] == 4          # 5 steps, one skipped
 
 
 def test_tunableop_solution_file_is_seeded_per_rank(monkeypatch, tmp_path):
