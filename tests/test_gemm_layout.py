@@ -81,3 +81,61 @@ def test_xcd_tile_map_is_a_bijection():
         q, r = nwg >> 3, nwg & 7
         ids = sorted((x * (q + 1) if x < r else r * (q + 1) + (x - r) * q) + (o >> 3) for o in range(nwg) for x in [o & 7])
         assert ids == list(range(nwg)), nwg
+
+
+def test_w4_tile_product_and_bank_slots():
+    """the four-wave form (csrc/gemm_w4_kernels.h, AUM_GEMM_W4): 256 x 192 workgroup tile, wave (wr, wc) of a 2 x 2 grid owns 128 rows x 96
+    columns (8 x 6 accumulator fragments); pieces c = 4 j + w (8 of A, 6 of B per wave); the same swizzles, MFMA roles and store map"""
+    NJ = 6
+    rng = np.random.default_rng(1)
+    A = rng.integers(-3, 4, (256, 64)).astype(np.float64)
+    B = rng.integers(-3, 4, (32 * NJ, 64)).astype(np.float64)
+    lds_a, lds_b = np.full((256, 8, 8), np.nan), np.full((32 * NJ, 8, 8), np.nan)
+    for w in range(4):
+        for j in range(8):
+            for lane in range(64):
+                r, s = (j * 4 + w) * 8 + (lane >> 3), lane & 7
+                fa = ((w & 1) * 4 + (lane >> 4)) & 7                         # the kernel's per-lane constants (independent of j)
+                fb = ((w & 3) << 1) | ((lane >> 4) & 1)
+                assert fa == f_a(r) and fb == f_b(r)
+                lds_a[r, s] = A[r, (s ^ fa) * 8:(s ^ fa) * 8 + 8]
+                if j < NJ:
+                    lds_b[r, s] = B[r, (s ^ fb) * 8:(s ^ fb) * 8 + 8]
+    assert not np.isnan(lds_a).any() and not np.isnan(lds_b).any()           # every row of both tiles is staged exactly by these pieces
+    C = np.full((256, 32 * NJ), np.nan)
+    for wr in range(2):
+        for wc in range(2):
+            acc = np.zeros((8, NJ, 64, 4))
+            for kk in range(2):
+                af, bf = np.zeros((8, 64, 8)), np.zeros((NJ, 64, 8))
+                addr_a, addr_b = np.zeros((8, 64), int), np.zeros((NJ, 64), int)
+                for lane in range(64):
+                    kg, rho = lane >> 4, lane & 15
+                    xa = (kg ^ ((lane >> 1) & 7)) ^ (4 * kk)
+                    xb = (kg ^ ((((rho >> 2) & 3) << 1) | ((rho >> 1) & 1))) ^ (4 * kk)
+                    for i in range(8):
+                        row = wr * 128 + i * 16 + rho
+                        af[i, lane], addr_a[i, lane] = lds_a[row, xa], row * 128 + xa * 16
+                    for j in range(NJ):
+                        row = wc * 16 * NJ + (rho >> 2) * 8 + (j >> 1) * 32 + (j & 1) * 4 + (rho & 3)
+                        bf[j, lane], addr_b[j, lane] = lds_b[row, xb], row * 128 + xb * 16
+                for grp in GROUPS:
+                    for addrs in list(addr_a) + list(addr_b):
+                        assert len({(int(addrs[l]) % 256) // 16 for l in grp}) == 16
+                for i in range(8):
+                    for j in range(NJ):
+                        a_op, b_op = np.zeros((16, 32)), np.zeros((32, 16))
+                        for lane in range(64):
+                            a_op[lane & 15, (lane >> 4) * 8:(lane >> 4) * 8 + 8] = bf[j, lane]
+                            b_op[(lane >> 4) * 8:(lane >> 4) * 8 + 8, lane & 15] = af[i, lane]
+                        D = a_op @ b_op
+                        for lane in range(64):
+                            acc[i, j, lane] += D[(lane >> 4) * 4:(lane >> 4) * 4 + 4, lane & 15]
+            for i in range(8):
+                for lane in range(64):
+                    m = wr * 128 + i * 16 + (lane & 15)
+                    for jp in range(NJ // 2):          # one 16-byte store per fragment pair: columns wc * 96 + 32 jp + 8 kg .. + 7
+                        n = wc * 16 * NJ + jp * 32 + (lane >> 4) * 8
+                        C[m, n:n + 4] = acc[i, 2 * jp, lane]
+                        C[m, n + 4:n + 8] = acc[i, 2 * jp + 1, lane]
+    assert np.array_equal(C, A @ B.T)

@@ -76,6 +76,6 @@ def test_bench_forced_ddp_reports_rccl():
                         "--no-cpu-baseline", "--grad-compress", "bf16"], capture_output=True, text=True, timeout=900,
                        env=_env(AUM_BENCH_FORCE_DDP="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])      # (RCCL prints its library path at shutdown)
     assert line["dist"]["rccl"] is True and line["dist"]["world_size"] == 1 and line["dist"]["grad_exchange_dtype"] == "bf16"
     assert line["n_gpus"] == 1 and np.isfinite(line["final_loss"]) and line["dist"]["ddp_buckets"] >= 1
