@@ -192,7 +192,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_gemm_tn_w4(GemmLaunch L) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) mfma_acc<BF16>(acc[i][j], bf[1][j], af[1][i]);
         }
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // last MFMA -> vector-ALU reads of the accumulators (at most 18 wait states)
+        // last MFMA -> vector-ALU reads of the accumulators (at most 18 wait states); the last fragment row is named so that its reads
+        // cannot be scheduled in front of the wait (the rows before it are older than that anyway)
+        asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][NJ - 2]), "+a"(acc[7][NJ - 1]));
         // store: lane holds, for fragment row i, columns wc * 128 + 32 (j >> 1) + 8 kg + 4 (j & 1) + r (r = 0..3) of row wr * 128 + 16 i + rho
         char* c_rows = static_cast<char*>(g.c) + ((int64_t)it.m0 * g.ldc + it.n0 + wc * (16 * NJ) + kg * 8) * 2;
 #pragma unroll

@@ -139,3 +139,62 @@ def test_w4_tile_product_and_bank_slots():
                         C[m, n:n + 4] = acc[i, 2 * jp, lane]
                         C[m, n + 4:n + 8] = acc[i, 2 * jp + 1, lane]
     assert np.array_equal(C, A @ B.T)
+
+
+def test_ring_tile_product_and_bank_slots():
+    """the five-stage ring form (csrc/gemm_ring_kernels.h, AUM_GEMM_RING): one 32-deep K-step of a 256 x 192 tile.  LDS rows are 64 bytes
+    (four 16-byte slots), a DMA piece is 16 rows (lane l -> row 16 c + (l >> 2), physical slot l & 3, source slot ^ f(row));
+    f_A(row) = G[(row >> 2) & 3], f_B(row) = G[(row >> 3) & 3], G = {0, 3, 2, 1}: every ds_read_b128 service group covers the 16 slots
+    of a 256-byte bank row exactly once, and the MFMA / store maps give A . B^T"""
+    G, NJ = [0, 3, 2, 1], 6
+    rng = np.random.default_rng(2)
+    A = rng.integers(-3, 4, (256, 32)).astype(np.float64)
+    B = rng.integers(-3, 4, (32 * NJ, 32)).astype(np.float64)
+    lds_a, lds_b = np.full((256, 4, 8), np.nan), np.full((32 * NJ, 4, 8), np.nan)
+    for w in range(4):
+        for lane in range(64):
+            fa = G[(lane >> 4) & 3]                                          # the kernel's per-lane constants
+            fb = G[(2 * (w & 1) + (lane >> 5)) & 3]
+            for j in range(4):
+                r, p = (j * 4 + w) * 16 + (lane >> 2), lane & 3
+                assert fa == G[(r >> 2) & 3]
+                lds_a[r, p] = A[r, (p ^ fa) * 8:(p ^ fa) * 8 + 8]
+            for j in range(3):
+                r, p = (j * 4 + w) * 16 + (lane >> 2), lane & 3
+                assert fb == G[(r >> 3) & 3]
+                lds_b[r, p] = B[r, (p ^ fb) * 8:(p ^ fb) * 8 + 8]
+    assert not np.isnan(lds_a).any() and not np.isnan(lds_b).any()
+    C = np.full((256, 32 * NJ), np.nan)
+    for wr in range(2):
+        for wc in range(2):
+            af, bf = np.zeros((8, 64, 8)), np.zeros((NJ, 64, 8))
+            addr_a, addr_b = np.zeros((8, 64), int), np.zeros((NJ, 64), int)
+            for lane in range(64):
+                kg, rho = lane >> 4, lane & 15
+                slot = kg ^ G[rho >> 2]
+                for i in range(8):
+                    row = wr * 128 + i * 16 + rho
+                    assert G[(row >> 2) & 3] == G[rho >> 2]
+                    af[i, lane], addr_a[i, lane] = lds_a[row, slot], row * 64 + slot * 16
+                for j in range(NJ):
+                    row = wc * 16 * NJ + (rho >> 2) * 8 + (j >> 1) * 32 + (j & 1) * 4 + (rho & 3)
+                    assert G[(row >> 3) & 3] == G[rho >> 2]
+                    bf[j, lane], addr_b[j, lane] = lds_b[row, slot], row * 64 + slot * 16
+            for grp in GROUPS:
+                for addrs in list(addr_a) + list(addr_b):
+                    assert len({(int(addrs[l]) % 256) // 16 for l in grp}) == 16
+            for i in range(8):
+                for lane in range(64):
+                    pass
+            for i in range(8):
+                for j in range(NJ):
+                    a_op, b_op = np.zeros((16, 32)), np.zeros((32, 16))
+                    for lane in range(64):
+                        a_op[lane & 15, (lane >> 4) * 8:(lane >> 4) * 8 + 8] = bf[j, lane]
+                        b_op[(lane >> 4) * 8:(lane >> 4) * 8 + 8, lane & 15] = af[i, lane]
+                    D = a_op @ b_op
+                    for lane in range(64):
+                        m = wr * 128 + i * 16 + (lane & 15)
+                        n = wc * 16 * NJ + (j >> 1) * 32 + (lane >> 4) * 8 + (j & 1) * 4
+                        C[m, n:n + 4] = D[(lane >> 4) * 4:(lane >> 4) * 4 + 4, lane & 15]
+    assert np.array_equal(C, A @ B.T)
