@@ -25,7 +25,8 @@
 namespace aum {
 
 // timing experiments only (tools/build_variant.sh -DAUM_SCANT_ABL=<bits>; never set in the product build): 1 no v_exp_f32, 2 no B/C
-// row loads, 4 no stores, 8 no activation loads, 16 no per-step LDS reads, 32 no per-step LDS writes
+// row loads, 4 no stores, 8 no activation loads, 16 no per-step LDS reads, 32 no per-step LDS writes, 64 no state checkpoints,
+// 128 a checkpoint every second block only (= the forward's side of a 16-step spacing)
 #ifndef AUM_SCANT_ABL
 #define AUM_SCANT_ABL 0
 #endif
@@ -395,7 +396,7 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
                     for (int j = 0; j < N / 2; ++j) Bq[j] = Bn[j];
                 }
             }
-            if (want_ck && !CARRY && blk < nck) ckpt_store(blk);
+            if (want_ck && !CARRY && blk < nck && !(AUM_SCANT_ABL & 64) && !((AUM_SCANT_ABL & 128) && (blk & 1) == 0)) ckpt_store(blk);
         } else {        // ragged: steps outside the phase are skipped
             for (int s = 0; s < SCANT_CK; ++s) {
                 if (base + s < it0 || base + s >= it1) continue;
