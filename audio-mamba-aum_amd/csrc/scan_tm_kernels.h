@@ -578,10 +578,39 @@ AUM_DEV void scant_seg_fwd(const AumScanTmFwdArgs& p, const ScanTSeg& sg, int wg
 // 1.4 ms kernel: one pass is shorter than a loaded HBM round trip and two waves per SIMD cannot hide the difference.
 // LDS tiles are planes of 8 rows x 128 bytes (lane l's 16 bytes of a load at l * 16), the order the direct loads write in.
 // ================================================================================================
+#ifndef AUM_SCANT_LSUM
+// 1 (opt-in builds, -DAUM_SCANT_LSUM=1 [-DAUM_LSUM_PUT_ASM=1]; round 5): 16-bit activations: the dB / dC channel sums of a pass through a
+// per-wave LDS tile (wave.h, lsum_*) instead of two transposing butterflies -- the butterflies are 58 half-rate DPP instructions of a
+// pass's 189 on the pipe that bounds the kernel, the LDS route costs the vector ALU 28 (4 rounds of 8 values: 3 packed adds + 1 add +
+// 3 DPP adds) and moves the transposition to ds_write_b32 / ds_write2st64_b32 + ds_read_b128 (154 vector-ALU instructions per pass
+// instead of 192, 263 instructions in all instead of 275).  The tile is the half of the entry-state strip that 16-bit checkpoints leave
+// unused (fp32 activations keep the butterflies: their checkpoints fill the strip).  Built, parity-green (emulator + 166 GPU tests of
+// the asm-put build) and measured: SLOWER -- same box, B = 64 bf16 Fo-Bi + softplus: butterflies 1.015 ms, LDS route 1.165 ms
+// (1.126 ms with the row pairs as one ds_write2st64_b32), bench 999 vs 958-962 clips/s; the ablation with no sums at all is 0.828 ms
+// (profiles/r05_ab_lsum.txt).  44 more LDS instructions per pass cost ~8 cycles of a wave's issue each and the in-order LDS queue puts
+// every fetch behind the row writes in front of it: with two waves per SIMD that is not hidden.  Default 0: the butterflies.
+#define AUM_SCANT_LSUM 0
+#endif
+#define AUM_SCANT_LSUM_ON (AUM_SCANT_LSUM != 0)
 template <class T> AUM_HOSTDEV constexpr int scant_bwd_lds_wave_floats() {
     // u, delta, z, dout, ypre | du, ddelta, dz | B/C block | dB/dC block | u (odd blocks) | entry states [16][64] | A [16][64] | raw B, C pairs
-    return 9 * ScanTTile<T>::FLOATS + 2 * SCANT_BC_BLOCK + 2 * SCANT_N * WAVE + 2 * ScanTTile<T>::NLD * WAVE;
+    // (+ fp32 activations: the other direction's dB | dC row block of the second phase; 16-bit activations park it in the half of the
+    // entry-state strip their packed checkpoints leave free)
+    return 9 * ScanTTile<T>::FLOATS + 2 * SCANT_BC_BLOCK + 2 * SCANT_N * WAVE + 2 * ScanTTile<T>::NLD * WAVE + (sizeof(T) == 4 ? SCANT_BC_BLOCK : 0);
 }
+// Fo-Bi: the two directions of a channel group hand their dB | dC partial rows over like their du / ddelta partials -- the wave that runs a
+// time step in its SECOND phase adds the row block the other direction wrote there in its first -- so the reduce kernel sums one row per
+// channel group instead of two (round 5: 201 -> 101 MB read by k_scant_bwd_reduce).  Slots of a token's partial rows: [0, nparts / 2)
+// finished rows (second phase), [nparts / 2, nparts) first-phase partials.  Off in the -DAUM_SCANT_LSUM / -DAUM_SCANT_CK_F32 A/B builds
+// (they use the same LDS).
+#ifndef AUM_SCANT_DBC_MERGE
+#if AUM_SCANT_LSUM_ON || defined(AUM_SCANT_CK_F32)
+#define AUM_SCANT_DBC_MERGE 0
+#else
+#define AUM_SCANT_DBC_MERGE 1       // -DAUM_SCANT_DBC_MERGE=0: both directions' rows go to the reduce kernel, as until round 4 (A/B builds)
+#endif
+#endif
+AUM_HOSTDEV constexpr int scant_dbc_rows_to_sum(int nparts, bool bidir) { return bidir && AUM_SCANT_DBC_MERGE ? nparts / 2 : nparts; }
 // partials of one (batch entry, direction, channel group) wave
 struct ScanTBwdOut {
     float* dbc;        // [batch][len][nparts][2N] fp32 partial rows
@@ -601,19 +630,6 @@ struct ScanTBwdOut {
 // 962 vs 968 clips/s (profiles/r04_ab_msum.txt).  The kernel is bound by the issue time of its two waves per SIMD, and a matrix
 // instruction occupies the SIMD's issue for its 8 passes: four per pass cost what 32 DPP adds saved.  Default 0: the butterflies.
 #define AUM_SCANT_MSUM 0
-#endif
-#ifndef AUM_SCANT_LSUM
-// 1 (opt-in builds, -DAUM_SCANT_LSUM=1 [-DAUM_LSUM_PUT_ASM=1]; round 5): 16-bit activations: the dB / dC channel sums of a pass through a
-// per-wave LDS tile (wave.h, lsum_*) instead of two transposing butterflies -- the butterflies are 58 half-rate DPP instructions of a
-// pass's 189 on the pipe that bounds the kernel, the LDS route costs the vector ALU 28 (4 rounds of 8 values: 3 packed adds + 1 add +
-// 3 DPP adds) and moves the transposition to ds_write_b32 / ds_write2st64_b32 + ds_read_b128 (154 vector-ALU instructions per pass
-// instead of 192, 263 instructions in all instead of 275).  The tile is the half of the entry-state strip that 16-bit checkpoints leave
-// unused (fp32 activations keep the butterflies: their checkpoints fill the strip).  Built, parity-green (emulator + 166 GPU tests of
-// the asm-put build) and measured: SLOWER -- same box, B = 64 bf16 Fo-Bi + softplus: butterflies 1.015 ms, LDS route 1.165 ms
-// (1.126 ms with the row pairs as one ds_write2st64_b32), bench 999 vs 958-962 clips/s; the ablation with no sums at all is 0.828 ms
-// (profiles/r05_ab_lsum.txt).  44 more LDS instructions per pass cost ~8 cycles of a wave's issue each and the in-order LDS queue puts
-// every fetch behind the row writes in front of it: with two waves per SIMD that is not hidden.  Default 0: the butterflies.
-#define AUM_SCANT_LSUM 0
 #endif
 #ifndef AUM_SCANT_TAIL2
 #define AUM_SCANT_TAIL2 1     // 0 (A/B builds): each butterfly complete where its terms exist, as in round 3
@@ -654,7 +670,12 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     const int u_tb = (int)p.u_ts * ES, d_tb = (int)p.delta_ts * ES, z_tb = HAS_Z ? (int)p.z_ts * ES : 0, g_tb = (int)p.dout_ts * ES,
               y_tb = HAS_Z ? (int)p.pre_ts * ES : 0, du_tb = (int)p.du_ts * ES, dd_tb = (int)p.ddelta_ts * ES,
               dz_tb = HAS_Z ? (int)p.dz_ts * ES : 0, B_tb = (int)p.B_ts * ES, C_tb = (int)p.C_ts * ES;
-    const int dbc_tb = wo.nparts * (2 * N) * 4, dbc_col = part * (2 * N) * 4;
+    // `part`: the channel group's slot.  Fo-Bi with merged hand-over: first phase -> slot nparts / 2 + part, second phase reads that slot
+    // of the OTHER direction (same group) and writes slot part
+    constexpr bool DBC_MERGE = AUM_SCANT_DBC_MERGE && PHASE != 0;
+    const int dbc_tb = wo.nparts * (2 * N) * 4;
+    const int dbc_col_in = (wo.nparts / 2 + part) * (2 * N) * 4;
+    const int dbc_col = DBC_MERGE && PHASE == 1 ? dbc_col_in : part * (2 * N) * 4;
     auto tok = [&](int it) { return t0 + it * tstep; };
     // u is read again in a block's last lines, after the next block's u arrived: two tiles, by block parity
     float* t_u0 = lds;
@@ -672,6 +693,8 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     float* t_A = t_ck + N * WAVE;                  // A[e][n] likewise
     float* t_rawB = t_A + N * WAVE;                // the next block's B / C pairs as loaded (NLD dwords per lane and tensor)
     float* t_rawC = t_rawB + NLD * WAVE;
+    // the other direction's dB | dC row block of this block (second phase): [step][dB | dC] fp32 like t_dbc
+    float* t_dbi = sizeof(T) == 4 ? t_rawC + NLD * WAVE : t_ck + CKR * WAVE;
     auto t_u_of = [&](int blk) { return (blk & 1) ? t_u1 : t_u0; };
     // lane = (row st_i, 16-byte column st_c) of a 8 x 128-byte plane; the row is the block's step st_i IN ITERATION ORDER, which a
     // reversed direction finds at memory row 7 - st_i of the block
@@ -794,7 +817,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     //   block's tensors, PART loads of this block's partial du / ddelta] [this block's passes: 2 entry rows of the next block each]
     constexpr int NST = 2 * NLD + ((HAS_Z && FINAL) ? NLD : 0) + 1;       // stores at the end of a block: du, ddelta, dz, dB/dC
     constexpr int RBN = ((HAS_Z ? 5 : 3) + 2) * NLD;                      // request_block
-    constexpr int PART = LD_PART ? 2 * NLD : 0;
+    constexpr int PART = LD_PART ? 2 * NLD + (DBC_MERGE ? 1 : 0) : 0;
     AUM_TMB_STAMP(0);
     // one block; FULL: all eight steps belong to the phase (no per-step conditions)
     auto do_block = [&](auto full_tag, int blk) {
@@ -867,6 +890,8 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             if (LD_PART) {
                 load_tile(dubuf, du_tb, rc, t_du);
                 load_tile(ddbuf, dd_tb, rc, t_dd);
+                if constexpr (DBC_MERGE)        // lane = (step st_i, 16-byte chunk st_c) of the [8][2N] fp32 block: the layout of the store below
+                    gbuf_load16_lds(dbcbuf, rc.rowt * dbc_tb + st_c * 16 + dbc_col_in, rc.t_lo * dbc_tb, t_dbi);
             }
         }
         AUM_TMB_STAMP(1);
@@ -1097,7 +1122,12 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
         store_tile(ddbuf, dd_tb, t_dd, rc);
         if (HAS_Z && FINAL) store_tile(dzbuf, dz_tb, t_dz, rc);
         {       // dB / dC partial rows of the block: [step][2N] fp32 = 16 bytes per lane
-            const vq q = lds_read16(t_dbc, st_i * (SCANT_BC_ROW * 4) + st_c * 16);
+            vq q = lds_read16(t_dbc, st_i * (SCANT_BC_ROW * 4) + st_c * 16);
+            if constexpr (DBC_MERGE && LD_PART) {
+                const vq qi = lds_read16(t_dbi, st_i * (SCANT_BC_ROW * 4) + st_c * 16);
+                AUM_UNROLL
+                for (int k = 0; k < 4; ++k) q.w[k] = f32_as_int(int_as_f32(q.w[k]) + int_as_f32(qi.w[k]));
+            }
             if (rc.inside) gbuf_store16(dbcbuf, rc.rowt * dbc_tb + st_c * 16 + dbc_col, rc.t_lo * dbc_tb, q);
             else gbuf_store16_m(dbcbuf, rc.rowt * dbc_tb + st_c * 16 + dbc_col, 0, q, rc.valid);
         }
@@ -1170,7 +1200,7 @@ AUM_DEV void scant_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int wg,
             const int phase = h == 0 ? (stage == 0 ? 1 : 2) : (stage == 2 ? 2 : 1);
             const int unit = wg * 3 + slot;
             if (unit < npairs) {
-                const int b = unit / gpb, e0 = (unit % gpb) * WAVE, prt = (unit % gpb) * 2 + d;
+                const int b = unit / gpb, e0 = (unit % gpb) * WAVE, prt = AUM_SCANT_DBC_MERGE ? unit % gpb : (unit % gpb) * 2 + d;
                 float* cy = wo.carry + ((int64_t)wg * 2 + d) * (2 * N + 2) * WAVE;
                 const vi lane = lane_id();
                 if (phase == 1) {
@@ -1227,7 +1257,7 @@ AUM_DEV void scant_seg_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, con
         const int item = wg * NW + w;
         if (item < items) {
             const int d = sg.dir0, s = item % sg.nseg, unit = item / sg.nseg;
-            const int b = unit / gpb, e0 = (unit % gpb) * WAVE, prt = bidir ? (unit % gpb) * 2 + d : unit % gpb;
+            const int b = unit / gpb, e0 = (unit % gpb) * WAVE, prt = bidir && !AUM_SCANT_DBC_MERGE ? (unit % gpb) * 2 + d : unit % gpb;
             const bool rev = bidir ? d == 1 : (p.flags & AUM_SCAN_REVERSE) != 0;
             const int it0 = s * sg.seg_len < L ? s * sg.seg_len : L;
             const int it1 = it0 + sg.seg_len < L ? it0 + sg.seg_len : L;

@@ -456,6 +456,9 @@ AUM_DEV vq lds_read16(const float* lds, vi byte_off) {
     q.w[0] = v.x; q.w[1] = v.y; q.w[2] = v.z; q.w[3] = v.w;
     return q;
 }
+// the bits of a raw word as fp32 and back (the fp32 rows that travel as 16-byte pieces)
+AUM_DEV vf int_as_f32(vi x) { return __builtin_bit_cast(float, x); }
+AUM_DEV vi f32_as_int(vf x) { return __builtin_bit_cast(int, x); }
 // Global -> LDS without registers (buffer_load_dword / _dwordx4 ... lds): lane l's 4 or 16 bytes land at lds_dst + l * 4 / l * 16, the
 // data never passes through VGPRs and nothing has to be "parked" later.  Completion is counted in vmcnt like any load: AUM_WAIT_VM(n)
 // (memory operations complete in issue order, n = the number of YOUNGER ones that may stay in flight) before the LDS data is read.
@@ -779,6 +782,8 @@ template <class T> inline void lds_pair_to_f32(const float* lds, vf& lo, vf& hi)
         }
     }
 }
+inline vf int_as_f32(const vi& x) { vf r; AUM_LANES std::memcpy(&r.v[l], &x.v[l], 4); return r; }
+inline vi f32_as_int(const vf& x) { vi r; AUM_LANES std::memcpy(&r.v[l], &x.v[l], 4); return r; }
 template <class T> inline vi lds_read_raw(const float* lds, const vi& byte_off) {
     vi r;
     AUM_LANES {
