@@ -15,11 +15,23 @@ from aum.model import build_aum  # noqa: E402
 from aum.frontend import FbankTables, wav2fbank  # noqa: E402
 
 
-def run(size, btype, train, batch=64, steps=6, warm=3, frames=1024):
+def run(size, btype, train, batch=64, steps=6, warm=3, frames=1024, ddp=None):
+    """ddp: None, or the gradient-exchange kind ("no" / "bf16") of a DistributedDataParallel wrapper over a world-size-1 RCCL group (the
+    data-parallel step on one GPU: reducer, bucket views, the stream-joining exchange hook -- everything but the wire)"""
     dev = torch.device("cuda")
     torch.manual_seed(0)
     model = build_aum(size, depth=24, num_classes=527, bimamba_type=btype, spectrogram_size=(128, frames)).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    net = model
+    if ddp is not None:
+        import torch.distributed as dist
+        from aum.train import compress_gradients
+        if not dist.is_initialized():
+            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29547"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
+            dist.init_process_group("nccl", device_id=dev)
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True, bucket_cap_mb=64, broadcast_buffers=False)
+        compress_gradients(net, ddp)
     tabs = FbankTables(dev)
     wave = (torch.randn(batch, 400 + (frames - 1) * 160 if frames != 1024 else 160000, device=dev) * 0.1).clamp_(-1, 1)
     y = torch.zeros(batch, 527, device=dev)
@@ -30,7 +42,7 @@ def run(size, btype, train, batch=64, steps=6, warm=3, frames=1024):
         x = wav2fbank(wave, tabs, target_length=frames)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             if train:
-                loss = loss_fn(model(x).float(), y)
+                loss = loss_fn(net(x).float(), y)
             else:
                 with torch.no_grad():
                     return model(x)
@@ -48,10 +60,10 @@ def run(size, btype, train, batch=64, steps=6, warm=3, frames=1024):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     r = {"size": size, "block": {"v1": "Fo-Bi", "v2": "Bi-Bi", "none": "Fo-Fo"}[btype], "mode": "train" if train else "inference",
-         "frames": frames, "tokens": model.num_patches + 1, "batch": batch, "ms_per_step": round(dt * 1e3, 2), "clips_per_s": round(batch / dt, 1),
+         "frames": frames, "tokens": model.num_patches + 1, "batch": batch, "ddp": ddp, "ms_per_step": round(dt * 1e3, 2), "clips_per_s": round(batch / dt, 1),
          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
     print(json.dumps(r), flush=True)
-    del model, opt
+    del model, opt, net
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
     return r
@@ -65,6 +77,15 @@ if __name__ == "__main__":
         out, name = [long_form()], "variants_bench_long.json"
     elif only == "bibi":      # the Bi-Bi block (and Fo-Fo beside it); AUM_DEBUG=1 AUM_TM_MIN_WAVES=1000000000 keeps the channel-major block for A/B
         out, name = [run("base", "v2", True), run("base", "none", True)], "variants_bench_bibi.json"
+    elif only == "bibi_ddp":  # Bi-Bi under DistributedDataParallel (RCCL group of one): two backward streams joined by the exchange hook vs in line
+        import mamba_ssm.ops.selective_scan_interface as ssi
+        out = [run("base", "v2", True), run("base", "v2", True, ddp="no")]
+        ssi._V2_STREAMS = False
+        out.append(run("base", "v2", True, ddp="no"))
+        out[-1]["block"] = "Bi-Bi (one stream)"
+        ssi._V2_STREAMS = True
+        out.append(run("base", "v1", True, ddp="bf16"))
+        name = "variants_bench_bibi_ddp.json"
     else:
         out = [run("base", "v1", True), run("base", "v1", False), run("base", "v2", True), run("base", "none", True),
                run("small", "v1", True), run("small", "v1", False), run("tiny", "v1", True), run("base", "v1", True, batch=256, steps=3, warm=2), long_form()]
