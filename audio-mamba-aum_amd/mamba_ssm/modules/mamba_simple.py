@@ -125,24 +125,33 @@ class Mamba(nn.Module):
             elif self.bimamba_type == "v2":
                 A_b = neg_exp(self.A_b_log)
                 # Bi-Bi's two pipelines are independent until their outputs are added; each is one-direction launches of 1 536 waves at
-                # the bench shape (half of what the time-serial kernels hold), so the second runs on a side stream next to the first
-                # (forward here; autograd runs each pipeline's backward on the stream its forward ran on).  AUM_V2_STREAMS=0: in line.
+                # the bench shape (half of what the time-serial kernels hold), so the two run next to each other on two side streams
+                # (forward here; autograd runs each pipeline's backward on the stream its forward ran on; why BOTH leave the calling
+                # stream: ssi.side_streams).  AUM_V2_STREAMS=0: in line.
                 two = tm and xz.is_cuda and ssi.v2_two_streams((self.conv1d_b.weight, self.x_proj_b.weight, self.dt_proj_b.weight))
                 if two:
-                    main, side = torch.cuda.current_stream(xz.device), ssi.side_stream(xz.device)
-                    side.wait_stream(main)
-                out_f = mamba_inner_fn_no_out_proj(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
-                                                   self.dt_proj.weight, A, None, None, self.D.float(),
-                                                   delta_bias=self.dt_proj.bias.float(), delta_softplus=True,
-                                                   reverse=time_reversed)
-                with (torch.cuda.stream(side) if two else contextlib.nullcontext()):
+                    main = torch.cuda.current_stream(xz.device)
+                    s_f, s_b = ssi.side_streams(xz.device)
+                    s_f.wait_stream(main)
+                    s_b.wait_stream(main)
+                    for t_ in (xz, A, A_b):
+                        t_.record_stream(s_f)
+                        t_.record_stream(s_b)
+                with (torch.cuda.stream(s_f) if two else contextlib.nullcontext()):
+                    out_f = mamba_inner_fn_no_out_proj(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
+                                                       self.dt_proj.weight, A, None, None, self.D.float(),
+                                                       delta_bias=self.dt_proj.bias.float(), delta_softplus=True,
+                                                       reverse=time_reversed)
+                with (torch.cuda.stream(s_b) if two else contextlib.nullcontext()):
                     out_b = mamba_inner_fn_no_out_proj(xz, self.conv1d_b.weight, self.conv1d_b.bias,
                                                        self.x_proj_b.weight, self.dt_proj_b.weight, A_b, None, None,
                                                        self.D_b.float(), delta_bias=self.dt_proj_b.bias.float(),
                                                        delta_softplus=True, reverse=not time_reversed)
                 if two:
-                    main.wait_stream(side)
-                    out_b.record_stream(main)          # allocated on the side stream, consumed on the main one
+                    main.wait_stream(s_f)
+                    main.wait_stream(s_b)
+                    out_f.record_stream(main)          # allocated on the side streams, consumed on the calling one
+                    out_b.record_stream(main)
                 y = out_f + out_b                                          # (B, E, L) logical, both in xz's storage order
                 if self.if_devide_out:
                     y = y / 2

@@ -403,11 +403,16 @@ def v2_two_streams(params=()):
     return not any(getattr(p_, "_post_accumulate_grad_hooks", None) for p_ in params)
 
 
-def side_stream(device):
+def side_streams(device):
+    """the two streams Bi-Bi's pipelines run on.  BOTH pipelines leave the stream the block was called on: under DistributedDataParallel the
+    gradient accumulators of every parameter were created on that stream (the reducer's constructor touches them all), so autograd makes
+    it wait for the producer of every parameter gradient -- with one pipeline ON that stream, that pipeline's own backward then queues
+    behind the other pipeline's (measured: no gain left from the second stream under DDP); with both pipelines elsewhere the calling
+    stream only waits, and the pipelines overlap."""
     s = _side_streams.get(device)
     if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device=device)
-    _main_streams[device] = torch.cuda.current_stream(device)       # the stream the other pipeline (and its backward) runs on
+        s = _side_streams[device] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    _main_streams[device] = torch.cuda.current_stream(device)       # the stream the block was called on (joins happen there)
     return s
 
 
@@ -423,7 +428,7 @@ def ddp_join_streams_hook(hook=None):
         buf = bucket.buffer()
         if buf.is_cuda:
             cur = torch.cuda.current_stream(buf.device)
-            for s in (_side_streams.get(buf.device), _main_streams.get(buf.device)):
+            for s in tuple(_side_streams.get(buf.device) or ()) + (_main_streams.get(buf.device),):
                 if s is not None and s != cur:
                     cur.wait_stream(s)
         return inner(state, bucket)

@@ -18,7 +18,7 @@ from aum.frontend import FbankTables, wav2fbank  # noqa: E402
 def run(size, btype, train, batch=64, steps=6, warm=3, frames=1024, ddp=None):
     """ddp: None, or the gradient-exchange kind ("no" / "bf16") of a DistributedDataParallel wrapper over a world-size-1 RCCL group (the
     data-parallel step on one GPU: reducer, bucket views, the stream-joining exchange hook -- everything but the wire)"""
-    dev = torch.device("cuda")
+    dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     model = build_aum(size, depth=24, num_classes=527, bimamba_type=btype, spectrogram_size=(128, frames)).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
