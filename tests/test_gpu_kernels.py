@@ -586,6 +586,17 @@ def test_gemm_tn_full_size(lib, shape):
     whole = aum_hip.gemm_tn(a, b, lib=lib, split_tail=False)         # (N = 768: the default splits the tail tiles along K -- test_gemm_tn_split_tail)
     for fl in (aum_hip.GEMM_LOCKSTEP, aum_hip.GEMM_STAGGERED, aum_hip.GEMM_PERSISTENT, aum_hip.GEMM_PIPELINED):                            # every schedule: the same sums in the same order
         assert torch.equal(whole, aum_hip.gemm_tn(a, b, lib=lib, flags=fl))
+    # round 5: the four-wave division (accumulators as tied AGPR operands) and the five-stage ring (32-deep steps, a tile's last step stores
+    # its rows between the MFMAs, buffer stores that drop the ragged block's rows): the same sums in the same order, so bit-equal; nothing
+    # written outside the result (the ring's stores rely on a range check)
+    if n % 192 == 0 and k >= 256:
+        for fl in (aum_hip.GEMM_W4, aum_hip.GEMM_RING):
+            buf = torch.full((m + 5, n + 16), 3.0, device="cuda", dtype=torch.bfloat16)
+            o = buf[:m, 8:8 + n]
+            for _ in range(2):
+                aum_hip.gemm_tn(a, b, out=o, lib=lib, flags=fl)
+                assert torch.equal(o, whole), fl
+            assert bool((buf[m:] == 3.0).all()) and bool((buf[:, :8] == 3.0).all()) and bool((buf[:, 8 + n:] == 3.0).all()), fl
 
 
 def test_norm_headline_shape(lib):
