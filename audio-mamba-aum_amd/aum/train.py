@@ -180,12 +180,16 @@ def build_model(args):
 def compress_gradients(ddp, kind):
     """The gradient exchange of a DistributedDataParallel model (TT:39, TT:168).  kind "bf16" / "fp16": each fp32 bucket is cast,
     all-reduced (RCCL ring over xGMI: per-link bound, so half the bytes is close to half the exchange time) and cast back into the
-    bucket view; master weights and Adam stay fp32.  "no": the plain fp32 all-reduce + mean.  In every case the bucket goes through
-    ssi.ddp_join_streams_hook first: Bi-Bi's two backward streams are joined before the collective is ordered behind one of them."""
+    bucket view; master weights and Adam stay fp32.  "no": the reducer's own fp32 all-reduce + mean.  A model with Bi-Bi (v2) blocks gets
+    ssi.ddp_join_streams_hook around whichever exchange it is: its two backward streams are joined before the collective is ordered behind
+    one of them (and only then do the blocks use their second stream under a process group)."""
     from mamba_ssm.ops import selective_scan_interface as ssi
     from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
     inner = {"no": None, "bf16": default_hooks.bf16_compress_hook, "fp16": default_hooks.fp16_compress_hook}[kind]
-    ddp.register_comm_hook(None, ssi.ddp_join_streams_hook(inner))
+    if any(getattr(m, "bimamba_type", None) == "v2" for m in ddp.modules()):
+        ddp.register_comm_hook(None, ssi.ddp_join_streams_hook(inner))      # Bi-Bi blocks: two backward streams to join
+    elif inner is not None:
+        ddp.register_comm_hook(None, inner)                                 # one stream: the reducer's own ordering is right as it is
 
 
 class Frontend:

@@ -393,7 +393,7 @@ def v2_two_streams(params=()):
     consumes a parameter gradient INSIDE backward sees two producer streams.  DistributedDataParallel's reducer orders a bucket's
     all-reduce behind the stream of the LAST gradient hook only, and a bucket holds gradients of both pipelines: under an initialised
     process group (any world size) the side stream is used only when the gradient exchange goes through `ddp_join_streams_hook`
-    (aum.train.compress_gradients and bench.py register it), which makes the exchange wait for both streams.  Parameters that carry
+    (aum.train.compress_gradients registers it for models with Bi-Bi blocks), which makes the exchange wait for both streams.  Parameters that carry
     post-accumulate-grad hooks (FSDP, user hooks: `params`, the side pipeline's) keep the pipelines in line as well."""
     if not _V2_STREAMS:
         return False
