@@ -820,8 +820,30 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     constexpr int PART = LD_PART ? 2 * NLD + (DBC_MERGE ? 1 : 0) : 0;
     AUM_TMB_STAMP(0);
     // one block; FULL: all eight steps belong to the phase (no per-step conditions)
+// Two waves share a SIMD for the whole kernel and the arbiter serves equal priorities oldest first: left alone, the older wave of every
+// SIMD runs ahead, finishes at ~0.7 of the kernel's span and leaves the younger one to run the rest alone -- at the issue rate of ONE wave
+// (profiles/r04_trace_bwd.txt: wave durations 841 ... 1188 us in a 1189 us launch).  So the two take turns: priority 3 / 0, exchanged with
+// every 8-step block, offset by the wave's slot on its SIMD (round 5; same box, bench launch: 1.016 -> 0.962 ms; by pass instead of by
+// block 0.976; the odd slot at a fixed priority 1.004; levels 1 / 0 0.949 against 0.943 for 3 / 0 on another box: profiles/r05_ab_bwd_prio.txt).
+// -DAUM_SCANT_BPRIO=0: no priorities (round 4); 2: the odd slot holds priority 1; 3: the turn changes with the pass.
+#ifndef AUM_SCANT_BPRIO
+#define AUM_SCANT_BPRIO 1
+#endif
+#ifndef AUM_SCANT_BPRIO_SHIFT
+#define AUM_SCANT_BPRIO_SHIFT 0
+#endif
+#ifndef AUM_SCANT_BPRIO_HI
+#define AUM_SCANT_BPRIO_HI 3
+#endif
+    const int bslot = AUM_SCANT_BPRIO ? wave_slot_on_simd() : 0;
     auto do_block = [&](auto full_tag, int blk) {
         constexpr bool FULL = decltype(full_tag)::value;
+        if (AUM_SCANT_BPRIO == 1) {
+            if (((blk >> AUM_SCANT_BPRIO_SHIFT) + bslot) & 1) AUM_SET_PRIO(AUM_SCANT_BPRIO_HI);
+            else AUM_SET_PRIO(0);
+        } else if (AUM_SCANT_BPRIO == 2) {
+            if (bslot & 1) AUM_SET_PRIO(1);
+        }
         const int base = blk * SCANT_CK;
         const int s_lo = FULL ? 0 : (it0 > base ? it0 - base : 0);                       // steps [s_lo, s_hi) of the block are this phase's
         const int s_hi = FULL ? SCANT_CK : (it1 < base + SCANT_CK ? it1 - base : SCANT_CK);
@@ -904,6 +926,10 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             // twelve LDS round trips per pass in a chain that two waves per SIMD cannot hide)
             // this pass's entry rows: younger are the later rows (CKR - RPP (j + 1)), the previous block's stores, this block's requests and
             // the RPP j rows of the next block requested so far -- a constant; fewer were issued near the ends of a phase
+            if (AUM_SCANT_BPRIO == 3) {          // A/B: the turn changes with the pass, not the block
+                if (((j >> AUM_SCANT_BPRIO_SHIFT) + bslot) & 1) AUM_SET_PRIO(AUM_SCANT_BPRIO_HI);
+                else AUM_SET_PRIO(0);
+            }
             if (blk != blk_hi - 1) {
                 if (more && cknext) AUM_WAIT_VM((CKR - RPP) + NST + RBN + PART);
                 else if (more) AUM_WAIT_VM(NST + RBN + PART);
