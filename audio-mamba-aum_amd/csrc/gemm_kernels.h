@@ -43,6 +43,9 @@ typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 
+#ifndef AUM_GEMM_PRIO
+#define AUM_GEMM_PRIO 0     // A/B builds: 1 the second-dispatched half of the waves (4-7, the younger wave of every SIMD) holds priority 1; 2 the two waves of a SIMD take turns K-step by K-step
+#endif
 constexpr int NWAVES = 8, THREADS = NWAVES * 64;
 constexpr int TILE_BYTES = BM * BK * 2;                 // one operand, one K-step: 32 KB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;             // A | B
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
     const int lane = (int)(threadIdx.x & 63u);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = w >> 2, wc = w & 3;
+    if (AUM_GEMM_PRIO == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
     const int ntn = g.n / BN;
     const int tile = xcd_tile((int)blockIdx.x, (int)gridDim.x);
     const int tm = tile / ntn, tn = tile - tm * ntn;
@@ -168,6 +172,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) af[0][i] = lds_frag(lds, a_rd + i * 2048);
         for (int t = 0; t < nk; ++t) {
+            if (AUM_GEMM_PRIO == 2) { if ((t + (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
             const char* st = lds + (t & 1) * STAGE_BYTES;
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[1][j] = lds_frag(st, (b_rd ^ 64) + b_joff(j));
@@ -328,6 +333,7 @@ __device__ __forceinline__ void gemm_steps(f4v (&acc)[8][4], int nk, int par, bo
                                            __amdgpu_buffer_rsrc_t rb, bool has_next, __amdgpu_buffer_rsrc_t ra_n, __amdgpu_buffer_rsrc_t rb_n,
                                            int voff_a, int voff_b, int rowstep_a, int rowstep_b, int w, bool stores16, uint32_t L_flags) {
     for (int t = 0; t < nk; ++t) {
+        if (AUM_GEMM_PRIO == 2) { if ((t + (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         if (t == 0 && stores16 && !(L_flags & (AUM_GEMM_NO_COUNTED_WAIT | AUM_GEMM_NO_PREFETCH))) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -380,6 +386,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_persistent(GemmLaunch L)
     const int lane = (int)(threadIdx.x & 63u);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = w >> 2, wc = w & 3;
+    if (AUM_GEMM_PRIO == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
     const int ntn = g.n / BN, grid = (int)gridDim.x, nk = g.k / BK;
 
     const int srow = w * 8 + (lane >> 3);
@@ -658,6 +665,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_wgrad(AumGemmWArgs g) {
     const int lane = (int)(threadIdx.x & 63u);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = w >> 2, wc = w & 3;
+    if (AUM_GEMM_PRIO == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
     const int ntn = g.n / 256, ntk = g.k / 256;
     // work item (split, tile) of this workgroup.  Every workgroup of a split streams the same token rows, so the items are numbered split-major
     // and each XCD (blockIdx % 8: its CUs share an L2) takes a contiguous run of them: its ~32 workgroups walk one or two token ranges in step and
