@@ -360,6 +360,12 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
 #ifndef AUM_SCANT_PRIO
 #define AUM_SCANT_PRIO 1
 #endif
+#ifndef AUM_SCANT_PRIO_A        // the levels of the three turns (A/B builds)
+#define AUM_SCANT_PRIO_A 2
+#endif
+#ifndef AUM_SCANT_PRIO_B
+#define AUM_SCANT_PRIO_B 1
+#endif
     // Three waves share a SIMD and the arbiter serves equal priorities oldest first: left alone, one wave runs at full speed and
     // finishes at 0.55 of the kernel's time, the second at 0.75, and the last runs the final quarter alone at less than half the
     // vector ALU's rate (measured: wave durations 185 / 254 / 325 us on every SIMD).  Each wave therefore walks through the
@@ -370,8 +376,8 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
         const bool more = blk + 1 < blk1;
         if (AUM_SCANT_PRIO) {
             const int turn = (blk + wslot) % 3;
-            if (turn == 0) AUM_SET_PRIO(2);
-            else if (turn == 1) AUM_SET_PRIO(1);
+            if (turn == 0) AUM_SET_PRIO(AUM_SCANT_PRIO_A);
+            else if (turn == 1) AUM_SET_PRIO(AUM_SCANT_PRIO_B);
             else AUM_SET_PRIO(0);
         }
         if (more) request(blk + 1, nx);
