@@ -360,6 +360,9 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
 #ifndef AUM_SCANT_PRIO
 #define AUM_SCANT_PRIO 1
 #endif
+#ifndef AUM_SCANT_PRIO_SHIFT    // the turns change every 2^SHIFT blocks (A/B builds)
+#define AUM_SCANT_PRIO_SHIFT 0
+#endif
 #ifndef AUM_SCANT_PRIO_A        // the levels of the three turns (A/B builds)
 #define AUM_SCANT_PRIO_A 2
 #endif
@@ -375,7 +378,7 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
         const int base = blk * SCANT_CK;
         const bool more = blk + 1 < blk1;
         if (AUM_SCANT_PRIO) {
-            const int turn = (blk + wslot) % 3;
+            const int turn = ((blk >> AUM_SCANT_PRIO_SHIFT) + wslot) % 3;
             if (turn == 0) AUM_SET_PRIO(AUM_SCANT_PRIO_A);
             else if (turn == 1) AUM_SET_PRIO(AUM_SCANT_PRIO_B);
             else AUM_SET_PRIO(0);

@@ -54,6 +54,7 @@ def main():
         cfgs["bidir_sp"] = lambda lib: aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, D, z, bias, True, A_b=A_b, lib=lib)
         cfgs["bidir_nosp_pre"] = lambda lib: aum_hip.scan_tm_fwd(u, dsp, A, Bm, Cm, D, z, None, False, A_b=A_b, want_out_pre=True, lib=lib)
         cfgs["bidir_nosp_train"] = lambda lib: aum_hip.scan_tm_fwd(u, dsp, A, Bm, Cm, D, z, None, False, A_b=A_b, want_out_pre=True, ckpt=ck2, lib=lib)
+        cfgs["bidir_sp_train"] = lambda lib: aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, ckpt=ck2, lib=lib)      # the bench's launch
     else:
         _, pre = aum_hip.scan_tm_fwd(u, dsp, A, Bm, Cm, D, z, None, False, A_b=A_b, want_out_pre=True, ckpt=ck2)
         _, pre1 = aum_hip.scan_tm_fwd(u, dsp, A, Bm, Cm, D, z, None, False, want_out_pre=True, ckpt=ck1)
