@@ -260,9 +260,12 @@ def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
 # r02_sweep_gemm_tokens.txt).  The four big projection GEMMs are therefore issued as a tile-aligned GEMM over the first
 # n0 = 256 * floor(ntok / 256) tokens plus a small one over the remainder, both writing slices of one output.  AUM_GEMM_TOKEN_SPLIT is
 # a bit mask for A/B runs (1 in_proj forward, 2 out_proj forward, 4 out_proj data gradient, 8 in_proj data gradient).  Same-box A/B of the
-# step: mask 0 / 1 / 2 / 4 / 8 / 15 / 13 = 80.06 / 79.67 / 80.10 / 79.53 / 79.63 / 78.97 / 78.87 ms -> default 13 (the out_proj forward
-# loses what it gains to its 17 us remainder GEMM).
-_TOKEN_SPLIT = int(_dbg_env("AUM_GEMM_TOKEN_SPLIT", "13"))
+# step: mask 0 / 1 / 2 / 4 / 8 / 15 / 13 = 80.06 / 79.67 / 80.10 / 79.53 / 79.63 / 78.97 / 78.87 ms -> default 13 in rounds 2-4 (the out_proj
+# forward loses what it gains to its 17 us remainder GEMM).  Round 5 re-measured it on the token-major block, where the out_proj data gradient
+# runs on aum_gemm_tn (ragged rows in its stride) and the in_proj data gradient is a different library call than in round 2
+# (profiles/r05_gemm_dispatch_ab.txt, same box x3, ms per step): 13: 61.58 / 61.54 / 61.54, 0: 61.20 / 61.26 / 61.17, 1: 61.17 / 61.26 / 61.19,
+# 8: 61.75 / 61.61 / 61.74 -- the in_proj data gradient's split now COSTS 0.4 ms, the in_proj forward's is level -> default 0 (single GEMMs).
+_TOKEN_SPLIT = int(_dbg_env("AUM_GEMM_TOKEN_SPLIT", "0"))
 
 
 def _tok_n0(ntok, bit, t):

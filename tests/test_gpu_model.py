@@ -279,10 +279,11 @@ def test_split_k_weight_gradients_match_single_gemm(dtype, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_token_aligned_gemm_split_matches_single_gemm():
+def test_token_aligned_gemm_split_matches_single_gemm(monkeypatch):
     """The big projection GEMMs issued as a tile-aligned GEMM + a remainder GEMM into one output (selective_scan_interface.
-    _mm_tokens_cols / _mm_tokens_rows) against the single GEMM, at the AuM-Base shapes, bf16."""
+    _mm_tokens_cols / _mm_tokens_rows; opt-in since round 5: AUM_GEMM_TOKEN_SPLIT) against the single GEMM, at the AuM-Base shapes, bf16."""
     from mamba_ssm.ops import selective_scan_interface as S
+    monkeypatch.setattr(S, "_TOKEN_SPLIT", 13)
     torch.manual_seed(0)
     ntok = 64 * 513
     w = torch.randn(3072, 768, device="cuda").to(torch.bfloat16)
@@ -602,3 +603,4 @@ def test_bibi_block_two_streams_bit_equal(monkeypatch):
     h = m.conv1d_b.weight.register_post_accumulate_grad_hook(lambda p_: None)
     assert not ssi.v2_two_streams((m.conv1d_b.weight,))
     h.remove()
+
