@@ -25,7 +25,7 @@ _ERR = {-1: "AUM_E_NULL", -2: "AUM_E_SHAPE", -3: "AUM_E_DTYPE", -4: "AUM_E_UNSUP
         -6: "AUM_E_LAUNCH"}
 
 _i64, _i32, _u32, _vp, _fp = C.c_int64, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class _Debug:
@@ -41,6 +41,7 @@ class _Debug:
         self.no_lane_ckpt = False  # L = 513 rows: scan_lane_ckpt() hands out no checkpoint
         self.proj_splits = 0       # token splits of the projection weight-gradient kernel (0: aum_proj_bwd_weight_splits)
         self.torch_sums = False    # partial results summed by torch.sum instead of aum_sum_rows
+        self.sums_one_by_one = False   # sum_rows_multi: one aum_sum_rows launch per partial set (the launches of rounds 2-4; A/B)
         if os.environ.get("AUM_DEBUG") == "1":
             self.ablate = int(os.environ.get("AUM_ABLATE", "0"))
             self.rowpair = os.environ.get("AUM_SCAN_ROWPAIR") == "1"
@@ -48,6 +49,7 @@ class _Debug:
             self.no_accumulate = os.environ.get("AUM_SCAN_NO_ACCUMULATE") == "1"
             self.no_lane_ckpt = os.environ.get("AUM_SCAN_NO_LANE_CKPT") == "1"
             self.torch_sums = os.environ.get("AUM_TORCH_SUMS") == "1"
+            self.sums_one_by_one = os.environ.get("AUM_SUMS_ONE_BY_ONE") == "1"
 
 
 debug = _Debug()
@@ -158,6 +160,10 @@ class GemmWArgs(C.Structure):
                 ("n", C.c_int32), ("k", C.c_int32), ("splits", C.c_int32), ("dtype", C.c_int32)]
 
 
+class SumJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("outer", C.c_int64), ("inner", C.c_int64), ("tr_cols", C.c_int32), ("reserved", C.c_int32)]
+
+
 class ConvUpdateArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("conv_state", C.c_void_p), ("weight", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
                 ("batch", C.c_int32), ("dim", C.c_int32), ("width", C.c_int32), ("dtype", C.c_int32), ("flags", C.c_uint32)]
@@ -180,7 +186,7 @@ class XdtArgs(C.Structure):
 
 EXPORTS = ["aum_gemm_tn", "aum_dtproj_tm_fwd", "aum_xdt_tm_fwd", "aum_proj_fwd", "aum_proj_bwd_data", "aum_proj_bwd_weight", "aum_proj_bwd_weight_splits", "aum_fbank_fwd", "aum_frontend_tokens_fwd", "aum_abi_version", "aum_selective_scan_fwd", "aum_selective_scan_bwd", "aum_scan_max_single_pass_len",
            "aum_selective_scan_workspace_bytes", "aum_selective_scan_ckpt_bytes", "aum_selective_scan_lane_ckpt_bytes", "aum_causal_conv1d_fwd", "aum_causal_conv1d_bwd", "aum_rmsnorm_fwd",
-           "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows",
+           "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows", "aum_sum_rows_multi",
            "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_ckpt_rows", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_scan_tm_seg_fwd", "aum_scan_tm_seg_bwd",
            "aum_scan_tm_seg_carry_bytes", "aum_scan_tm_seg_workspace_bytes", "aum_selftest_wave_sum32",
            "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_scan_tm_bwd_matrix_sums", "aum_gemm_wgrad", "aum_gemm_tn_sk", "aum_gemm_tn_sk_workspace_bytes", "aum_xdt_tm_bwd", "aum_causal_conv1d_update", "aum_selective_state_update"]
@@ -237,6 +243,7 @@ class Lib:
         self.c.aum_hbm_copy.argtypes = [_vp, _vp, _i64, _vp]
         self.c.aum_selftest_wave_sum32.argtypes = [_vp, _vp, _vp]
         self.c.aum_sum_rows.argtypes = [_vp, _vp, _i64, _i64, _i64, _i32, _vp]
+        self.c.aum_sum_rows_multi.argtypes = [_vp, _i32, _vp]
         self.c.aum_selective_scan_ckpt_bytes.restype = _i64
         self.c.aum_selective_scan_ckpt_bytes.argtypes = [_i32] * 4
         self.c.aum_selective_scan_lane_ckpt_bytes.restype = _i64
@@ -1014,8 +1021,9 @@ def conv1d_tm_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, li
     a.batch, a.dim, a.len, a.width, a.dtype = batch, dim, length, width, _DT[x.dtype]
     a.flags = (CONV_SILU if silu else 0) | (CONV_REVERSE if reverse else 0)
     _launch(lib.c.aum_conv1d_tm_bwd, a, x, lib, "conv_tm_bwd", (batch, dim, length, x.element_size()))
-    dweight = sum_rows(dw_part, lib=lib)                       # (dim, width): the partial rows are in the weight's own layout
-    dbias = sum_rows(db_part, lib=lib) if db_part is not None else None
+    if db_part is None:
+        return dx, sum_rows(dw_part, lib=lib), None           # (dim, width): the partial rows are in the weight's own layout
+    dweight, dbias = sum_rows_multi([dw_part, db_part], lib=lib)      # both partial sets in one launch
     return dx, dweight, dbias
 
 
@@ -1329,6 +1337,27 @@ def sum_rows(t, lib=None):
     out = torch.empty(shape, dtype=torch.float32, device=t.device)
     _chk(lib.c.aum_sum_rows(_ptr(t), _ptr(out), 1, outer, inner, _DT[t.dtype], stream), "aum_sum_rows")
     return out
+
+
+def sum_rows_multi(parts, tr_cols=None, lib=None):
+    """parts: up to four (outer, ...) contiguous fp32 tensors of partial results on one device -> their fp32 sums over dim 0 in ONE launch
+    (aum_sum_rows_multi; the same order of additions as sum_rows).  tr_cols[q] > 0: part q is (outer, rows, tr_cols) and its sum is
+    returned transposed, (tr_cols, rows) contiguous.  Shapes the entry does not take go through sum_rows / torch one by one."""
+    lib = lib or get()
+    tr_cols = list(tr_cols or [0] * len(parts))
+    ok = 0 < len(parts) <= 4 and not debug.torch_sums and not debug.sums_one_by_one and all(
+        t.dtype == torch.float32 and t.is_contiguous() and t[0].numel() % 8 == 0 and t.data_ptr() % 16 == 0 and t.shape[0] > 0 and t[0].numel() > 0
+        and (not tc or (t.dim() == 3 and t.shape[2] == tc)) for t, tc in zip(parts, tr_cols))
+    if not ok:
+        return [(sum_rows(t, lib=lib).t().contiguous() if tc else sum_rows(t, lib=lib)) for t, tc in zip(parts, tr_cols)]
+    for t in parts:
+        lib.check_tensor(t)
+    outs = [torch.empty((t.shape[2], t.shape[1]) if tc else t.shape[1:], dtype=torch.float32, device=t.device) for t, tc in zip(parts, tr_cols)]
+    jobs = (SumJob * len(parts))()
+    for j, t, o, tc in zip(jobs, parts, outs, tr_cols):
+        j.src, j.dst, j.outer, j.inner, j.tr_cols = _ptr(t), _ptr(o), t.shape[0], t[0].numel(), tc
+    _chk(lib.c.aum_sum_rows_multi(C.cast(jobs, C.c_void_p), len(parts), lib.stream(parts[0])), "aum_sum_rows_multi")
+    return outs
 
 
 def hbm_copy(src, dst, lib=None):

@@ -442,13 +442,11 @@ __global__ __launch_bounds__(256) void k_hbm_copy(const float4* __restrict__ src
 
 // dst[i] = sum_o src[o][i]: 256 threads = CW columns of 8 elements x RG row groups; a thread walks rows rg, rg + RG, ... with four loads in
 // flight, the row groups meet in LDS in a fixed order (no atomics: the result does not depend on the launch).
-template <class T, int RG> __global__ __launch_bounds__(256) void k_sum_rows(const T* __restrict__ src, float* __restrict__ dst, int64_t outer, int64_t inner) {
+template <class T, int RG> __device__ __forceinline__ void sum_rows_body(const T* __restrict__ src, float* __restrict__ dst, int64_t outer, int64_t inner, int wgx, int tr_cols) {
     constexpr int CW = 256 / RG;
     __shared__ float part[RG > 1 ? 256 * 8 : 8];
     const int c = threadIdx.x % CW, rg = threadIdx.x / CW;
-    const int64_t col = ((int64_t)blockIdx.x * CW + c) * 8;
-    src += (int64_t)blockIdx.y * outer * inner;        // batch entry
-    dst += (int64_t)blockIdx.y * inner;
+    const int64_t col = ((int64_t)wgx * CW + c) * 8;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (col < inner) {
         int64_t o = rg;
@@ -498,10 +496,35 @@ template <class T, int RG> __global__ __launch_bounds__(256) void k_sum_rows(con
         }
     }
     if (rg == 0 && col < inner) {
-        float4* d4 = reinterpret_cast<float4*>(dst + col);
-        d4[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        d4[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        if (tr_cols > 0) {              // the summed (inner / tr_cols, tr_cols) matrix leaves transposed (a few hundred KB: scattered 4-byte stores)
+            const int64_t nrows = inner / tr_cols;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[((col + j) % tr_cols) * nrows + (col + j) / tr_cols] = acc[j];
+        } else {
+            float4* d4 = reinterpret_cast<float4*>(dst + col);
+            d4[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            d4[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
     }
+}
+
+template <class T, int RG> __global__ __launch_bounds__(256) void k_sum_rows(const T* __restrict__ src, float* __restrict__ dst, int64_t outer, int64_t inner) {
+    sum_rows_body<T, RG>(src + (int64_t)blockIdx.y * outer * inner, dst + (int64_t)blockIdx.y * inner, outer, inner, (int)blockIdx.x, 0);     // blockIdx.y: batch entry
+}
+
+// up to four independent sums in one launch (aum_sum_rows_multi): a workgroup finds its job from the running workgroup counts
+struct SumJobs {
+    const float* src[4];
+    float* dst[4];
+    int64_t outer[4], inner[4];
+    int32_t tr_cols[4];
+    int32_t wg_end[4];
+};
+template <int RG> __global__ __launch_bounds__(256) void k_sum_rows_multi(SumJobs js) {
+    const int wg = (int)blockIdx.x;
+    int q = 0;
+    while (q < 3 && wg >= js.wg_end[q]) ++q;
+    sum_rows_body<float, RG>(js.src[q], js.dst[q], js.outer[q], js.inner[q], wg - (q ? js.wg_end[q - 1] : 0), js.tr_cols[q]);
 }
 #endif
 

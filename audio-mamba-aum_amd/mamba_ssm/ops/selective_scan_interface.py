@@ -683,10 +683,14 @@ def _inner_backward_tm(ctx, dout):
         # (a shape the kernel's own argument check would refuse -- e.g. a token split beyond 32-bit byte offsets -- takes the library's
         # split-K products instead of raising inside backward)
         splits = _pick_splits(Bsz * L, _WGRAD_SPLITS[1])
-        ddelta_proj_weight = (aum_hip.gemm_wgrad(ddelta2, x_dbl[:, :R]) if aum_hip.gemm_wgrad_supported(ddelta2, x_dbl[:, :R])
-                              else split_k_wgrad(ddelta2.t(), x_dbl[:, :R], splits, torch.float32))          # SSI:586  (E, R) fp32
-        dx_proj_weight = (aum_hip.gemm_wgrad(conv2d, dx_dbl).t().contiguous() if aum_hip.gemm_wgrad_supported(conv2d, dx_dbl)
-                          else split_k_wgrad(dx_dbl.t(), conv2d, splits, torch.float32))                     # SSI:589  (R + 2N, E) fp32
+        if aum_hip.gemm_wgrad_supported(ddelta2, x_dbl[:, :R]) and aum_hip.gemm_wgrad_supported(conv2d, dx_dbl):
+            # the two partial sets are summed by ONE launch, which also stores the x_proj gradient in the parameter's (R + 2N, E) layout
+            ddelta_proj_weight, dx_proj_weight = aum_hip.sum_rows_multi(
+                [aum_hip.gemm_wgrad(ddelta2, x_dbl[:, :R], partials=True),                                   # SSI:586  (E, R) fp32
+                 aum_hip.gemm_wgrad(conv2d, dx_dbl, partials=True)], [0, R + 2 * N])                         # SSI:589  (R + 2N, E) fp32
+        else:
+            ddelta_proj_weight = split_k_wgrad(ddelta2.t(), x_dbl[:, :R], splits, torch.float32)
+            dx_proj_weight = split_k_wgrad(dx_dbl.t(), conv2d, splits, torch.float32)
     else:
         dx_dbl = torch.empty_like(x_dbl)
         dx_dbl[:, R:].copy_(dbc2)                                                            # SSI:570-574

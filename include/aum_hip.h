@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AUM_ABI_VERSION 10  /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
+#define AUM_ABI_VERSION 11  /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
                                3: x_lane (lane-entry state checkpoint of the L = 513 row kernels) appended after it;
                                4: aug / noise (per-clip augmentation in the log-mel kernel's epilogue) appended to AumFbankArgs;
                                5: aum_frontend_tokens_fwd (waveform -> token sequence in one launch);
@@ -37,7 +37,8 @@ extern "C" {
                                9: aum_gemm_tn (the dense in_proj / out_proj GEMMs on token-major activations); aum_dtproj_tm_fwd, aum_xdt_tm_fwd; aum_scan_tm_ckpt_rows
                                   (packed 16-bit state checkpoints of the token-major scan for 16-bit activations);
                                10: aum_gemm_wgrad (weight gradients of the projections), aum_scan_tm_seg_fwd / _bwd (time segments: long rows at a small
-                                  batch), aum_causal_conv1d_update / aum_selective_state_update (streaming inference), aum_scan_tm_bwd_matrix_sums */
+                                  batch), aum_causal_conv1d_update / aum_selective_state_update (streaming inference), aum_scan_tm_bwd_matrix_sums;
+                               11: aum_sum_rows_multi (several partial sets summed in one launch) */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 
@@ -591,6 +592,23 @@ int aum_hbm_copy(const void* src, void* dst, int64_t bytes, void* stream);
  * src_dtype (AUM_F32 / AUM_BF16 / AUM_F16), dst: (batch, inner) fp32.  inner % 8 == 0, 16-byte aligned pointers.
  */
 int aum_sum_rows(const void* src, float* dst, int64_t batch, int64_t outer, int64_t inner, int32_t src_dtype, void* stream);
+
+/*
+ * ABI 11: up to four independent fixed-order sums of fp32 partial results in ONE launch -- a layer's backward leaves its small partial sets in pairs
+ * (the conv weight and bias partials of aum_conv1d_tm_bwd; the two skinny partial sets of aum_gemm_wgrad for the dt_proj / x_proj weights, SSI:586, 589),
+ * and a 5 us launch per set is 5 us of the step.  Job q:  dst[i] = sum over o < outer of src[o][i],  i < inner  (the same order of additions as
+ * aum_sum_rows with the same row grouping: bitwise repeatable).  tr_cols > 0: the summed (inner / tr_cols, tr_cols) matrix is stored transposed, dst
+ * (tr_cols, inner / tr_cols) -- the x_proj weight gradient leaves aum_gemm_wgrad as (dim, R + 2N) and the parameter is (R + 2N, dim).
+ * 1 <= njobs <= 4, inner % 8 == 0, inner % tr_cols == 0, 16-byte aligned pointers; `jobs` is read on the host during the call.
+ */
+typedef struct AumSumJob {
+    const float* src;       /* (outer, inner) contiguous */
+    float* dst;             /* (inner), or (tr_cols, inner / tr_cols) */
+    int64_t outer, inner;
+    int32_t tr_cols;
+    int32_t reserved;
+} AumSumJob;
+int aum_sum_rows_multi(const AumSumJob* jobs, int32_t njobs, void* stream);
 
 #ifdef __cplusplus
 }

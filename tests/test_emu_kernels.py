@@ -203,6 +203,33 @@ def test_sum_rows_emu(emu):
         assert torch.allclose(got, t.float().sum(0), rtol=1e-5, atol=1e-5)
 
 
+def test_sum_rows_multi_emu(emu):
+    """aum_sum_rows_multi (ABI 11) on the lane-array build: the two pairs a layer's backward hands over (conv weight + bias partials; the
+    skinny dt_proj / x_proj partial sets, the second stored transposed), one to four jobs, and the shapes that go job by job instead"""
+    torch.manual_seed(0)
+    dw, db = torch.randn(9, 24, 4), torch.randn(9, 24)
+    gw, gb = aum_hip.sum_rows_multi([dw, db], lib=emu)
+    assert gw.shape == (24, 4) and gb.shape == (24,)
+    assert torch.allclose(gw, dw.sum(0), rtol=1e-5, atol=1e-5) and torch.allclose(gb, db.sum(0), rtol=1e-5, atol=1e-5)
+    p1, p2 = torch.randn(5, 32, 48), torch.randn(5, 32, 80)
+    g1, g2 = aum_hip.sum_rows_multi([p1, p2], [0, 80], lib=emu)
+    assert g1.shape == (32, 48) and g2.shape == (80, 32) and g2.is_contiguous()
+    assert torch.allclose(g1, p1.sum(0), rtol=1e-5, atol=1e-5) and torch.allclose(g2, p2.sum(0).t(), rtol=1e-5, atol=1e-5)
+    four = [torch.randn(3, 8 * (q + 1)) for q in range(4)]
+    for got, t in zip(aum_hip.sum_rows_multi(four, lib=emu), four):
+        assert torch.allclose(got, t.sum(0), rtol=1e-5, atol=1e-5)
+    one = aum_hip.sum_rows_multi([torch.ones(1, 16)], lib=emu)
+    assert torch.equal(one[0], torch.ones(16))
+    odd = [torch.randn(3, 7), torch.randn(3, 2, 5)]              # inner % 8 != 0: one by one (sum_rows' own fallback), transposition included
+    g = aum_hip.sum_rows_multi(odd, [0, 5], lib=emu)
+    assert torch.allclose(g[0], odd[0].sum(0), rtol=1e-5, atol=1e-5) and torch.allclose(g[1], odd[1].sum(0).t(), rtol=1e-5, atol=1e-5)
+    import ctypes
+    jobs = (aum_hip.SumJob * 1)()
+    jobs[0].src, jobs[0].dst, jobs[0].outer, jobs[0].inner, jobs[0].tr_cols = dw.data_ptr(), gw.data_ptr(), 9, 96, 5          # 96 % 5 != 0
+    assert emu.c.aum_sum_rows_multi(ctypes.cast(jobs, ctypes.c_void_p), 1, None) != 0
+    assert emu.c.aum_sum_rows_multi(ctypes.cast(jobs, ctypes.c_void_p), 5, None) != 0
+
+
 # ---- time-serial token-major kernels (scan_tm_kernels.h, conv_tm_kernels.h) ---------------------------------------------------
 def test_wave_sum_butterflies(emu):
     KC.check_wave_sum32(emu, "cpu")

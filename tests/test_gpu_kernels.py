@@ -322,6 +322,26 @@ def test_sum_rows(lib):
         assert torch.equal(got, aum_hip.sum_rows(t, lib=lib))
 
 
+@pytest.mark.gpu
+def test_sum_rows_multi(lib):
+    """aum_sum_rows_multi (ABI 11) at the two callers' shapes -- the conv weight + bias partials of aum_conv1d_tm_bwd at the bench batch, the skinny
+    dt_proj / x_proj partial sets (the second stored transposed) -- against fp64 sums; every row grouping; repeatable bit for bit"""
+    torch.manual_seed(0)
+    nparts = int(lib.c.aum_conv1d_tm_nparts(64, 513))
+    cases = [([(nparts, 1536, 4), (nparts, 1536)], [0, 0]), ([(42, 1536, 48), (42, 1536, 80)], [0, 80]), ([(3, 8)], [0]), ([(2, 256 * 512 * 8)], [0]),
+             ([(7, 64, 16), (9, 40), (33, 24, 8), (64, 8)], [16, 0, 8, 0]), ([(600, 768), (600, 16)], [0, 0])]
+    for shapes, tr in cases:
+        parts = [torch.randn(sh, device="cuda") for sh in shapes]
+        got = aum_hip.sum_rows_multi(parts, tr, lib=lib)
+        again = aum_hip.sum_rows_multi(parts, tr, lib=lib)
+        for t, g, g2, tc in zip(parts, got, again, tr):
+            ref = t.double().sum(0)
+            ref = ref.t() if tc else ref
+            assert g.shape == ref.shape and g.is_contiguous() and g.dtype == torch.float32
+            assert (g.double() - ref).abs().max() <= 2e-6 * max(1.0, ref.abs().max().item()) * t.shape[0] ** 0.5, (shapes, tr)
+            assert torch.equal(g, g2)
+
+
 # ---- time-serial token-major kernels --------------------------------------------------------------------------------------------
 def test_wave_sum_butterflies(lib):
     """the masked-DPP / permlane-swap butterflies on the real lanes (the emulator states their result, not their data movement)"""
