@@ -160,6 +160,9 @@ class GemmWArgs(C.Structure):
                 ("n", C.c_int32), ("k", C.c_int32), ("splits", C.c_int32), ("dtype", C.c_int32)]
 
 
+SUM_MAX_JOBS = 8        # AUM_SUM_MAX_JOBS
+
+
 class SumJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("outer", C.c_int64), ("inner", C.c_int64), ("tr_cols", C.c_int32), ("reserved", C.c_int32)]
 
@@ -998,9 +1001,10 @@ def conv1d_tm_fwd(x, weight, bias=None, silu=True, reverse=False, lib=None):
     return y
 
 
-def conv1d_tm_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, lib=None):
+def conv1d_tm_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, lib=None, partials=False):
     """-> (dx (batch, len, dim), dweight (dim, width) fp32, dbias (dim) fp32 | None); dx_out may be a strided token-major view (the
-    first half of d(in_proj output)).  The per-wave partial sums of dweight / dbias are added in a fixed order (aum_sum_rows)."""
+    first half of d(in_proj output)).  The per-wave partial sums of dweight / dbias are added in a fixed order (aum_sum_rows_multi);
+    partials=True: -> (dx, dw_part (nparts, dim, width), db_part (nparts, dim) | None) for a caller that sums them with other sets."""
     lib = lib or get()
     lib.check_tensor(x)
     batch, length, dim = x.shape
@@ -1021,6 +1025,8 @@ def conv1d_tm_bwd(x, weight, bias, dy, silu=True, reverse=False, dx_out=None, li
     a.batch, a.dim, a.len, a.width, a.dtype = batch, dim, length, width, _DT[x.dtype]
     a.flags = (CONV_SILU if silu else 0) | (CONV_REVERSE if reverse else 0)
     _launch(lib.c.aum_conv1d_tm_bwd, a, x, lib, "conv_tm_bwd", (batch, dim, length, x.element_size()))
+    if partials:
+        return dx, dw_part, db_part
     if db_part is None:
         return dx, sum_rows(dw_part, lib=lib), None           # (dim, width): the partial rows are in the weight's own layout
     dweight, dbias = sum_rows_multi([dw_part, db_part], lib=lib)      # both partial sets in one launch
@@ -1340,12 +1346,12 @@ def sum_rows(t, lib=None):
 
 
 def sum_rows_multi(parts, tr_cols=None, lib=None):
-    """parts: up to four (outer, ...) contiguous fp32 tensors of partial results on one device -> their fp32 sums over dim 0 in ONE launch
-    (aum_sum_rows_multi; the same order of additions as sum_rows).  tr_cols[q] > 0: part q is (outer, rows, tr_cols) and its sum is
+    """parts: up to SUM_MAX_JOBS (outer, ...) contiguous fp32 tensors of partial results on one device -> their fp32 sums over dim 0 in ONE launch
+    (aum_sum_rows_multi; bitwise the sums sum_rows gives one by one).  tr_cols[q] > 0: part q is (outer, rows, tr_cols) and its sum is
     returned transposed, (tr_cols, rows) contiguous.  Shapes the entry does not take go through sum_rows / torch one by one."""
     lib = lib or get()
     tr_cols = list(tr_cols or [0] * len(parts))
-    ok = 0 < len(parts) <= 4 and not debug.torch_sums and not debug.sums_one_by_one and all(
+    ok = 0 < len(parts) <= SUM_MAX_JOBS and not debug.torch_sums and not debug.sums_one_by_one and all(
         t.dtype == torch.float32 and t.is_contiguous() and t[0].numel() % 8 == 0 and t.data_ptr() % 16 == 0 and t.shape[0] > 0 and t[0].numel() > 0
         and (not tc or (t.dim() == 3 and t.shape[2] == tc)) for t, tc in zip(parts, tr_cols))
     if not ok:

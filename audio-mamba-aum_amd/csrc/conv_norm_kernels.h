@@ -512,19 +512,26 @@ template <class T, int RG> __global__ __launch_bounds__(256) void k_sum_rows(con
     sum_rows_body<T, RG>(src + (int64_t)blockIdx.y * outer * inner, dst + (int64_t)blockIdx.y * inner, outer, inner, (int)blockIdx.x, 0);     // blockIdx.y: batch entry
 }
 
-// up to four independent sums in one launch (aum_sum_rows_multi): a workgroup finds its job from the running workgroup counts
+// several independent sums in one launch (aum_sum_rows_multi): a workgroup finds its job from the running workgroup counts and runs it with the
+// row grouping aum_sum_rows would pick for that job alone (the same additions in the same order as a launch of its own)
+constexpr int SUM_MAX_JOBS = 8;
 struct SumJobs {
-    const float* src[4];
-    float* dst[4];
-    int64_t outer[4], inner[4];
-    int32_t tr_cols[4];
-    int32_t wg_end[4];
+    const float* src[SUM_MAX_JOBS];
+    float* dst[SUM_MAX_JOBS];
+    int64_t outer[SUM_MAX_JOBS], inner[SUM_MAX_JOBS];
+    int32_t tr_cols[SUM_MAX_JOBS], rg[SUM_MAX_JOBS], wg_end[SUM_MAX_JOBS];
 };
-template <int RG> __global__ __launch_bounds__(256) void k_sum_rows_multi(SumJobs js) {
+__global__ __launch_bounds__(256) void k_sum_rows_multi(SumJobs js) {
     const int wg = (int)blockIdx.x;
     int q = 0;
-    while (q < 3 && wg >= js.wg_end[q]) ++q;
-    sum_rows_body<float, RG>(js.src[q], js.dst[q], js.outer[q], js.inner[q], wg - (q ? js.wg_end[q - 1] : 0), js.tr_cols[q]);
+    while (q < SUM_MAX_JOBS - 1 && wg >= js.wg_end[q]) ++q;
+    const int wgx = wg - (q ? js.wg_end[q - 1] : 0);
+    switch (js.rg[q]) {         // uniform over the workgroup
+        case 1: sum_rows_body<float, 1>(js.src[q], js.dst[q], js.outer[q], js.inner[q], wgx, js.tr_cols[q]); break;
+        case 4: sum_rows_body<float, 4>(js.src[q], js.dst[q], js.outer[q], js.inner[q], wgx, js.tr_cols[q]); break;
+        case 16: sum_rows_body<float, 16>(js.src[q], js.dst[q], js.outer[q], js.inner[q], wgx, js.tr_cols[q]); break;
+        default: sum_rows_body<float, 64>(js.src[q], js.dst[q], js.outer[q], js.inner[q], wgx, js.tr_cols[q]); break;
+    }
 }
 #endif
 

@@ -336,11 +336,34 @@ def split_k_wgrad(a_mk, b_kn, splits, out_dtype=None):
 _HIP_WGRAD = _dbg_env("AUM_WGRAD", "hip") != "lib"
 
 
-def _wgrad_tm(dy2d, x2d, splits_hint, out_dtype):
-    """dW [N, K] = dy2d [T, N]^T @ x2d [T, K] for token-major operands"""
+def _wgrad_tm(dy2d, x2d, splits_hint, out_dtype, pending=None):
+    """dW [N, K] = dy2d [T, N]^T @ x2d [T, K] for token-major operands.  pending: a _PendingSums of the caller -- the kernel's partial tiles
+    join it and the gradient is what its run() returns at the index this function returns (fp32 parameters only)"""
     if _HIP_WGRAD and _HIP_GEMM and dy2d.is_cuda and aum_hip.gemm_wgrad_supported(dy2d, x2d):
+        if pending is not None and out_dtype == torch.float32:
+            return pending.add(aum_hip.gemm_wgrad(dy2d, x2d, partials=True))
         return aum_hip.gemm_wgrad(dy2d, x2d).to(out_dtype)
     return split_k_wgrad(dy2d.t(), x2d, _pick_splits(x2d.shape[0], splits_hint), out_dtype)
+
+
+class _PendingSums:
+    """the partial sets a layer's backward leaves behind (weight-gradient splits, per-wave conv partials), summed by ONE launch at the end of
+    the backward function instead of one 5-12 us launch each (aum_hip.sum_rows_multi; every set is added in the order a launch of its own uses)"""
+
+    def __init__(self):
+        self.parts, self.tr = [], []
+
+    def add(self, part, tr_cols=0):
+        self.parts.append(part)
+        self.tr.append(tr_cols)
+        return _PendingIndex(len(self.parts) - 1)
+
+    def run(self):
+        return aum_hip.sum_rows_multi(self.parts, self.tr) if self.parts else []
+
+
+class _PendingIndex(int):
+    pass
 
 
 class InProjFn(torch.autograd.Function):
@@ -656,10 +679,11 @@ def _inner_backward_tm(ctx, dout):
     dxz_t = torch.empty((Bsz, L, two_e), dtype=xz.dtype, device=xz.device)                   # SSI:537
     dx, dz = dxz_t[:, :, :E], dxz_t[:, :, E:]
     dout_proj_weight = dout_proj_bias = None
+    pend = _PendingSums()
     if ctx.has_out_proj:
         dout2 = dout.reshape(Bsz * L, -1).to(out_proj_weight.dtype)
         dout_z = _gemm_dgrad(dout2, out_proj_weight, out_proj_wt, 4).view(Bsz, L, E).to(conv_out.dtype)     # SSI:540
-        dout_proj_weight = _wgrad_tm(dout2, out_z.view(Bsz * L, E), _WGRAD_SPLITS[1], ctx.out_proj_wdtype)       # SSI:563
+        dout_proj_weight = _wgrad_tm(dout2, out_z.view(Bsz * L, E), _WGRAD_SPLITS[1], ctx.out_proj_wdtype, pend)     # SSI:563
         dout_proj_bias = dout2.sum(0) if not ctx.out_proj_bias_is_None else None
     else:
         dout_z = dout.transpose(1, 2)
@@ -684,10 +708,9 @@ def _inner_backward_tm(ctx, dout):
         # split-K products instead of raising inside backward)
         splits = _pick_splits(Bsz * L, _WGRAD_SPLITS[1])
         if aum_hip.gemm_wgrad_supported(ddelta2, x_dbl[:, :R]) and aum_hip.gemm_wgrad_supported(conv2d, dx_dbl):
-            # the two partial sets are summed by ONE launch, which also stores the x_proj gradient in the parameter's (R + 2N, E) layout
-            ddelta_proj_weight, dx_proj_weight = aum_hip.sum_rows_multi(
-                [aum_hip.gemm_wgrad(ddelta2, x_dbl[:, :R], partials=True),                                   # SSI:586  (E, R) fp32
-                 aum_hip.gemm_wgrad(conv2d, dx_dbl, partials=True)], [0, R + 2 * N])                         # SSI:589  (R + 2N, E) fp32
+            # the partial sets join the function's one sum launch, which also stores the x_proj gradient in the parameter's (R + 2N, E) layout
+            ddelta_proj_weight = pend.add(aum_hip.gemm_wgrad(ddelta2, x_dbl[:, :R], partials=True))          # SSI:586  (E, R) fp32
+            dx_proj_weight = pend.add(aum_hip.gemm_wgrad(conv2d, dx_dbl, partials=True), R + 2 * N)          # SSI:589  (R + 2N, E) fp32
         else:
             ddelta_proj_weight = split_k_wgrad(ddelta2.t(), x_dbl[:, :R], splits, torch.float32)
             dx_proj_weight = split_k_wgrad(dx_dbl.t(), conv2d, splits, torch.float32)
@@ -699,7 +722,11 @@ def _inner_backward_tm(ctx, dout):
         ddelta_proj_weight = split_k_wgrad(ddelta2.t(), x_dbl[:, :R], splits, torch.float32)     # SSI:586
         dx_proj_weight = split_k_wgrad(dx_dbl.t(), conv2d, splits, torch.float32)            # SSI:589
         du2.addmm_(dx_dbl, x_proj_weight.to(dx_dbl.dtype))                                   # SSI:590
-    _, dconv_w, dconv_b = aum_hip.conv1d_tm_bwd(x, conv_w, conv1d_bias, g["du"], True, ctx.reverse, dx_out=dx)   # SSI:594
+    _, dconv_w, dconv_b = aum_hip.conv1d_tm_bwd(x, conv_w, conv1d_bias, g["du"], True, ctx.reverse, dx_out=dx, partials=True)   # SSI:594
+    dconv_w, dconv_b = pend.add(dconv_w), (None if dconv_b is None else pend.add(dconv_b))
+    sums = pend.run()
+    dout_proj_weight, ddelta_proj_weight, dx_proj_weight, dconv_w, dconv_b = (
+        sums[v] if isinstance(v, _PendingIndex) else v for v in (dout_proj_weight, ddelta_proj_weight, dx_proj_weight, dconv_w, dconv_b))
     return dict(dxz=dxz_t.transpose(1, 2), dconv_w=dconv_w.reshape(E, 1, -1), dconv_b=dconv_b, dx_proj_w=dx_proj_weight,
                 ddt_proj_w=ddelta_proj_weight, dout_proj_w=dout_proj_weight, dout_proj_b=dout_proj_bias,
                 dA=g["dA"], dA_b=g.get("dA_b"), dD=g["dD"], ddelta_bias=g["ddelta_bias"], dB_proj_bias=None, dC_proj_bias=None)

@@ -594,13 +594,14 @@ int aum_hbm_copy(const void* src, void* dst, int64_t bytes, void* stream);
 int aum_sum_rows(const void* src, float* dst, int64_t batch, int64_t outer, int64_t inner, int32_t src_dtype, void* stream);
 
 /*
- * ABI 11: up to four independent fixed-order sums of fp32 partial results in ONE launch -- a layer's backward leaves its small partial sets in pairs
- * (the conv weight and bias partials of aum_conv1d_tm_bwd; the two skinny partial sets of aum_gemm_wgrad for the dt_proj / x_proj weights, SSI:586, 589),
- * and a 5 us launch per set is 5 us of the step.  Job q:  dst[i] = sum over o < outer of src[o][i],  i < inner  (the same order of additions as
- * aum_sum_rows with the same row grouping: bitwise repeatable).  tr_cols > 0: the summed (inner / tr_cols, tr_cols) matrix is stored transposed, dst
+ * ABI 11: up to AUM_SUM_MAX_JOBS independent fixed-order sums of fp32 partial results in ONE launch -- a layer's backward leaves five partial sets behind
+ * (the out_proj weight-gradient splits and the two skinny partial sets of aum_gemm_wgrad, SSI:563, 586, 589; the conv weight and bias partials of
+ * aum_conv1d_tm_bwd), and a 5 us launch per set is 5 us of the step.  Job q:  dst[i] = sum over o < outer of src[o][i],  i < inner  -- each job with
+ * the row grouping aum_sum_rows (batch = 1) picks for it, i.e. the same additions in the same order as a launch of its own: bitwise the same result.  tr_cols > 0: the summed (inner / tr_cols, tr_cols) matrix is stored transposed, dst
  * (tr_cols, inner / tr_cols) -- the x_proj weight gradient leaves aum_gemm_wgrad as (dim, R + 2N) and the parameter is (R + 2N, dim).
- * 1 <= njobs <= 4, inner % 8 == 0, inner % tr_cols == 0, 16-byte aligned pointers; `jobs` is read on the host during the call.
+ * 1 <= njobs <= AUM_SUM_MAX_JOBS, inner % 8 == 0, inner % tr_cols == 0, 16-byte aligned pointers; `jobs` is read on the host during the call.
  */
+#define AUM_SUM_MAX_JOBS 8
 typedef struct AumSumJob {
     const float* src;       /* (outer, inner) contiguous */
     float* dst;             /* (inner), or (tr_cols, inner / tr_cols) */

@@ -215,8 +215,8 @@ def test_sum_rows_multi_emu(emu):
     g1, g2 = aum_hip.sum_rows_multi([p1, p2], [0, 80], lib=emu)
     assert g1.shape == (32, 48) and g2.shape == (80, 32) and g2.is_contiguous()
     assert torch.allclose(g1, p1.sum(0), rtol=1e-5, atol=1e-5) and torch.allclose(g2, p2.sum(0).t(), rtol=1e-5, atol=1e-5)
-    four = [torch.randn(3, 8 * (q + 1)) for q in range(4)]
-    for got, t in zip(aum_hip.sum_rows_multi(four, lib=emu), four):
+    eight = [torch.randn(3 + q, 8 * (q + 1)) for q in range(aum_hip.SUM_MAX_JOBS)]
+    for got, t in zip(aum_hip.sum_rows_multi(eight, lib=emu), eight):
         assert torch.allclose(got, t.sum(0), rtol=1e-5, atol=1e-5)
     one = aum_hip.sum_rows_multi([torch.ones(1, 16)], lib=emu)
     assert torch.equal(one[0], torch.ones(16))
@@ -227,7 +227,7 @@ def test_sum_rows_multi_emu(emu):
     jobs = (aum_hip.SumJob * 1)()
     jobs[0].src, jobs[0].dst, jobs[0].outer, jobs[0].inner, jobs[0].tr_cols = dw.data_ptr(), gw.data_ptr(), 9, 96, 5          # 96 % 5 != 0
     assert emu.c.aum_sum_rows_multi(ctypes.cast(jobs, ctypes.c_void_p), 1, None) != 0
-    assert emu.c.aum_sum_rows_multi(ctypes.cast(jobs, ctypes.c_void_p), 5, None) != 0
+    assert emu.c.aum_sum_rows_multi(ctypes.cast(jobs, ctypes.c_void_p), aum_hip.SUM_MAX_JOBS + 1, None) != 0
 
 
 # ---- time-serial token-major kernels (scan_tm_kernels.h, conv_tm_kernels.h) ---------------------------------------------------

@@ -329,7 +329,9 @@ def test_sum_rows_multi(lib):
     torch.manual_seed(0)
     nparts = int(lib.c.aum_conv1d_tm_nparts(64, 513))
     cases = [([(nparts, 1536, 4), (nparts, 1536)], [0, 0]), ([(42, 1536, 48), (42, 1536, 80)], [0, 80]), ([(3, 8)], [0]), ([(2, 256 * 512 * 8)], [0]),
-             ([(7, 64, 16), (9, 40), (33, 24, 8), (64, 8)], [16, 0, 8, 0]), ([(600, 768), (600, 16)], [0, 0])]
+             ([(7, 64, 16), (9, 40), (33, 24, 8), (64, 8)], [16, 0, 8, 0]), ([(600, 768), (600, 16)], [0, 0]),
+             ([(14, 768, 1536), (42, 1536, 48), (42, 1536, 80), (nparts, 1536, 4), (nparts, 1536)], [0, 0, 80, 0, 0]),      # a layer's backward
+             ([(2 + q, 8 * (q + 1)) for q in range(aum_hip.SUM_MAX_JOBS)], [0] * aum_hip.SUM_MAX_JOBS)]
     for shapes, tr in cases:
         parts = [torch.randn(sh, device="cuda") for sh in shapes]
         got = aum_hip.sum_rows_multi(parts, tr, lib=lib)
@@ -340,6 +342,8 @@ def test_sum_rows_multi(lib):
             assert g.shape == ref.shape and g.is_contiguous() and g.dtype == torch.float32
             assert (g.double() - ref).abs().max() <= 2e-6 * max(1.0, ref.abs().max().item()) * t.shape[0] ** 0.5, (shapes, tr)
             assert torch.equal(g, g2)
+            one = aum_hip.sum_rows(t, lib=lib)                       # a job's additions are those of a launch of its own
+            assert torch.equal(g, one.t().contiguous() if tc else one)
 
 
 # ---- time-serial token-major kernels --------------------------------------------------------------------------------------------
