@@ -32,4 +32,14 @@ def enable(local_rank=0, tuning=True):
     os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "60")
     os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS", "10")
     os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
+    dump = os.environ.get("AUM_TUNABLEOP_DUMP")
+    if dump:        # tools/tune_job.sh: everything this process looked up or tuned, written out for merging into the recorded file
+        def _dump():
+            import torch.cuda.tunable as t
+            with open(dump, "w") as f:          # the layout of TunableOp's own result files
+                for v in t.get_validators():
+                    f.write("Validator," + ",".join(str(x) for x in v) + "\n")
+                for r in t.get_results():
+                    f.write(",".join(str(x) for x in r) + "\n")
+        atexit.register(_dump)          # (registered after the scratch directory's removal: runs before it)
     return d
