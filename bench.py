@@ -62,8 +62,8 @@ def gemm_probe(dev, ntok, d_model, d_inner, iters=20):
         return e0.elapsed_time(e1) / iters
 
     flop = 2.0 * ntok * d_model * 2 * d_inner
-    # the library GEMM exactly as the step issues it (token-aligned part + remainder: the shapes with recorded TunableOp solutions --
-    # the unsplit shape would be tuned online here, a few seconds of candidate kernels at the end of every bench run)
+    # the library GEMM exactly as the step issues it (ssi._mm_rows: one launch since round 5 -- a shape with a recorded TunableOp solution;
+    # a shape without one would be tuned online here, a few seconds of candidate kernels at the end of every bench run)
     ms_lib = timed(lambda: ssi._mm_rows(a, w.t(), 1))
     use_hip = ssi._hip_gemm_ok(a, w.shape[0], w.shape[1]) and aum_hip.gemm_tn_supported(a, w)
     ms = timed(lambda: aum_hip.gemm_tn(a, w)) if use_hip else ms_lib
@@ -88,7 +88,7 @@ def gemm_probe(dev, ntok, d_model, d_inner, iters=20):
             "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
             "avg_launch_ms": round(ms, 4),
             "library_gemm": {"avg_launch_ms": round(ms_lib, 4), "achieved": round(flop / (ms_lib * 1e-3) / 1e12, 1),
-                             "kernel": "hipBLASLt via TunableOp (token-aligned part + remainder, as in the step), same operands"}}
+                             "kernel": "hipBLASLt via TunableOp (one launch, as in the step), same operands"}}
 
 
 def scan_alg_bytes(meta, backward):
