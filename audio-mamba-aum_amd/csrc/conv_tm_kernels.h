@@ -1,12 +1,12 @@
 // conv_tm_kernels.h -- width <= 4 depthwise causal conv1d (+ SiLU) on TOKEN-MAJOR activations (batch, len, dim): the channel is the
-// fastest axis, so a lane owns 16 bytes of consecutive channels (8 of a 16-bit type), a wave 1 KB of a token row, and the causal
-// window is four REGISTER rows that slide along time -- no halo exchange between lanes, every global access a full 16 bytes per lane.
+// fastest axis, so a lane owns 16 (or, in the backward, 8) bytes of consecutive channels, a wave 1 KB (512 bytes) of a token row, and the causal
+// window is four REGISTER rows that slide along time -- no halo exchange between lanes, every global access 16 (8) bytes per lane.
 // x may be the first half of the in_proj output (row stride 2 * dim), dx the first half of its gradient.
 //   forward   (MS:272 / causal_conv1d_fn):  y[t] = silu(bias + sum_k w[k] x[t - (W-1) + k])
 //   backward  (SSI:594-596 call site):      dpre = dy silu'(pre);  dx[t] = sum_k w[k] dpre[t + (W-1) - k];
 //                                           dw[k] = sum_{b,t} dpre[t] x[t - (W-1) + k];  dbias = sum_{b,t} dpre[t]
 // AUM_CONV_REVERSE: the same on the time-reversed sequence (flip(conv(flip(x))) without the copies) -- the wave walks time the other way.
-// A wave takes CONVT_TC steps of one batch entry; the backward walks them from the last to the first (dx[t] needs dpre[t .. t+3], known
+// A wave takes convt_tc(len) steps of one batch entry; the backward walks them from the last to the first (dx[t] needs dpre[t .. t+3], known
 // by then) and leaves ONE partial row of dw / dbias per wave: [part][dim][k] and [part][dim] fp32, summed by aum_sum_rows in a fixed
 // order (no atomics: bitwise repeatable).
 #pragma once
@@ -15,34 +15,65 @@
 namespace aum {
 
 constexpr int CONVT_W = 4;
-#ifndef AUM_CONVT_TC
-#define AUM_CONVT_TC 64
+// Time steps per wave (at most) and bytes of a token row per lane, separately for the two kernels (round 5, profiles/r05_ab_conv_tc.txt): the
+// forward keeps 16 bytes per lane and 64-step chunks (L = 513: nine ranges of 57 steps; 3 x 64 x 9 = 1 728 waves at 140 registers, all resident);
+// the backward holds two tensors and a twice-as-wide window -- 251 registers at 16 bytes per lane, 1.69 waves per SIMD of which no SIMD can
+// take a third -- and runs with 8 bytes per lane (four channels of a 16-bit type, 136 registers) and 65-step chunks: 6 x 64 x 8 = 3 072 waves,
+// exactly three per SIMD (2.16 -> 1.92 ms per step of the bench, same box; the forward in that form 1.05 -> 1.08: not taken).
+#ifndef AUM_CONVT_TC_FWD
+#define AUM_CONVT_TC_FWD 64
 #endif
-constexpr int CONVT_TC = AUM_CONVT_TC;       // time steps per wave, at most (convt_tc)
-constexpr int CONVT_UB = 8;        // forward: steps fetched together (raw 16-byte fragments, widened when used); two such blocks in flight
+#ifndef AUM_CONVT_TC_BWD
+#define AUM_CONVT_TC_BWD 65
+#endif
+#ifndef AUM_CONVT_NB16_FWD
+#define AUM_CONVT_NB16_FWD 16
+#endif
+#ifndef AUM_CONVT_NB16_BWD
+#define AUM_CONVT_NB16_BWD 8
+#endif
+static_assert((AUM_CONVT_NB16_FWD == 16 || AUM_CONVT_NB16_FWD == 8) && (AUM_CONVT_NB16_BWD == 16 || AUM_CONVT_NB16_BWD == 8), "16 or 8 bytes per lane");
+constexpr int CONVT_UB = 8;        // steps fetched together (raw fragments, widened when used); the forward keeps two such blocks in flight
+template <bool BWD> AUM_HOSTDEV constexpr int convt_tcmax() { return BWD ? AUM_CONVT_TC_BWD : AUM_CONVT_TC_FWD; }
 
-AUM_HOSTDEV inline int convt_chunks(int len) { return (len + CONVT_TC - 1) / CONVT_TC; }
+template <bool BWD> AUM_HOSTDEV int convt_chunks(int len) { return (len + convt_tcmax<BWD>() - 1) / convt_tcmax<BWD>(); }
 // steps per wave: the row cut into convt_chunks(len) EQUAL ranges -- L = 513 is nine ranges of 57 steps, not eight of 64 and a ninth wave
 // with one step (same box: forward 1.17 -> 1.12 ms, backward 2.12 -> 2.02 ms per step of the bench)
-AUM_HOSTDEV inline int convt_tc(int len) {
-    const int nch = convt_chunks(len), t = (len + nch - 1) / nch;
-    return (nch - 1) * t < len ? t : CONVT_TC;
+template <bool BWD> AUM_HOSTDEV int convt_tc(int len) {
+    const int nch = convt_chunks<BWD>(len), t = (len + nch - 1) / nch;
+    return (nch - 1) * t < len ? t : convt_tcmax<BWD>();
 }
-template <class T> AUM_HOSTDEV constexpr int convt_vec() { return 16 / (int)sizeof(T); }
-template <class T> AUM_HOSTDEV inline int convt_cblocks(int dim) { return (dim + WAVE * convt_vec<T>() - 1) / (WAVE * convt_vec<T>()); }
-AUM_HOSTDEV inline int convt_nparts(int batch, int len) { return batch * convt_chunks(len); }
+template <class T, bool BWD> AUM_HOSTDEV constexpr int convt_nb() { return sizeof(T) == 4 ? 16 : (BWD ? AUM_CONVT_NB16_BWD : AUM_CONVT_NB16_FWD); }
+template <class T, bool BWD> AUM_HOSTDEV constexpr int convt_vec() { return convt_nb<T, BWD>() / (int)sizeof(T); }
+template <int NB> struct ConvtRawSel { typedef vq type; };
+template <> struct ConvtRawSel<8> { typedef vh type; };
+template <class T, bool BWD> using convt_raw = typename ConvtRawSel<convt_nb<T, BWD>()>::type;
+template <class T, bool BWD> AUM_DEV convt_raw<T, BWD> convt_load(const gbuf<T>& b, vi voff_bytes, int soff_bytes) {
+    if constexpr (convt_nb<T, BWD>() == 16) return gbuf_load16(b, voff_bytes, soff_bytes);
+    else return gbuf_load8(b, voff_bytes, soff_bytes);
+}
+template <class T, bool BWD> AUM_DEV void convt_unpack(const convt_raw<T, BWD>& q, vf (&o)[convt_vec<T, BWD>()]) {
+    if constexpr (convt_nb<T, BWD>() == 16) vq_unpack<T>(q, o);
+    else vh_unpack<T>(q, o);
+}
+template <class T, bool BWD> AUM_DEV void convt_store_m(const gbuf<T>& b, vi voff_bytes, int soff_bytes, const vf (&v)[convt_vec<T, BWD>()], vm m) {
+    if constexpr (convt_nb<T, BWD>() == 16) gbuf_store16_m(b, voff_bytes, soff_bytes, vq_pack<T>(v), m);
+    else gbuf_store8_m(b, voff_bytes, soff_bytes, vh_pack<T>(v), m);
+}
+template <class T, bool BWD> AUM_HOSTDEV int convt_cblocks(int dim) { return (dim + WAVE * convt_vec<T, BWD>() - 1) / (WAVE * convt_vec<T, BWD>()); }
+AUM_HOSTDEV inline int convt_nparts(int batch, int len) { return batch * convt_chunks<true>(len); }      // the backward's partial rows: one per (batch entry, chunk)
 
 AUM_DEV vf convt_silu(vf a) { return a * vsigmoid(a); }
 
-template <class T> struct ConvtLane {
-    static constexpr int V = convt_vec<T>();
+template <class T, bool BWD> struct ConvtLane {
+    static constexpr int V = convt_vec<T, BWD>();
     vf w[CONVT_W][V];      // w[k][v]: tap k (right-aligned: taps 4 - width .. 3 are real) of channel c0 + v
     vf bias[V];
     vi c0;                 // first channel of the lane (clamped into the tensor for lanes past the end)
     vm live;
 };
-template <class T> AUM_DEV void convt_lane_setup(const AumConvTmArgs& a, int cb, ConvtLane<T>& ln) {
-    constexpr int V = convt_vec<T>();
+template <class T, bool BWD> AUM_DEV void convt_lane_setup(const AumConvTmArgs& a, int cb, ConvtLane<T, BWD>& ln) {
+    constexpr int V = convt_vec<T, BWD>();
     const vi c = (lane_id() + cb * WAVE) * V;
     ln.live = c < a.dim;
     ln.c0 = vsel_i(ln.live, c, c * 0);
@@ -81,21 +112,21 @@ template <class T> AUM_DEV void convt_lane_setup(const AumConvTmArgs& a, int cb,
     }
 }
 
-// unit = (batch entry, chunk of CONVT_TC steps, block of 64 * V channels), channel block fastest
+// unit = (batch entry, chunk of convt_tc(len) steps, block of 64 * V channels), channel block fastest
 template <class T, bool SILU>
 AUM_DEV void convt_fwd_wave(const AumConvTmArgs& a, int wg) {
-    constexpr int V = convt_vec<T>(), ES = (int)sizeof(T);
-    const int ncb = convt_cblocks<T>(a.dim), nch = convt_chunks(a.len), L = a.len;
+    constexpr int V = convt_vec<T, false>(), ES = (int)sizeof(T);
+    const int ncb = convt_cblocks<T, false>(a.dim), nch = convt_chunks<false>(a.len), L = a.len;
     const int cb = wg % ncb, ch = (wg / ncb) % nch, b = wg / (ncb * nch);
     const bool rev = (a.flags & AUM_CONV_REVERSE) != 0;
-    ConvtLane<T> ln;
-    convt_lane_setup<T>(a, cb, ln);
+    ConvtLane<T, false> ln;
+    convt_lane_setup<T, false>(a, cb, ln);
     const gbuf<T> xb = make_gbuf(row_ptr<T>(a.x, (int64_t)b * a.x_bs));
     const gbuf<T> yb = make_gbuf(row_ptr<T>(a.y, (int64_t)b * a.y_bs));
     const vi coff = ln.c0 * ES;
     const int x_tb = (int)a.x_ts * ES, y_tb = (int)a.y_ts * ES;
     auto tok = [&](int it) { return rev ? L - 1 - it : it; };
-    const int tc = convt_tc(L);
+    const int tc = convt_tc<false>(L);
     const int it0 = ch * tc, it1 = it0 + tc < L ? it0 + tc : L;
     vf xw[CONVT_W][V];
     // the window before the chunk: steps it0 - 3 .. it0 - 1 (zero padding before the sequence)
@@ -103,7 +134,7 @@ AUM_DEV void convt_fwd_wave(const AumConvTmArgs& a, int wg) {
     for (int k = 0; k < CONVT_W - 1; ++k) {
         const int it = it0 - (CONVT_W - 1) + k;
         if (it >= 0) {
-            vq_unpack<T>(gbuf_load16(xb, coff, tok(it) * x_tb), xw[k + 1]);
+            convt_unpack<T, false>(convt_load<T, false>(xb, coff, tok(it) * x_tb), xw[k + 1]);
         } else {
             AUM_UNROLL
             for (int v = 0; v < V; ++v) xw[k + 1][v] = splat(0.f);
@@ -113,14 +144,14 @@ AUM_DEV void convt_fwd_wave(const AumConvTmArgs& a, int wg) {
     // fetched a block, waited, computed and only then fetched again left the memory pipe idle for the arithmetic of every block -- there
     // are fewer than two waves per SIMD to fill the gap at the bench shape).  Requests past the chunk are clamped to its last row: no
     // conditions around the loads (the compiler would wait for ALL of them at the join).
-    auto load_blk = [&](int itb, vq (&raw)[CONVT_UB]) {
+    auto load_blk = [&](int itb, convt_raw<T, false> (&raw)[CONVT_UB]) {
         AUM_UNROLL
         for (int j = 0; j < CONVT_UB; ++j) {
             const int it = itb + j < it1 ? itb + j : it1 - 1;
-            raw[j] = gbuf_load16(xb, coff, tok(it) * x_tb);
+            raw[j] = convt_load<T, false>(xb, coff, tok(it) * x_tb);
         }
     };
-    auto comp_blk = [&](int itb, const vq (&raw)[CONVT_UB]) {
+    auto comp_blk = [&](int itb, const convt_raw<T, false> (&raw)[CONVT_UB]) {
         AUM_UNROLL
         for (int j = 0; j < CONVT_UB; ++j) {
             if (itb + j < it1) {
@@ -129,7 +160,7 @@ AUM_DEV void convt_fwd_wave(const AumConvTmArgs& a, int wg) {
                     AUM_UNROLL
                     for (int v = 0; v < V; ++v) xw[k][v] = xw[k + 1][v];
                 }
-                vq_unpack<T>(raw[j], xw[CONVT_W - 1]);
+                convt_unpack<T, false>(raw[j], xw[CONVT_W - 1]);
                 vf y[V];
                 AUM_UNROLL
                 for (int v = 0; v < V; ++v) {
@@ -138,11 +169,11 @@ AUM_DEV void convt_fwd_wave(const AumConvTmArgs& a, int wg) {
                     for (int k = 0; k < CONVT_W; ++k) acc = vfma(ln.w[k][v], xw[k][v], acc);
                     y[v] = SILU ? convt_silu(acc) : acc;
                 }
-                gbuf_store16_m(yb, coff, tok(itb + j) * y_tb, vq_pack<T>(y), ln.live);
+                convt_store_m<T, false>(yb, coff, tok(itb + j) * y_tb, y, ln.live);
             }
         }
     };
-    vq ra[CONVT_UB], rb[CONVT_UB];
+    convt_raw<T, false> ra[CONVT_UB], rb[CONVT_UB];
     load_blk(it0, ra);
     for (int itb = it0; itb < it1; itb += 2 * CONVT_UB) {
         load_blk(itb + CONVT_UB, rb);
@@ -158,19 +189,19 @@ AUM_DEV void convt_fwd_wave(const AumConvTmArgs& a, int wg) {
 // last steps), their dw / dbias terms belong to the next chunk
 template <class T, bool SILU>
 AUM_DEV void convt_bwd_wave(const AumConvTmArgs& a, int wg) {
-    constexpr int V = convt_vec<T>(), ES = (int)sizeof(T);
-    const int ncb = convt_cblocks<T>(a.dim), nch = convt_chunks(a.len), L = a.len;
+    constexpr int V = convt_vec<T, true>(), ES = (int)sizeof(T);
+    const int ncb = convt_cblocks<T, true>(a.dim), nch = convt_chunks<true>(a.len), L = a.len;
     const int cb = wg % ncb, ch = (wg / ncb) % nch, b = wg / (ncb * nch);
     const bool rev = (a.flags & AUM_CONV_REVERSE) != 0;
-    ConvtLane<T> ln;
-    convt_lane_setup<T>(a, cb, ln);
+    ConvtLane<T, true> ln;
+    convt_lane_setup<T, true>(a, cb, ln);
     const gbuf<T> xb = make_gbuf(row_ptr<T>(a.x, (int64_t)b * a.x_bs));
     const gbuf<T> gb = make_gbuf(row_ptr<T>(a.dy, (int64_t)b * a.dy_bs));
     const gbuf<T> dxb = make_gbuf(row_ptr<T>(a.dx, (int64_t)b * a.dx_bs));
     const vi coff = ln.c0 * ES;
     const int x_tb = (int)a.x_ts * ES, g_tb = (int)a.dy_ts * ES, dx_tb = (int)a.dx_ts * ES;
     auto tok = [&](int it) { return rev ? L - 1 - it : it; };
-    const int tc = convt_tc(L);
+    const int tc = convt_tc<true>(L);
     const int it0 = ch * tc, it1 = it0 + tc < L ? it0 + tc : L;
     const int itop = it1 + (CONVT_W - 1) < L ? it1 + (CONVT_W - 1) : L;        // first step NOT recomputed
     // xw[k] = x[it - 3 + k] of the step being processed (walking down, a new x[it - 3] enters at k = 0); dp[k] = dpre[it + k]
@@ -189,20 +220,20 @@ AUM_DEV void convt_bwd_wave(const AumConvTmArgs& a, int wg) {
     for (int k = 1; k < CONVT_W; ++k) {
         const int it = itop - 1 - (CONVT_W - 1) + k;
         if (it >= 0) {
-            vq_unpack<T>(gbuf_load16(xb, coff, tok(it) * x_tb), xw[k - 1]);       // stored one slot low: the loop shifts up before use
+            convt_unpack<T, true>(convt_load<T, true>(xb, coff, tok(it) * x_tb), xw[k - 1]);       // stored one slot low: the loop shifts up before use
         } else {
             AUM_UNROLL
             for (int v = 0; v < V; ++v) xw[k - 1][v] = splat(0.f);
         }
     }
     for (int itb = itop - 1; itb >= it0; itb -= CONVT_UB) {
-        vq rx[CONVT_UB], rg[CONVT_UB];
+        convt_raw<T, true> rx[CONVT_UB], rg[CONVT_UB];
         AUM_UNROLL
         for (int j = 0; j < CONVT_UB; ++j) {
             const int it = itb - j >= it0 ? itb - j : it0;
             const int itx = it - (CONVT_W - 1) >= 0 ? it - (CONVT_W - 1) : 0;
-            rx[j] = gbuf_load16(xb, coff, tok(itx) * x_tb);
-            rg[j] = gbuf_load16(gb, coff, tok(it) * g_tb);
+            rx[j] = convt_load<T, true>(xb, coff, tok(itx) * x_tb);
+            rg[j] = convt_load<T, true>(gb, coff, tok(it) * g_tb);
         }
         AUM_UNROLL
         for (int j = 0; j < CONVT_UB; ++j) {
@@ -217,13 +248,13 @@ AUM_DEV void convt_bwd_wave(const AumConvTmArgs& a, int wg) {
                     }
                 }
                 if (it - (CONVT_W - 1) >= 0) {
-                    vq_unpack<T>(rx[j], xw[0]);
+                    convt_unpack<T, true>(rx[j], xw[0]);
                 } else {
                     AUM_UNROLL
                     for (int v = 0; v < V; ++v) xw[0][v] = splat(0.f);
                 }
                 vf g[V], dxv[V];
-                vq_unpack<T>(rg[j], g);
+                convt_unpack<T, true>(rg[j], g);
                 const bool own = it < it1;
                 AUM_UNROLL
                 for (int v = 0; v < V; ++v) {
@@ -246,7 +277,7 @@ AUM_DEV void convt_bwd_wave(const AumConvTmArgs& a, int wg) {
                         dxv[v] = s;
                     }
                 }
-                if (own) gbuf_store16_m(dxb, coff, tok(it) * dx_tb, vq_pack<T>(dxv), ln.live);
+                if (own) convt_store_m<T, true>(dxb, coff, tok(it) * dx_tb, dxv, ln.live);
             }
         }
     }

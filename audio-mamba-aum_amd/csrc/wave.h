@@ -445,6 +445,38 @@ template <class T> AUM_DEV vq vq_pack(const vf (&v)[16 / sizeof(T)]) {
     }
     return q;
 }
+// 8 bytes per lane of a 16-bit type (four elements): the narrow form of the 16-byte accesses above, for kernels that want twice the waves at
+// half the registers (conv_tm_kernels.h: the backward)
+struct vh { vi w[2]; };
+template <class T> AUM_DEV vh gbuf_load8(const gbuf<T>& b, vi voff_bytes, int soff_bytes) {
+    typedef int i2 __attribute__((ext_vector_type(2)));
+    const i2 v = __builtin_bit_cast(i2, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff_bytes, soff_bytes, 0));
+    vh q;
+    q.w[0] = v.x; q.w[1] = v.y;
+    return q;
+}
+template <class T> AUM_DEV void gbuf_store8_m(const gbuf<T>& b, vi voff_bytes, int soff_bytes, const vh& q, vm m) {
+    typedef int i2 __attribute__((ext_vector_type(2)));
+    const i2 u = {q.w[0], q.w[1]};
+    if (m) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(b.r, 0, 0, 0)), u), b.r, voff_bytes, soff_bytes, 0);
+}
+template <class T> AUM_DEV void vh_unpack(const vh& q, vf (&o)[4]) {
+    static_assert(sizeof(T) == 2, "16-bit element types");
+    AUM_UNROLL
+    for (int i = 0; i < 2; ++i) {
+        vpair_raw r;
+        r.w[0] = q.w[i];
+        r.w[1] = 0;
+        pair_raw_to_f32<T>(r, o[2 * i], o[2 * i + 1]);
+    }
+}
+template <class T> AUM_DEV vh vh_pack(const vf (&v)[4]) {
+    static_assert(sizeof(T) == 2, "16-bit element types");
+    vh q;
+    AUM_UNROLL
+    for (int i = 0; i < 2; ++i) q.w[i] = (int)f32x2_to_elem2<T>(v[2 * i], v[2 * i + 1]);
+    return q;
+}
 AUM_DEV void lds_write16(float* lds, vi byte_off, const vq& q) {
     typedef int i4 __attribute__((ext_vector_type(4)));
     *reinterpret_cast<i4*>(reinterpret_cast<char*>(lds) + byte_off) = i4{q.w[0], q.w[1], q.w[2], q.w[3]};
@@ -743,6 +775,45 @@ template <class T> inline vq vq_pack(const vf (&v)[16 / sizeof(T)]) {
         int w[4];
         std::memcpy(w, e, 16);
         for (int k = 0; k < 4; ++k) q.w[k].v[l] = w[k];
+    }
+    return q;
+}
+struct vh { vi w[2]; };
+template <class T> inline vh gbuf_load8(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes) {
+    vh q;
+    AUM_LANES {
+        int t[2];
+        std::memcpy(t, (const char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes, 8);
+        for (int k = 0; k < 2; ++k) q.w[k].v[l] = t[k];
+    }
+    return q;
+}
+template <class T> inline void gbuf_store8_m(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes, const vh& q, const vm& m) {
+    AUM_LANES if (m.v[l]) {
+        int t[2];
+        for (int k = 0; k < 2; ++k) t[k] = q.w[k].v[l];
+        std::memcpy((char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes, t, 8);
+    }
+}
+template <class T> inline void vh_unpack(const vh& q, vf (&o)[4]) {
+    static_assert(sizeof(T) == 2, "16-bit element types");
+    AUM_LANES {
+        int w[2];
+        for (int k = 0; k < 2; ++k) w[k] = q.w[k].v[l];
+        T e[4];
+        std::memcpy(e, w, 8);
+        for (int k = 0; k < 4; ++k) o[k].v[l] = elem_to_f32(e[k]);
+    }
+}
+template <class T> inline vh vh_pack(const vf (&v)[4]) {
+    static_assert(sizeof(T) == 2, "16-bit element types");
+    vh q;
+    AUM_LANES {
+        T e[4];
+        for (int k = 0; k < 4; ++k) f32_to_elem(v[k].v[l], e[k]);
+        int w[2];
+        std::memcpy(w, e, 8);
+        for (int k = 0; k < 2; ++k) q.w[k].v[l] = w[k];
     }
     return q;
 }
