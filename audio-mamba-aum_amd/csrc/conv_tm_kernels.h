@@ -29,6 +29,9 @@ constexpr int CONVT_W = 4;
 #ifndef AUM_CONVT_NB16_FWD
 #define AUM_CONVT_NB16_FWD 16
 #endif
+#ifndef AUM_CONVT_BWD_BLOCKS
+#define AUM_CONVT_BWD_BLOCKS 1     // 8-step blocks of loads the backward keeps in flight (2: opt-in A/B build)
+#endif
 #ifndef AUM_CONVT_NB16_BWD
 #define AUM_CONVT_NB16_BWD 8
 #endif
@@ -226,15 +229,16 @@ AUM_DEV void convt_bwd_wave(const AumConvTmArgs& a, int wg) {
             for (int v = 0; v < V; ++v) xw[k - 1][v] = splat(0.f);
         }
     }
-    for (int itb = itop - 1; itb >= it0; itb -= CONVT_UB) {
-        convt_raw<T, true> rx[CONVT_UB], rg[CONVT_UB];
+    auto load_blk = [&](int itb, convt_raw<T, true> (&rx)[CONVT_UB], convt_raw<T, true> (&rg)[CONVT_UB]) {
         AUM_UNROLL
-        for (int j = 0; j < CONVT_UB; ++j) {
+        for (int j = 0; j < CONVT_UB; ++j) {                    // requests below the chunk are clamped to its first row: no conditions around the loads
             const int it = itb - j >= it0 ? itb - j : it0;
             const int itx = it - (CONVT_W - 1) >= 0 ? it - (CONVT_W - 1) : 0;
             rx[j] = convt_load<T, true>(xb, coff, tok(itx) * x_tb);
             rg[j] = convt_load<T, true>(gb, coff, tok(it) * g_tb);
         }
+    };
+    auto comp_blk = [&](int itb, const convt_raw<T, true> (&rx)[CONVT_UB], const convt_raw<T, true> (&rg)[CONVT_UB]) {
         AUM_UNROLL
         for (int j = 0; j < CONVT_UB; ++j) {
             const int it = itb - j;
@@ -280,7 +284,24 @@ AUM_DEV void convt_bwd_wave(const AumConvTmArgs& a, int wg) {
                 if (own) convt_store_m<T, true>(dxb, coff, tok(it) * dx_tb, dxv, ln.live);
             }
         }
+    };
+#if AUM_CONVT_BWD_BLOCKS == 2
+    // two blocks in flight, as in the forward: with 8 bytes per lane the second block's 32 raw registers fit under the three-waves-per-SIMD limit
+    convt_raw<T, true> ax[CONVT_UB], ag[CONVT_UB], bx[CONVT_UB], bg[CONVT_UB];
+    load_blk(itop - 1, ax, ag);
+    for (int itb = itop - 1; itb >= it0; itb -= 2 * CONVT_UB) {
+        load_blk(itb - CONVT_UB, bx, bg);
+        comp_blk(itb, ax, ag);
+        load_blk(itb - 2 * CONVT_UB, ax, ag);
+        comp_blk(itb - CONVT_UB, bx, bg);
     }
+#else
+    for (int itb = itop - 1; itb >= it0; itb -= CONVT_UB) {
+        convt_raw<T, true> rx[CONVT_UB], rg[CONVT_UB];
+        load_blk(itb, rx, rg);
+        comp_blk(itb, rx, rg);
+    }
+#endif
     // partial rows of this wave: dw_part[part][dim][k] (the weight's own layout: a lane's 8 channels x 4 taps are 128 contiguous bytes, and the
     // sum over the parts is the gradient as it is -- round 3 wrote [part][k][dim] and paid a transposing copy per layer), db_part[part][dim]
     const int part = b * nch + ch;
