@@ -20,6 +20,20 @@
 #   r04_ab_skinny_gradients.txt              bench_ab xdt_tm_bwd,gemm_wgrad d=- l=AUM_XDT_BWD_LIB=1 x2
 #   r04_ab_conv_tm.txt                       bench_ab conv_tm_fwd,conv_tm_bwd d=- o=lib:convold x2
 #   wgrad pipelining / AUM_WGRAD=lib         bench_ab gemm_wgrad d=- w=lib:wpipe0 l=AUM_WGRAD=lib x2  --  probe wgrad_probe.py
+# Round-5 measurements (build the named variants first: tools/build_variant.sh <name> <flags>; finish with csrc/build.py --force for the default):
+#   r05_ab_lsum.txt          l0 -DAUM_SCANT_LSUM=0 | l1 -DAUM_SCANT_LSUM=1 | l1a + -DAUM_LSUM_PUT_ASM=1 | babl1 / babl2 -DAUM_SCANT_BABL=1 / 2
+#                            tm_ab bwd l0 l1 l1a babl1 babl2  --  pytest scan_tm  --  bench_ab scan_tm_bwd_bidir d=- l0=lib:l0 l1a=lib:l1a x2
+#   r05_ab_dbc_merge.txt     nomerge -DAUM_SCANT_DBC_MERGE=0:  tm_ab bwd nomerge  --  bench_ab scan_tm_bwd_bidir d=- n=lib:nomerge x2
+#   r05_ab_bwd_prio.txt      bprio0 -DAUM_SCANT_BPRIO=0 (others: -DAUM_SCANT_BPRIO_SHIFT=1|2, _HI=1, BPRIO=2|3):  tm_ab bwd bprio0  --  bench_ab scan_tm_bwd_bidir d=- p0=lib:bprio0 x2
+#                            --  variants long  (and the same after AUM_HIP_LIB=.../libaum_hip_bprio0.so)
+#   r05_gemm_w4_ring.txt     GEMM_PROBE_FLAGS=4,64,128 probe gemm_probe.py      (flags 64 / 128: the four-wave / ring forms of aum_gemm_tn)
+#   r05_gemm_dispatch_ab.txt bench_ab gemm_tn d=- nofwd=AUM_GEMM_SHAPES=1536x768 none=AUM_GEMM_SHAPES=1x1 fwdonly=AUM_GEMM_SHAPES=3072x768 x3
+#                            bench_ab gemm_tn d=- m13=AUM_GEMM_TOKEN_SPLIT=13 m1=AUM_GEMM_TOKEN_SPLIT=1 m8=AUM_GEMM_TOKEN_SPLIT=8 x3      (d = 0 now)
+#   r05_ab_sum_multi.txt     bench_ab "" d=- o=AUM_SUMS_ONE_BY_ONE=1 x3
+#   r05_ab_conv_tc.txt       cv16 -DAUM_CONVT_NB16_BWD=16 -DAUM_CONVT_TC_BWD=64 (the round-4 backward) | cvb2 -DAUM_CONVT_BWD_BLOCKS=2:
+#                            bench_ab conv_tm_fwd,conv_tm_bwd d=- o=lib:cv16 b=lib:cvb2 x2
+#   r05_ab_bibi_ddp_streams.txt   variants bibi_ddp
+#   GEMM solutions (aum/tunableop_gfx950.csv)   tools/tune_job.sh, then tools/merge_tunable.py gpurun_out/tunable_*.csv
 set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export PYTHONPATH=$PWD/audio-mamba-aum_amd:${PYTHONPATH:-}
