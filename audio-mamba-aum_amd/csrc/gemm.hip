@@ -4,6 +4,7 @@
 #include "gemm_kernels.h"
 #include "gemm_w4_kernels.h"
 #include "gemm_ring_kernels.h"
+#include "gemm_ps_kernels.h"
 #include "dtproj_kernels.h"
 #include "xdt_kernels.h"
 #include "decode_kernels.h"
@@ -44,6 +45,18 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
     // workgroup per tile is as fast or faster (84.3 vs 87.4 us, 159.4 vs 162.2 us; profiles/r03_gemm_probe.txt) -- since round 4 with the
     // software-pipelined K loop (SCHED 2: 74.6 / 134.7 us on the box where the persistent kernel took 82.7 / 154.2)
     uint32_t flags = g.flags;
+    if (flags & AUM_GEMM_PACED) {
+        if (g.k < (aumg::PS_NST + 1) * aumg::BK) return AUM_E_UNSUPPORTED;
+        aumg::GemmLaunch L;
+        L.g = g;
+        L.full_rb = (g.m + aumg::BM - 1) / aumg::BM;
+        L.half_rb = 0;
+        L.nitems = L.full_rb * (g.n / aumg::BN);
+        const int grid = L.nitems < ncu ? L.nitems : ncu;
+        if (g.dtype == AUM_BF16) hipLaunchKernelGGL(aumg::k_gemm_tn_ps<true>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
+        else hipLaunchKernelGGL(aumg::k_gemm_tn_ps<false>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
+        return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
+    }
     if (flags & AUM_GEMM_RING) {
         if (g.n % aumg::RING_BN || g.k < 8 * aumg::RING_BK) return AUM_E_UNSUPPORTED;
         aumg::GemmLaunch L;

@@ -46,6 +46,9 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 #ifndef AUM_GEMM_PRIO
 #define AUM_GEMM_PRIO 0     // A/B builds: 1 the second-dispatched half of the waves (4-7, the younger wave of every SIMD) holds priority 1; 2 the two waves of a SIMD take turns K-step by K-step
 #endif
+#ifndef AUM_GEMM_ABL
+#define AUM_GEMM_ABL 0      // timing experiments on the persistent kernel only (wrong results; tools/gemm_abl_probe.py): 1 no tile-end stores, 2 two dummy
+#endif                      // stores per wave in each of a tile's first eight K-steps (the paced-store pattern), 4 no DMA pieces inside the K loop, 8 no reads / MFMAs
 constexpr int NWAVES = 8, THREADS = NWAVES * 64;
 constexpr int TILE_BYTES = BM * BK * 2;                 // one operand, one K-step: 32 KB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;             // A | B
@@ -331,17 +334,39 @@ __device__ __forceinline__ GemmItem gemm_item(const GemmLaunch& L, int id, int n
 template <bool BF16, int NI>
 __device__ __forceinline__ void gemm_steps(f4v (&acc)[8][4], int nk, int par, bool active, char* lds, int a_rd, int b_rd, __amdgpu_buffer_rsrc_t ra,
                                            __amdgpu_buffer_rsrc_t rb, bool has_next, __amdgpu_buffer_rsrc_t ra_n, __amdgpu_buffer_rsrc_t rb_n,
-                                           int voff_a, int voff_b, int rowstep_a, int rowstep_b, int w, bool stores16, uint32_t L_flags) {
+                                           int voff_a, int voff_b, int rowstep_a, int rowstep_b, int w, bool stores16, uint32_t L_flags,
+                                           char* abl_c = nullptr, int64_t abl_ldc2 = 0, int abl_row0 = 0, int abl_rows = 0) {
     for (int t = 0; t < nk; ++t) {
         if (AUM_GEMM_PRIO == 2) { if ((t + (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         if (t == 0 && stores16 && !(L_flags & (AUM_GEMM_NO_COUNTED_WAIT | AUM_GEMM_NO_PREFETCH))) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if ((AUM_GEMM_ABL & 2) && t >= 1 && t <= NI) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // the previous step's two stores stay in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (AUM_GEMM_ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's ds_write of the step's pieces
         __builtin_amdgcn_s_barrier();
         char* nxt = lds + ((par + t + 1) & 1) * STAGE_BYTES;
-        if (t + 1 < nk) stage(ra, rb, voff_a, voff_b, (t + 1) * (BK * 2), rowstep_a, rowstep_b, nxt, w);
+        u4v rg_a[4], rg_b[4];                        // AUM_GEMM_ABL & 16: the next step's pieces through registers (buffer_load -> ds_write_b128) instead of LDS-DMA
+        if (AUM_GEMM_ABL & 16) {
+            const bool nx = t + 1 < nk;
+            const __amdgpu_buffer_rsrc_t qa = nx ? ra : ra_n, qb = nx ? rb : rb_n;
+            const int kb = nx ? (t + 1) * (BK * 2) : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rg_a[j] = __builtin_amdgcn_raw_buffer_load_b128(qa, voff_a, kb + j * rowstep_a, 0);
+                rg_b[j] = __builtin_amdgcn_raw_buffer_load_b128(qb, voff_b, kb + j * rowstep_b, 0);
+            }
+        } else if (AUM_GEMM_ABL & 4) {
+        } else if (t + 1 < nk) stage(ra, rb, voff_a, voff_b, (t + 1) * (BK * 2), rowstep_a, rowstep_b, nxt, w);
         else if (has_next && !(L_flags & AUM_GEMM_NO_PREFETCH)) stage(ra_n, rb_n, voff_a, voff_b, 0, rowstep_a, rowstep_b, nxt, w);
         const char* st = lds + ((par + t) & 1) * STAGE_BYTES;
-        if (active) {
+        if ((AUM_GEMM_ABL & 2) && t < NI) {           // the paced-store pattern with whatever two registers hold: row block t of the tile, both halves
+            const int row = abl_row0 + t * 16;
+            if (row < abl_rows) {
+                u4v* dst = reinterpret_cast<u4v*>(abl_c + (int64_t)row * abl_ldc2);
+                dst[0] = __builtin_bit_cast(u4v, acc[0][0]);
+                dst[4] = __builtin_bit_cast(u4v, acc[0][1]);
+            }
+        }
+        if (active && !(AUM_GEMM_ABL & 8)) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 s8v bf[4], af[NI];
@@ -353,6 +378,14 @@ __device__ __forceinline__ void gemm_steps(f4v (&acc)[8][4], int nk, int par, bo
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(bf[j], af[i], acc[i][j]);
+            }
+        }
+        if (AUM_GEMM_ABL & 16) {
+            const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<u4v*>(nxt + (j * 8 + w) * 1024 + lane * 16) = rg_a[j];
+                *reinterpret_cast<u4v*>(nxt + TILE_BYTES + (j * 8 + w) * 1024 + lane * 16) = rg_b[j];
             }
         }
     }
@@ -432,8 +465,15 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_persistent(GemmLaunch L)
         const int a_rd = (row_base + rho) * 128 + a_swz;
         char* c_rows = static_cast<char*>(g.c) + ((int64_t)it.m0 * g.ldc + it.n0 + wc * 64 + kg * 8) * 2;
         if (!it.half) {
-            gemm_steps<BF16, 8>(acc, nk, par, true, lds, a_rd, b_rd, ra, rb, has_next, ra_n, rb_n, voff_a, voff_b, rowstep_a, rowstep_b, w, stores16, g.flags);
-            gemm_store<BF16, 8>(acc, c_rows, (int64_t)g.ldc * 2, row_base + rho, it.rows);
+            gemm_steps<BF16, 8>(acc, nk, par, true, lds, a_rd, b_rd, ra, rb, has_next, ra_n, rb_n, voff_a, voff_b, rowstep_a, rowstep_b, w,
+                                (AUM_GEMM_ABL & 1) ? false : stores16, g.flags, c_rows, (int64_t)g.ldc * 2, row_base + rho, it.rows);
+            if (!(AUM_GEMM_ABL & 1)) gemm_store<BF16, 8>(acc, c_rows, (int64_t)g.ldc * 2, row_base + rho, it.rows);
+            else {          // the accumulators stay live (no code): without a consumer the compiler deletes the MFMAs and their reads
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+            }
         } else {
             gemm_steps<BF16, 4>(acc, nk, par, row_base < it.rows, lds, a_rd, b_rd, ra, rb, has_next, ra_n, rb_n, voff_a, voff_b, rowstep_a,
                                 rowstep_b, w, stores16, g.flags);

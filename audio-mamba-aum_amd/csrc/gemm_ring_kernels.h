@@ -28,7 +28,7 @@
 namespace aumg {
 
 #ifndef AUM_RING_ABL
-#define AUM_RING_ABL 0      // timing experiments only (wrong results): 1 no DMA pieces inside the steps, 2 no fragment reads inside the steps, 4 no barrier
+#define AUM_RING_ABL 0      // timing experiments only (wrong results): 1 no DMA pieces inside the steps, 2 no fragment reads inside the steps, 4 no barrier, 8 no MFMAs
 #endif
 constexpr int RING_BK = 32, RING_NJ = 6, RING_BN = 32 * RING_NJ;
 constexpr int RING_TA = BM * RING_BK * 2, RING_TB = RING_BN * RING_BK * 2;        // 16 KB + 12 KB
@@ -138,7 +138,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_gemm_tn_ring(GemmLaunch L) {
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    if constexpr (MODE == 0) mfma_first<BF16>(acc[i][j], bf[SET][j], af[SET][i]);
+                    if constexpr (AUM_RING_ABL & 8) {          // no MFMAs: the DMA stream (and the stores) alone
+                        if constexpr (MODE == 0) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+                    } else if constexpr (MODE == 0) mfma_first<BF16>(acc[i][j], bf[SET][j], af[SET][i]);
                     else mfma_acc<BF16>(acc[i][j], bf[SET][j], af[SET][i]);
                     const int m = i * NJ + j;
                     // side operations, one per two MFMAs: the 7 pieces first (they have the longest way), then the 14 fragment reads.  In a
