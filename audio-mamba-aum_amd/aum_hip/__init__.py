@@ -779,7 +779,7 @@ def gemm_tn_supported(a, b):
             and 512 * a.stride(0) < 2 ** 31 and 512 * b.stride(0) < 2 ** 31)
 
 
-GEMM_LOCKSTEP, GEMM_STAGGERED, GEMM_PERSISTENT, GEMM_PIPELINED, GEMM_W4, GEMM_RING, GEMM_PACED, GEMM_STREAM = 1, 2, 4, 32, 64, 128, 256, 512
+GEMM_LOCKSTEP, GEMM_STAGGERED, GEMM_PERSISTENT, GEMM_PIPELINED, GEMM_W4, GEMM_RING, GEMM_PACED = 1, 2, 4, 32, 64, 128, 256
 
 
 def gemm_tn(a, b, out=None, lib=None, flags=0, split_tail=None):

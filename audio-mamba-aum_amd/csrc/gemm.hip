@@ -45,18 +45,11 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
     // workgroup per tile is as fast or faster (84.3 vs 87.4 us, 159.4 vs 162.2 us; profiles/r03_gemm_probe.txt) -- since round 4 with the
     // software-pipelined K loop (SCHED 2: 74.6 / 134.7 us on the box where the persistent kernel took 82.7 / 154.2)
     uint32_t flags = g.flags;
-    if (flags & AUM_GEMM_STREAM) {
-        if (g.k < 16 * aumg::S4_BK) return AUM_E_UNSUPPORTED;
-        aumg::GemmLaunch L;
-        L.g = g;
-        L.full_rb = (g.m + aumg::BM - 1) / aumg::BM;
-        L.half_rb = 0;
-        L.nitems = L.full_rb * (g.n / aumg::BN);
-        const int grid = L.nitems < ncu ? L.nitems : ncu;
-        if (g.dtype == AUM_BF16) hipLaunchKernelGGL(aumg::k_gemm_tn_stream<true>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
-        else hipLaunchKernelGGL(aumg::k_gemm_tn_stream<false>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
-        return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
-    }
+    // default (no schedule named): the paced-store kernel of round 6 whenever a tile has the seven K-steps its store pacing needs (every
+    // projection of the model: k >= 768); shorter products keep the round-3 / round-4 kernels below
+    if (!(flags & (AUM_GEMM_LOCKSTEP | AUM_GEMM_STAGGERED | AUM_GEMM_PERSISTENT | AUM_GEMM_PIPELINED | AUM_GEMM_W4 | AUM_GEMM_RING | AUM_GEMM_PACED))
+        && g.k >= (aumg::PS_NST + 1) * aumg::BK)
+        flags |= AUM_GEMM_PACED;
     if (flags & AUM_GEMM_PACED) {
         if (g.k < (aumg::PS_NST + 1) * aumg::BK) return AUM_E_UNSUPPORTED;
         aumg::GemmLaunch L;

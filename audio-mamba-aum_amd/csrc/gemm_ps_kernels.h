@@ -21,7 +21,15 @@
 //     i), and its stores leave paced: fragment rows 0, 1 inside that last step, rows 2 .. 7 two stores per K-step under the NEXT tile's first
 //     six steps (48 parked registers; with all 64 parked the kernel spilled).  Buffer stores: rows beyond M are dropped by the range
 //     check, so every tile issues the same 16 stores per wave and the counted waits -- vmcnt(2), vmcnt(4) in a last step -- hold for all;
-//   * a tile's first half step multiplies with a zero addend (no accumulator fill).
+//   * a tile's first half step multiplies with a zero addend (no accumulator fill);
+//   * a ragged last row block (64 x 513 tokens = 128 row blocks + 64 rows) is an ordinary item whose rows beyond M read as zero (no memory
+//     traffic: such a tile runs at the MFMA stream's pace, 0.65 of a full one) and are dropped by the stores' range check.
+// Built on top of this and measured slower or level, all bit-equal (profiles/r06_gemm_ablations.txt (5), removed again): four 32-deep stages with
+// the pieces requested four steps ahead (half cache lines per request: every line crosses the L2 -> L1 path twice -- also why round 5's ring
+// kernel lost); L2 prefetch touches three steps ahead (64 lines per 4-byte load are 64 tag look-ups in the CU's L1); skipping the MFMAs of
+// fragment rows beyond M (a scalar test per MFMA costs every tile 20 %; a second copy of the steps for ragged tiles makes the register
+// allocator move the accumulators between the copies: 112 spills); two copies of the loop for the two waves of a SIMD with their pieces
+// and stores at different MFMAs (level).
 #pragma once
 #include "gemm_kernels.h"
 
@@ -64,16 +72,12 @@ __device__ __forceinline__ void ps_item(const GemmLaunch& L, int id, int ntn, in
     rows = L.g.m - m0 < BM ? L.g.m - m0 : BM;
 }
 
-#ifndef AUM_PS_PF
-#define AUM_PS_PF 1         // the L2 prefetch touches (0: without, for A/B runs)
-#endif
-constexpr int PS_PF_DIST = 3;       // how many K-steps ahead of a step's pieces its cache lines are touched
 constexpr int PS_NST = 6;           // K-steps of a tile that carry the previous tile's stores (fragment rows 2 .. 7, two stores per wave each); rows 0, 1 leave
                                     // inside the tile's own last step: 48 parked registers instead of 64 (64 spilled); k >= 7 * 64
 
 template <bool BF16>
 __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_ps(GemmLaunch L) {
-    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES + (AUM_PS_PF ? 512 : 0)];        // + the landing place of the L2 prefetch touches
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
     const AumGemmArgs& g = L.g;
     const int lane = (int)(threadIdx.x & 63u);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -95,10 +99,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_ps(GemmLaunch L) {
     // stores: lane holds, for fragment row i, columns wc * 64 + 32 (j >> 1) + 8 kg + 4 (j & 1) + r of row wr * 128 + 16 i + rho
     const int ldc2 = g.ldc * 2;
     const int c_voff = (wr * 128 + rho) * ldc2 + (wc * 64 + kg * 8) * 2;
-    // L2 prefetch: one dword per 64 bytes of the 32 + 32 cache lines this wave's eight pieces of a K-step cover (lane l: row 8 w + (l & 7) + 64 ((l >> 3) & 3),
-    // half l >> 5 of its 128 bytes), sent PF_DIST steps ahead of the pieces as two 4-byte LDS-DMA loads into a scratch corner of LDS (no register)
-    const int pf_row = w * 8 + (lane & 7) + 64 * ((lane >> 3) & 3);
-    const int pf_a = pf_row * g.lda * 2 + (lane >> 5) * 64, pf_b = pf_row * g.ldb * 2 + (lane >> 5) * 64;
 
     auto rsrc_a = [&](int m0, int rows) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(g.a) + (int64_t)((AUM_PS_ABL & 16) ? 0 : m0) * g.lda * 2), 0, rows * g.lda * 2, 0x00020000);
@@ -177,9 +177,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_ps(GemmLaunch L) {
             const __amdgpu_buffer_rsrc_t ra_1 = same1 ? ra : ra_n, rb_1 = same1 ? rb : rb_n;
             const __amdgpu_buffer_rsrc_t ra_2 = same2 ? ra : ra_n, rb_2 = same2 ? rb : rb_n;
             const int kb1 = (same1 ? t + 1 : 0) * (BK * 2), kb2 = (same2 ? t + 2 : t + 2 - nk) * (BK * 2);
-            const bool same3 = t + PS_PF_DIST < nk;
-            const __amdgpu_buffer_rsrc_t ra_3 = same3 ? ra : ra_n, rb_3 = same3 ? rb : rb_n;
-            const int kb3 = (same3 ? t + PS_PF_DIST : t + PS_PF_DIST - nk) * (BK * 2);
             // ---- first half: fragment rows g = 0 .. 7 on bfA
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -193,10 +190,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_ps(GemmLaunch L) {
                     }
                     if (j == 3 && i >= 4) bfB[i - 4] = lds_frag(cur, (b_rd ^ 64) + b_joff(i - 4));      // the second half's weight fragments
                     if (i < 2 && (j == 0 || j == 2)) piece(ra_1, rb_1, kb1, oth, 4 + i * 2 + (j >> 1));
-                    if (AUM_PS_PF && !(AUM_PS_ABL & 1) && i == 2 && j == 0)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_3, (lds_ptr_t)(lds + LDS_BYTES), 4, pf_a, kb3, 0, 0);
-                    if (AUM_PS_PF && !(AUM_PS_ABL & 1) && i == 2 && j == 2)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_3, (lds_ptr_t)(lds + LDS_BYTES + 256), 4, pf_b, kb3, 0, 0);
                     if constexpr (ST >= 0 && !(AUM_PS_ABL & 2)) {
                         if ((i == 3 || i == 4) && j == 0)
                             __builtin_amdgcn_raw_buffer_store_b128(pend[ST][i - 3], rc_prev, c_voff + (ST + 2) * 16 * ldc2 + (i - 3) * 64, 0, 0);
@@ -209,10 +202,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_ps(GemmLaunch L) {
                 if (i == 5) {
                     // every read of this step's stage has been issued (the last one under row 12); this wave's have returned, its pieces of
                     // step t + 1 have landed (behind them: this step's two stores at most) -- and, past the barrier, everybody's
-                    // (behind the pieces: the step's two prefetch touches, then its stores -- two, or the four of rows 0, 1 in a tile's last step)
-                    constexpr int NPF = (AUM_PS_PF && !(AUM_PS_ABL & 1)) ? 2 : 0;
+                    // (behind the pieces: the step's stores -- two, or the four of rows 0, 1 in a tile's last step)
                     constexpr int NSTO = (AUM_PS_ABL & 2) ? 0 : ST >= 0 ? 2 : LAST ? 4 : 0;
-                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPF + NSTO) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSTO) : "memory");
                     __builtin_amdgcn_s_barrier();
                 }
 #pragma unroll
@@ -275,232 +267,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_ps(GemmLaunch L) {
         kstep(PsC<0>{}, PsC<5>{}, PsC<0>{}, 5);
         for (int t = PS_NST; t + 1 < nk; ++t) kstep(PsC<0>{}, PsC<-1>{}, PsC<0>{}, t);
         kstep(PsC<0>{}, PsC<-1>{}, PsC<1>{}, nk - 1);
-        rc_prev = rc;
-        if (!has_next) break;
-        id = nid;
-        m0 = m1, n0 = n1, rows = rows1;
-        ra = ra_n;
-        rb = rb_n;
-    }
-    // the last tile's stores (rows 2 .. 7; rows 0, 1 left in its last step)
-    if (!(AUM_PS_ABL & 2)) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_raw_buffer_store_b128(pend[i][0], rc_prev, c_voff + (i + 2) * 16 * ldc2, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(pend[i][1], rc_prev, c_voff + (i + 2) * 16 * ldc2 + 64, 0, 0);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------------
-// The same kernel on a FOUR-stage ring of 32-deep K-steps (AUM_GEMM_STREAM).  What the ablations of the two-stage form above said
-// (profiles/r06_gemm_ablations.txt; in_proj forward, 7 rounds of 12 K-steps): everything 135 us | no DMA pieces 108 | no stores 117-125 | neither
-// 86.5 (= the MFMA stream, at the matrix pipes' pace) | no MFMAs 111 | DMA + reads + barriers only 87.  Memory path and MFMA stream each need
-// ~1.03 us per K-step, together they take 1.6: with two 64-deep stages a step's pieces can only be requested once the previous step has
-// been read (the barrier) and have to land before the next barrier -- one step of flight time for a burst that takes about that long, every
-// delay lands on the matrix pipes.  Here a stage is 32 deep (256 + 256 rows of 64 bytes = 32 KB, the LDS image of gemm_ring_kernels.h:
-// f_A(row) = G[(row >> 2) & 3], f_B(row) = G[(row >> 3) & 3], G = {0, 3, 2, 1}), four of them: the pieces of step p + 4 are requested
-// behind the barrier of step p (into the stage step p was read from) and are needed at the barrier of step p + 3 -- three steps of flight.
-//   * a step = 32 MFMAs (fragment rows 0 .. 7 x 4 weight fragments); activation fragments through the ring of four registers sets, weight
-//     fragments double-buffered, as above; the barrier sits between rows 4 and 5 (every read of the step's stage issued and returned);
-//     rows 5 .. 7 carry the next step's first seven fragment reads, the wave's four pieces of step p + 4 and, in a tile's first six
-//     steps, two stores of the previous tile;
-//   * memory operations retire in issue order, so the wait names what may stay in flight BEHIND the pieces it needs (those of step
-//     p + 1, requested in step p - 3): two steps' pieces (8) plus the stores issued since -- 12 / 14 / 12 / 14 / 14 / 14 / 14 / 12 / 10 in
-//     a tile's steps 0 .. 8, 8 after that, 12 in its last step (whose four stores of fragment rows 0, 1 leave in front of its barrier).
-// ------------------------------------------------------------------------------------------------------------------------------------
-constexpr int S4_BK = 32, S4_TA = BM * S4_BK * 2, S4_STG = 2 * S4_TA, S4_N = 4;       // 16 KB + 16 KB per stage, four stages
-__device__ __forceinline__ constexpr int s4_bjoff(int j) { return ((j >> 1) * 32 + (j & 1) * 4) * 64; }
-
-template <bool BF16>
-__global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_stream(GemmLaunch L) {
-    __shared__ __attribute__((aligned(1024))) char lds[S4_N * S4_STG];
-    const AumGemmArgs& g = L.g;
-    const int lane = (int)(threadIdx.x & 63u);
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int wr = w >> 2, wc = w & 3;
-    const int ntn = g.n / BN, grid = (int)gridDim.x, np = g.k / S4_BK;          // steps per tile
-    constexpr int G4 = 0x1230;            // G = {0, 3, 2, 1} as nibbles
-    auto Gf = [](int i) { return (G4 >> (4 * i)) & 3; };
-
-    // staging: piece c = 8 j + w (j < 2, for each operand) is rows 16 c .. 16 c + 15; lane l fills slot (l & 3) of row 16 c + (l >> 2)
-    const int srow = w * 16 + (lane >> 2);
-    const int f_a = Gf((lane >> 4) & 3);                                  // (row >> 2) & 3 = lane >> 4
-    const int f_b = Gf((2 * w + (lane >> 5)) & 3);                        // (row >> 3) & 3 = (2 c + (lane >> 5)) & 3, 2 c = 16 j + 2 w
-    const int voff_a = srow * g.lda * 2 + (((lane & 3) ^ f_a) << 4);
-    const int voff_b = srow * g.ldb * 2 + (((lane & 3) ^ f_b) << 4);
-    const int rowstep_a = 128 * g.lda * 2, rowstep_b = 128 * g.ldb * 2;
-    // fragment reads: lane = (operand row rho, k-group kg)
-    const int rho = lane & 15, kg = lane >> 4;
-    const int swz = (kg ^ Gf(rho >> 2)) << 4;
-    const int a_rd = (wr * 128 + rho) * 64 + swz;                                                // + i * 1024
-    const int b_rd = S4_TA + (wc * 64 + (rho >> 2) * 8 + (rho & 3)) * 64 + swz;                  // + s4_bjoff(j)
-    const int ldc2 = g.ldc * 2;
-    const int c_voff = (wr * 128 + rho) * ldc2 + (wc * 64 + kg * 8) * 2;
-
-    auto rsrc_a = [&](int m0, int rows) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(g.a) + (int64_t)m0 * g.lda * 2), 0, rows * g.lda * 2, 0x00020000);
-    };
-    auto rsrc_b = [&](int n0) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(g.b) + (int64_t)n0 * g.ldb * 2), 0, BN * g.ldb * 2, 0x00020000);
-    };
-    auto rsrc_c = [&](int m0, int n0, int rows) {
-        return __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(g.c) + ((int64_t)m0 * g.ldc + n0) * 2, 0, (rows - 1) * ldc2 + BN * 2, 0x00020000);
-    };
-    const __amdgpu_buffer_rsrc_t r_null = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a), 0, 0, 0x00020000);
-
-    int id = (int)blockIdx.x;
-    if (id >= L.nitems) return;
-    int m0, n0, rows;
-    ps_item(L, id, ntn, grid, m0, n0, rows);
-    __amdgpu_buffer_rsrc_t ra = rsrc_a(m0, rows), rb = rsrc_b(n0);
-
-    // piece n of a step (n < 2: activation rows, else weight rows) into stage `dst`
-    auto piece = [&](__amdgpu_buffer_rsrc_t ra_s, __amdgpu_buffer_rsrc_t rb_s, int kbyte, char* dst, int n) {
-        if (AUM_PS_ABL & 1) return;
-        if (n < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_s, (lds_ptr_t)(dst + (n * 8 + w) * 1024), 16, voff_a, kbyte + n * rowstep_a, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_s, (lds_ptr_t)(dst + S4_TA + ((n - 2) * 8 + w) * 1024), 16, voff_b, kbyte + (n - 2) * rowstep_b, 0, 0);
-    };
-
-    s8v bfA[4], bfB[4], af[4];
-    u4v pend[6][2];                     // fragment rows 2 .. 7 of the finished tile, rounded
-#pragma unroll
-    for (int i = 0; i < 6; ++i) pend[i][0] = pend[i][1] = u4v{0u, 0u, 0u, 0u};
-    f4v acc[8][4];
-
-    // ---- prologue: steps 0 .. 3 of the first tile are requested, step 0 lands, its first fragments are read
-    {
-        const bool has_next = id + grid < L.nitems;
-        int m1 = m0, n1 = n0, rows1 = rows;
-        if (has_next) ps_item(L, id + grid, ntn, grid, m1, n1, rows1);
-        const __amdgpu_buffer_rsrc_t ra_n = has_next ? rsrc_a(m1, rows1) : r_null, rb_n = has_next ? rsrc_b(n1) : r_null;
-#pragma unroll
-        for (int p = 0; p < S4_N; ++p) {
-            const bool same = p < np;
-            // (four stores that the range check drops, where a tile's last step has its four: the first tile's waits then count the same
-            // operations as every other tile's)
-            if (p == 3 && !(AUM_PS_ABL & 2)) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b128(u4v{0u, 0u, 0u, 0u}, r_null, 0, 0, 0);
-            }
-#pragma unroll
-            for (int n = 0; n < 4; ++n) piece(same ? ra : ra_n, same ? rb : rb_n, (same ? p : p - np) * (S4_BK * 2), lds + p * S4_STG, n);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AUM_PS_ABL & 2) ? 12 : 16) : "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bfA[j] = lds_frag(lds, b_rd + s4_bjoff(j));
-#pragma unroll
-    for (int r = 0; r < 3; ++r) af[r] = lds_frag(lds, a_rd + r * 1024);
-    int sc = 0;                                     // the stage that holds the step about to run
-    __amdgpu_buffer_rsrc_t rc_prev = r_null;        // C rows of the tile whose rounded values wait in `pend`
-
-    while (true) {
-        const int nid = id + grid;
-        const bool has_next = nid < L.nitems;
-        int m1 = m0, n1 = n0, rows1 = rows;
-        if (has_next) ps_item(L, nid, ntn, grid, m1, n1, rows1);
-        const __amdgpu_buffer_rsrc_t ra_n = has_next ? rsrc_a(m1, rows1) : r_null, rb_n = has_next ? rsrc_b(n1) : r_null;
-        const __amdgpu_buffer_rsrc_t rc = (AUM_PS_ABL & 8) ? r_null : rsrc_c(m0, n0, rows);
-
-        // One step.  SET: which weight-fragment set it multiplies on (0: bfA, 1: bfB; the other one receives the next step's).  FIRST: a tile's
-        // first step (zero addend); ST >= 0: the step carries stores 2 ST, 2 ST + 1 of the previous tile; VM: what may stay in flight behind
-        // the pieces the step's barrier needs; LAST: the tile's last step (rows rounded behind its MFMAs, rows 0 and 1 stored at once).
-        auto step = [&](auto set_c, auto first_c, auto st_c, auto vm_c, auto last_c, int p) {
-            constexpr bool FIRST = decltype(first_c)::value != 0, LAST = decltype(last_c)::value != 0;
-            constexpr int SET = decltype(set_c)::value, ST = decltype(st_c)::value, VM = decltype(vm_c)::value;
-            s8v(&bc)[4] = SET ? bfB : bfA;
-            s8v(&bn)[4] = SET ? bfA : bfB;
-            char* cur = lds + sc * S4_STG;
-            const int sn = (sc + 1) & (S4_N - 1);
-            char* nxt = lds + sn * S4_STG;
-            // the pieces this step requests: step p + 4 (of this tile, or of the next one)
-            const bool same = p + S4_N < np;
-            const __amdgpu_buffer_rsrc_t ra_s = same ? ra : ra_n, rb_s = same ? rb : rb_n;
-            const int kb = (same ? p + S4_N : p + S4_N - np) * (S4_BK * 2);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i == 5) {
-                    // every read of this step's stage has been issued (the last one under row 4) and has returned; this wave's pieces of step
-                    // p + 1 have landed -- and, past the barrier, everybody's
-                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((AUM_PS_ABL & 2) ? 8 : VM) : "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (FIRST) ps_mfma0<BF16>(acc[i][j], bc[j], af[i & 3]);
-                    else ps_mfma<BF16>(acc[i][j], bc[j], af[i & 3]);
-                    if (j == 1 && i + 3 < 8) af[(i + 3) & 3] = lds_frag(cur, a_rd + (i + 3) * 1024);      // row i + 3 into the slot row i - 1 has left
-                    if (i >= 5) {
-                        // under rows 5 .. 7: the next step's first fragments (its stage has landed), this wave's four pieces of step p + 4 (into the
-                        // stage this step has finished with) and the stores.  Ring slots: rows 5, 6, 7 multiply on slots 1, 2, 3 -- slot 0
-                        // is free, slot 1 once row 5's MFMAs have been issued, slot 2 after row 6's
-                        const int q = (i - 5) * 4 + j;              // 0 .. 11
-                        if (q == 0 || q == 3 || q == 6 || q == 9) piece(ra_s, rb_s, kb, cur, q / 3);
-                        if (q == 1) bn[0] = lds_frag(nxt, b_rd + s4_bjoff(0));
-                        if (q == 2) af[0] = lds_frag(nxt, a_rd);
-                        if (q == 4) bn[1] = lds_frag(nxt, b_rd + s4_bjoff(1));
-                        if (q == 5) af[1] = lds_frag(nxt, a_rd + 1024);
-                        if (q == 7) bn[2] = lds_frag(nxt, b_rd + s4_bjoff(2));
-                        if (q == 8) bn[3] = lds_frag(nxt, b_rd + s4_bjoff(3));
-                        if (q == 10) af[2] = lds_frag(nxt, a_rd + 2 * 1024);
-                        if constexpr (ST >= 0 && !(AUM_PS_ABL & 2)) {
-                            if (q == 10 || q == 11)
-                                __builtin_amdgcn_raw_buffer_store_b128(pend[ST][q - 10], rc_prev, c_voff + (ST + 2) * 16 * ldc2 + (q - 10) * 64, 0, 0);
-                        }
-                    }
-                }
-                if constexpr (LAST) {
-                    if (i > 0) {
-                        // fragment row i - 1 is final (its last MFMAs were issued four MFMAs ago): round it.  Its vector-ALU reads must stay
-                        // BEHIND row i's MFMAs (the compiler knows nothing about the latency of the assembly that produced the values and
-                        // would hoist them right behind it): an empty volatile statement that "rewrites" the row pins them here
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i - 1][j]));
-                        const u4v lo = u4v{pack2<BF16>(acc[i - 1][0][0], acc[i - 1][0][1]), pack2<BF16>(acc[i - 1][0][2], acc[i - 1][0][3]),
-                                           pack2<BF16>(acc[i - 1][1][0], acc[i - 1][1][1]), pack2<BF16>(acc[i - 1][1][2], acc[i - 1][1][3])};
-                        const u4v hi = u4v{pack2<BF16>(acc[i - 1][2][0], acc[i - 1][2][1]), pack2<BF16>(acc[i - 1][2][2], acc[i - 1][2][3]),
-                                           pack2<BF16>(acc[i - 1][3][0], acc[i - 1][3][1]), pack2<BF16>(acc[i - 1][3][2], acc[i - 1][3][3])};
-                        if (i - 1 < 2) {            // rows 0, 1 leave at once (under rows 1 .. 3: in front of the barrier's wait, which leaves them in flight)
-                            if (!(AUM_PS_ABL & 2)) {
-                                __builtin_amdgcn_raw_buffer_store_b128(lo, rc, c_voff + (i - 1) * 16 * ldc2, 0, 0);
-                                __builtin_amdgcn_raw_buffer_store_b128(hi, rc, c_voff + (i - 1) * 16 * ldc2 + 64, 0, 0);
-                            }
-                        } else {
-                            pend[i - 3][0] = lo;
-                            pend[i - 3][1] = hi;
-                        }
-                    }
-                }
-            }
-            if constexpr (LAST) {
-                // last MFMA -> vector-ALU reads of its accumulators: 18 wait states, and the reads pinned behind them
-                asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]));
-                pend[5][0] = u4v{pack2<BF16>(acc[7][0][0], acc[7][0][1]), pack2<BF16>(acc[7][0][2], acc[7][0][3]),
-                                 pack2<BF16>(acc[7][1][0], acc[7][1][1]), pack2<BF16>(acc[7][1][2], acc[7][1][3])};
-                pend[5][1] = u4v{pack2<BF16>(acc[7][2][0], acc[7][2][1]), pack2<BF16>(acc[7][2][2], acc[7][2][3]),
-                                 pack2<BF16>(acc[7][3][0], acc[7][3][1]), pack2<BF16>(acc[7][3][2], acc[7][3][3])};
-            }
-            sc = sn;
-        };
-        // np is even (k % 64 == 0): the steps alternate between the two weight-fragment sets, a tile starts on set 0
-        step(PsC<0>{}, PsC<1>{}, PsC<0>{}, PsC<12>{}, PsC<0>{}, 0);
-        step(PsC<1>{}, PsC<0>{}, PsC<1>{}, PsC<14>{}, PsC<0>{}, 1);
-        step(PsC<0>{}, PsC<0>{}, PsC<2>{}, PsC<12>{}, PsC<0>{}, 2);
-        step(PsC<1>{}, PsC<0>{}, PsC<3>{}, PsC<14>{}, PsC<0>{}, 3);
-        step(PsC<0>{}, PsC<0>{}, PsC<4>{}, PsC<14>{}, PsC<0>{}, 4);
-        step(PsC<1>{}, PsC<0>{}, PsC<5>{}, PsC<14>{}, PsC<0>{}, 5);
-        step(PsC<0>{}, PsC<0>{}, PsC<-1>{}, PsC<14>{}, PsC<0>{}, 6);
-        step(PsC<1>{}, PsC<0>{}, PsC<-1>{}, PsC<12>{}, PsC<0>{}, 7);
-        step(PsC<0>{}, PsC<0>{}, PsC<-1>{}, PsC<10>{}, PsC<0>{}, 8);
-        step(PsC<1>{}, PsC<0>{}, PsC<-1>{}, PsC<8>{}, PsC<0>{}, 9);
-        for (int p = 10; p + 2 < np; p += 2) {
-            step(PsC<0>{}, PsC<0>{}, PsC<-1>{}, PsC<8>{}, PsC<0>{}, p);
-            step(PsC<1>{}, PsC<0>{}, PsC<-1>{}, PsC<8>{}, PsC<0>{}, p + 1);
-        }
-        step(PsC<0>{}, PsC<0>{}, PsC<-1>{}, PsC<8>{}, PsC<0>{}, np - 2);
-        step(PsC<1>{}, PsC<0>{}, PsC<-1>{}, PsC<12>{}, PsC<1>{}, np - 1);
         rc_prev = rc;
         if (!has_next) break;
         id = nid;

@@ -475,7 +475,7 @@ _HIP_GEMM = _GEMM_MODE != "lib"
 # out_proj data gradient only 62.62 / 62.54 / 62.54, both 62.67 / 62.73 / 62.88, in_proj forward only 63.65 / 63.63 / 63.40, library only
 # 63.14 / 63.12 / 62.99: the kernel is 5-8 % behind the library standalone on that shape (155-160 vs 146-148 us) and does not win it back in the
 # step.  The library keeps it; the out_proj data gradient (84 vs 91 us standalone, -0.5 ms in the step) stays on the kernel.
-_HIP_GEMM_FASTER = {(1536, 768)}
+_HIP_GEMM_FASTER = {(1536, 768), (3072, 768)}
 if _dbg_env("AUM_GEMM_SHAPES", ""):         # A/B runs: another set, "NxK,NxK"
     _HIP_GEMM_FASTER = {tuple(int(v) for v in sh.split("x")) for sh in _dbg_env("AUM_GEMM_SHAPES", "").replace("+", ",").split(",")}
 

@@ -75,7 +75,6 @@ enum {
 #define AUM_GEMM_NO_PREFETCH 16u    /* debug / A-B (persistent): a tile's first K-step is fetched at its head, not under the previous tile's last step */
 #define AUM_GEMM_W4 64u             /* round 5: four waves of 128 x 96 (one per SIMD, accumulators in AGPRs), 256 x 192 tiles, persistent; needs n % 192 == 0, k >= 128 */
 #define AUM_GEMM_PACED 256u         /* round 6: the 8-wave 256 x 256 x 64 kernel as one stream of K-steps with a hand-placed schedule; a tile's stores leave under the next tile's first eight steps; k >= 576 */
-#define AUM_GEMM_STREAM 512u        /* round 6: the paced-store kernel on a four-stage ring of 32-deep K-steps (pieces requested four steps ahead); k >= 512 */
 #define AUM_GEMM_RING 128u          /* round 5: the W4 division as one stream of 32-deep K-steps through a five-stage LDS ring (pieces requested five steps ahead); n % 192 == 0, k >= 256 */
 #define AUM_NORM_PRENORM 1u  /* also return residual_out                                                        */
 #define AUM_NORM_GENERIC 2u  /* force the any-cols kernel (default: register-cached vector kernel, cols <= 2048)  */
