@@ -178,18 +178,29 @@ def build_model(args):
 
 
 def compress_gradients(ddp, kind):
-    """The gradient exchange of a DistributedDataParallel model (TT:39, TT:168).  kind "bf16" / "fp16": each fp32 bucket is cast,
+    """The gradient exchange of a DistributedDataParallel model (TT:39, TT:168).  Returns an ssi.GradHomes: call its after_backward() after
+    every backward pass and the kernels write the parameter gradients straight into the reducer's buckets (no per-parameter copies).
+    kind "bf16" / "fp16": each fp32 bucket is cast,
     all-reduced (RCCL ring over xGMI: per-link bound, so half the bytes is close to half the exchange time) and cast back into the
     bucket view; master weights and Adam stay fp32.  "no": the reducer's own fp32 all-reduce + mean.  A model with Bi-Bi (v2) blocks gets
     ssi.ddp_join_streams_hook around whichever exchange it is: its two backward streams are joined before the collective is ordered behind
     one of them (and only then do the blocks use their second stream under a process group)."""
     from mamba_ssm.ops import selective_scan_interface as ssi
     from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-    inner = {"no": None, "bf16": default_hooks.bf16_compress_hook, "fp16": default_hooks.fp16_compress_hook}[kind]
+    inner = {"no": default_hooks.allreduce_hook, "bf16": default_hooks.bf16_compress_hook, "fp16": default_hooks.fp16_compress_hook}[kind]
     if any(getattr(m, "bimamba_type", None) == "v2" for m in ddp.modules()):
         ddp.register_comm_hook(None, ssi.ddp_join_streams_hook(inner))      # Bi-Bi blocks: two backward streams to join
-    elif inner is not None:
-        ddp.register_comm_hook(None, inner)                                 # one stream: the reducer's own ordering is right as it is
+    else:
+        # "no" is registered too (the reducer's own exchange, as a hook): without a hook the reducer divides every gradient that already
+        # lives in its bucket (ssi.adopt_grad_homes) by the world size one launch per parameter; the hook divides the bucket once
+        if kind == "no":
+            # (the reducer's C++ statement of the same hook: divide the bucket once, all-reduce -- no Python on the autograd thread; every
+            # Python hook call holds back the launches behind it by ~30 us, 14 buckets per step)
+            import torch.distributed as dist_
+            ddp._register_builtin_comm_hook(dist_.BuiltinCommHookType.ALLREDUCE)
+        else:
+            ddp.register_comm_hook(None, inner)
+    return ssi.GradHomes(ddp.module)
 
 
 class Frontend:
@@ -343,11 +354,13 @@ def train(model, train_loader, val_loader, args, D):
         optimizer = torch.optim.SGD(trainables, args.lr, momentum=0.9, weight_decay=args.weight_decay)
     if args.optim_path:
         optimizer.load_state_dict(torch.load(args.optim_path, map_location="cpu"))
-    net = model
+    net, homes = model, None
     if D.ddp:
         net = nn.parallel.DistributedDataParallel(model, device_ids=[D.dev_index] if D.cuda else None,
-                                                  gradient_as_bucket_view=True, static_graph=bool(args.if_nan2num), bucket_cap_mb=100)
-        compress_gradients(net, args.grad_compress)
+                                                  gradient_as_bucket_view=True, static_graph=bool(args.if_nan2num))
+        # (torch's default buckets -- 25 MB behind a first one of 1 MB: with a custom cap the odd-sized head.bias sits at the front of a big
+        # bucket and leaves every view behind it off a 16-byte boundary, which the in-bucket gradient writes of ssi.grad_home need)
+        homes = compress_gradients(net, args.grad_compress)
     scaler = torch.amp.GradScaler("cuda", enabled=(args.mixed_precision == "fp16" and D.cuda))
     scheduler = torch.optim.lr_scheduler.MultiStepLR(
         optimizer, list(range(args.lrscheduler_start, 1000, args.lrscheduler_step)), gamma=args.lrscheduler_decay)
@@ -404,6 +417,8 @@ def train(model, train_loader, val_loader, args, D):
                     sys.exit(1)
             optimizer.zero_grad(set_to_none=True)
             scaler.scale(loss).backward()
+            if homes is not None:
+                homes.after_backward()
             scaler.step(optimizer)
             scaler.update()
             # running loss stays on the device: no .item() and no collective per step (the reference's per-step gather + print,

@@ -10,6 +10,7 @@ The functions mirror the reference's extension modules:
   rmsnorm_fwd / rmsnorm_bwd    <- _layer_norm_fwd / _layer_norm_bwd (LN:123-177, 293-377)
 """
 import ctypes as C
+import math
 import os
 
 import torch
@@ -626,7 +627,7 @@ def scan_tm_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softpl
 
 
 def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_softplus=False, reverse=False, A_b=None, dz_out=None,
-                lib=None, segments=1, want_dA_xA=False):
+                lib=None, segments=1, want_dA_xA=False, param_out=None):
     """Backward of scan_tm_fwd (same tensor conventions; ckpt: the tensor scan_tm_fwd filled).  Returns dict(du, ddelta, dz (batch, len,
     dim) in u's dtype, dBC (batch, len, 2 * dstate) fp32 = dB | dC, dA, dA_b (dim, dstate), dD, ddelta_bias (dim) fp32)."""
     lib = lib or get()
@@ -660,13 +661,16 @@ def scan_tm_bwd(u, delta, A, B, C, D, z, delta_bias, dout, out_pre, ckpt, delta_
         dz = dz_out if dz_out is not None else torch.empty((batch, length, dim), dtype=u.dtype, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
     dBC = torch.empty((batch, length, 2 * dstate), **f32)
+    # param_out: {"dD" | "ddelta_bias" | "dA_xA" | "dA_b_xA": destination} -- where a parameter's gradient is wanted (its bucket view under
+    # DistributedDataParallel); anything missing or unfit is a new tensor
+    po = param_out or {}
     dA = torch.empty((dim, dstate), **f32)
     dA_b = torch.empty((dim, dstate), **f32) if bidir else None
-    dD = torch.empty((dim,), **f32) if D is not None else None
-    dbias = torch.empty((dim,), **f32) if delta_bias is not None else None
+    dD = _sum_out(po.get("dD"), (dim,), dev) if D is not None else None
+    dbias = _sum_out(po.get("ddelta_bias"), (dim,), dev) if delta_bias is not None else None
     # want_dA_xA: dA .* A (and dA_b .* A_b) from the same partial-sum launch -- the gradient of A_log where A = -exp(A_log)
-    dA_xA = torch.empty((dim, dstate), **f32) if want_dA_xA else None
-    dA_b_xA = torch.empty((dim, dstate), **f32) if want_dA_xA and bidir else None
+    dA_xA = _sum_out(po.get("dA_xA"), (dim, dstate), dev) if want_dA_xA else None
+    dA_b_xA = _sum_out(po.get("dA_b_xA"), (dim, dstate), dev) if want_dA_xA and bidir else None
     if segments > 1:
         ws_bytes = int(lib.c.aum_scan_tm_seg_workspace_bytes(batch, dim, length, dstate, int(bidir), int(segments)))
         if ws_bytes <= 0:
@@ -747,7 +751,7 @@ def gemm_wgrad_supported(y, x, splits=None):
     return chunk * y.stride(0) * 2 < (1 << 31) and chunk * x.stride(0) * 2 < (1 << 31)
 
 
-def gemm_wgrad(y, x, splits=None, lib=None, partials=False):
+def gemm_wgrad(y, x, splits=None, lib=None, partials=False, out=None):
     """dW (n, k) fp32 = y (t, n)^T @ x (t, k): the weight gradient of a projection from token-major operands (aum_gemm_wgrad: hand-written
     MFMA kernel with transposing LDS reads, fp32 partial tiles over `splits` token ranges summed in a fixed order by aum_sum_rows)."""
     lib = lib or get()
@@ -765,7 +769,9 @@ def gemm_wgrad(y, x, splits=None, lib=None, partials=False):
     _launch(lib.c.aum_gemm_wgrad, a, y, lib, "gemm_wgrad", (t, n, k, y.element_size()))
     if partials:
         return part
-    return part[0] if splits == 1 else sum_rows(part, lib=lib)
+    if splits == 1:
+        return part[0] if out is None else sum_rows(part, lib=lib, out=out)
+    return sum_rows(part, lib=lib, out=out)
 
 
 def gemm_tn_supported(a, b):
@@ -1108,7 +1114,7 @@ def rmsnorm_fwd(x, weight, residual=None, eps=1e-5, residual_dtype=None, generic
     return y, rstd, (res_out if res_out is not None else x)
 
 
-def rmsnorm_bwd(dy, x_saved, weight, rstd, dresidual=None, has_residual=False, x_dtype=None, generic=False, lib=None):
+def rmsnorm_bwd(dy, x_saved, weight, rstd, dresidual=None, has_residual=False, x_dtype=None, generic=False, lib=None, dw_out=None):
     """_layer_norm_bwd(is_rms_norm=True) (LN:293-377).  x_saved = residual_out of the forward.  Returns
     (dx [x_dtype], dweight fp32, dresidual_in | None)."""
     lib = lib or get()
@@ -1135,7 +1141,7 @@ def rmsnorm_bwd(dy, x_saved, weight, rstd, dresidual=None, has_residual=False, x
     a.res_dtype = _DT[x_saved.dtype]
     a.flags = 2 if generic else 0
     _launch(lib.c.aum_rmsnorm_bwd, a, dy, lib, "rmsnorm_bwd", (rows, cols, dy.element_size()))
-    dw = sum_rows(dwp, lib)
+    dw = sum_rows(dwp, lib, out=dw_out)
     if has_residual and dres_in is None:
         dres_in = dx
     return dx, dw, dres_in
@@ -1325,14 +1331,26 @@ def selftest_wave_sum32(values, lib=None):
     return out
 
 
-def sum_rows(t, lib=None):
+def _sum_out(out, shape, device):
+    """the destination of a sum: `out` (a contiguous fp32 tensor of that many elements on that device -- e.g. the bucket view a parameter's
+    gradient lives in under DistributedDataParallel) or a new tensor"""
+    if out is not None and out.dtype == torch.float32 and out.is_contiguous() and out.device == device and out.numel() == math.prod(shape):
+        return out.view(shape)          # (4-byte aligned is enough: a view in a bucket behind an odd-sized parameter)
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def sum_rows(t, lib=None, out=None):
     """t: (outer, ...) contiguous fp32 / bf16 / fp16 -> fp32 sum over dim 0, in a fixed order (aum_sum_rows): the partial results of
     rmsnorm_bwd / proj_bwd_weight and split-K GEMM partial products.  Tall and narrow inputs (the 4096 x 768 norm partials: too few
-    columns for one pass to fill the chip) are summed in two stages, 32 slices first.  Shapes the kernel does not take go through torch."""
+    columns for one pass to fill the chip) are summed in two stages, 32 slices first.  Shapes the kernel does not take go through torch.
+    out: where to put the sum (see _sum_out); the result is returned either way."""
     lib = lib or get()
-    inner = t[0].numel()
-    if debug.torch_sums or t.dtype not in _DT or not t.is_contiguous() or inner % 8 or t.data_ptr() % 16:
-        return t.sum(0, dtype=torch.float32)
+    inner = t[0].numel() if t.shape[0] > 0 else 0
+    if debug.torch_sums or t.dtype not in _DT or not t.is_contiguous() or inner % 8 or inner == 0 or t.data_ptr() % 16:
+        r = t.sum(0, dtype=torch.float32)
+        if out is not None and out.shape == r.shape and out.dtype == r.dtype:
+            return out.copy_(r)
+        return r
     lib.check_tensor(t)
     outer, shape = t.shape[0], t.shape[1:]
     stream = lib.stream(t)
@@ -1340,25 +1358,39 @@ def sum_rows(t, lib=None):
         mid = torch.empty((32, inner), dtype=torch.float32, device=t.device)
         _chk(lib.c.aum_sum_rows(_ptr(t), _ptr(mid), 32, outer // 32, inner, _DT[t.dtype], stream), "aum_sum_rows")
         t, outer = mid, 32
-    out = torch.empty(shape, dtype=torch.float32, device=t.device)
+    out = _sum_out(out, shape, t.device)
     _chk(lib.c.aum_sum_rows(_ptr(t), _ptr(out), 1, outer, inner, _DT[t.dtype], stream), "aum_sum_rows")
     return out
 
 
-def sum_rows_multi(parts, tr_cols=None, lib=None):
+def _two_stage(t):
+    """sum_rows' rule for a tall and narrow partial set (two stages, 32 slices first)"""
+    return t.shape[0] >= 1024 and t[0].numel() < 8192 and t.shape[0] % 32 == 0
+
+
+def sum_rows_multi(parts, tr_cols=None, lib=None, outs=None):
     """parts: up to SUM_MAX_JOBS (outer, ...) contiguous fp32 tensors of partial results on one device -> their fp32 sums over dim 0 in ONE launch
     (aum_sum_rows_multi; bitwise the sums sum_rows gives one by one).  tr_cols[q] > 0: part q is (outer, rows, tr_cols) and its sum is
     returned transposed, (tr_cols, rows) contiguous.  Shapes the entry does not take go through sum_rows / torch one by one."""
     lib = lib or get()
     tr_cols = list(tr_cols or [0] * len(parts))
+    outs = list(outs or [None] * len(parts))
+    # (a set that sum_rows would add in two stages keeps that order: it goes through sum_rows, and so does every set of its call)
     ok = 0 < len(parts) <= SUM_MAX_JOBS and not debug.torch_sums and not debug.sums_one_by_one and all(
-        t.dtype == torch.float32 and t.is_contiguous() and t[0].numel() % 8 == 0 and t.data_ptr() % 16 == 0 and t.shape[0] > 0 and t[0].numel() > 0
-        and (not tc or (t.dim() == 3 and t.shape[2] == tc)) for t, tc in zip(parts, tr_cols))
+        t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] > 0 and t[0].numel() > 0 and t[0].numel() % 8 == 0 and t.data_ptr() % 16 == 0
+        and not _two_stage(t) and (not tc or (t.dim() == 3 and t.shape[2] == tc)) for t, tc in zip(parts, tr_cols))
     if not ok:
-        return [(sum_rows(t, lib=lib).t().contiguous() if tc else sum_rows(t, lib=lib)) for t, tc in zip(parts, tr_cols)]
+        res = []
+        for t, tc, o in zip(parts, tr_cols, outs):
+            if tc:
+                r = sum_rows(t, lib=lib).t()
+                res.append(o.copy_(r) if o is not None and o.shape == r.shape else r.contiguous())
+            else:
+                res.append(sum_rows(t, lib=lib, out=o))
+        return res
     for t in parts:
         lib.check_tensor(t)
-    outs = [torch.empty((t.shape[2], t.shape[1]) if tc else t.shape[1:], dtype=torch.float32, device=t.device) for t, tc in zip(parts, tr_cols)]
+    outs = [_sum_out(o, (t.shape[2], t.shape[1]) if tc else tuple(t.shape[1:]), t.device) for t, tc, o in zip(parts, tr_cols, outs)]
     jobs = (SumJob * len(parts))()
     for j, t, o, tc in zip(jobs, parts, outs, tr_cols):
         j.src, j.dst, j.outer, j.inner, j.tr_cols = _ptr(t), _ptr(o), t.shape[0], t[0].numel(), tc

@@ -501,9 +501,12 @@ template <class T, int RG> __device__ __forceinline__ void sum_rows_body(const T
 #pragma unroll
             for (int j = 0; j < 8; ++j) dst[((col + j) % tr_cols) * nrows + (col + j) / tr_cols] = acc[j];
         } else {
-            float4* d4 = reinterpret_cast<float4*>(dst + col);
-            d4[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            d4[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            // (the destination may be a view into a DistributedDataParallel bucket behind an odd-sized parameter: 4-byte aligned only.  16-byte
+            // stores on a 4-byte aligned type -- global_store_dwordx4 in unaligned-access mode, as the row kernels' loads)
+            struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
+            F4* d4 = reinterpret_cast<F4*>(dst + col);
+            d4[0] = F4{acc[0], acc[1], acc[2], acc[3]};
+            d4[1] = F4{acc[4], acc[5], acc[6], acc[7]};
         }
     }
 }

@@ -51,6 +51,75 @@ def _autocast_dtype():
 
 
 # =================================================================================================
+# gradient homes
+# =================================================================================================
+# Under DistributedDataParallel(gradient_as_bucket_view=True) a parameter's gradient lives in a view of a flat bucket.  With
+# zero_grad(set_to_none=True) (torch's default) every backward produces a NEW gradient tensor and the reducer's per-parameter hook copies
+# it into the bucket: 271 copy launches and 2 x 368 MB of traffic per AuM-Base step, 1.3 ms of GPU time with no wire at all
+# (profiles/r06_ddp_overhead.txt).  A parameter that carries `_aum_grad_home` (adopt_grad_homes: the bucket view the reducer gave it in an
+# earlier step) has its gradient WRITTEN there by the kernel that finishes it -- the weight-gradient sums, the scan's parameter sums, the norm's
+# weight sum -- and what the autograd function returns is a fresh alias of that view: the accumulator keeps it without a copy, the
+# reducer's hook finds a gradient that already aliases its bucket and copies nothing.  A stale home (buckets rebuilt, another wrapper) only
+# costs the copy it was meant to save: the reducer then copies as before.
+def grad_home(p):
+    """where parameter p's gradient is wanted, or None.  Only while p.grad is None: a backward that ACCUMULATES (gradient accumulation,
+    no_sync) must not overwrite what it is added to."""
+    h = getattr(p, "_aum_grad_home", None) if p is not None else None
+    if h is None or p.grad is not None or h.dtype != torch.float32 or p.dtype != torch.float32 or h.device != p.device or h.shape != p.shape \
+            or not h.is_contiguous():
+        return None
+    return h
+
+
+def _homed(t, home):
+    """what the backward returns for a gradient `t` that was written into `home`: a fresh tensor object on the same storage (the one the
+    gradient accumulator may keep); anything else unchanged"""
+    if home is not None and t is not None and t.data_ptr() == home.data_ptr() and t.numel() == home.numel():
+        HOME_HITS[0] += 1
+        return home.view(home.shape)
+    return t
+
+
+HOME_HITS = [0]         # gradients handed over inside their home since import (tests, bench.py's dist record)
+
+
+def adopt_grad_homes(module):
+    """after a backward under DistributedDataParallel(gradient_as_bucket_view=True): remember each parameter's bucket view as the place its
+    next gradient is written to.  Returns the number of parameters that have one.  (TT:39, TT:168: the reference wraps the model in the
+    same reducer; its CUDA kernels cannot be told where to write.)"""
+    n = 0
+    for p in module.parameters():
+        g = p.grad
+        if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and g._base is not None:
+            p._aum_grad_home = g
+            n += 1
+    return n
+
+
+class GradHomes:
+    """adopt_grad_homes on a schedule: after each of the first backward passes (the reducer rebuilds its buckets once, after the first
+    iteration) and every 64th one after that (a stale home costs a copy, never a wrong gradient)"""
+
+    def __init__(self, module):
+        self.module, self.calls = module, 0
+
+    def after_backward(self):
+        self.calls += 1
+        if self.calls <= 3 or self.calls % 64 == 0:
+            return adopt_grad_homes(self.module)
+        return None
+
+
+def drop_grad_homes(module):
+    for p in module.parameters():
+        if hasattr(p, "_aum_grad_home"):
+            del p._aum_grad_home
+
+
+_A_OWNER = {}           # storage address of a cached A (neg_exp) -> the A_log parameter it came from, for the open forward
+
+
+# =================================================================================================
 # per-forward weight cache
 # =================================================================================================
 # What autocast does per call -- one fp32 -> 16-bit cast kernel per projection weight and layer, plus this package's transposed
@@ -105,6 +174,8 @@ def step_cache(mixers, dtype):
         for k in mine:                      # only this context's entries: another model's forward may be open around this one
             _STEP_CACHE.pop(k, None)
         _A_CACHE_PTRS.difference_update(a_ptrs)
+        for a_ in a_ptrs:
+            _A_OWNER.pop(a_, None)
 
 
 def _cast(w, dtype):
@@ -148,6 +219,7 @@ class _NegExpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, A_log, A):
         ctx.save_for_backward(A)
+        ctx.A_log = A_log
         return A.view_as(A)
 
     @staticmethod
@@ -155,14 +227,17 @@ class _NegExpFn(torch.autograd.Function):
         ent = _DA_XA.pop(g.data_ptr(), None)
         if ent is not None and ent[0].data_ptr() == g.data_ptr() and ent[0].shape == g.shape and ent[0].dtype == g.dtype \
                 and ent[2].data_ptr() == ctx.saved_tensors[0].data_ptr():
-            return ent[1], None
+            return _homed(ent[1], grad_home(ctx.A_log)), None
         return g * ctx.saved_tensors[0], None
 
 
 def neg_exp(A_log):
     """-exp(A_log.float())  (MS:190, 204, 220)"""
     c = _STEP_CACHE.get(id(A_log))
-    return _NegExpFn.apply(A_log, c[1]) if c is not None and c[0] == "A" else -torch.exp(A_log.float())
+    if c is not None and c[0] == "A":
+        _A_OWNER[c[1].data_ptr()] = A_log
+        return _NegExpFn.apply(A_log, c[1])
+    return -torch.exp(A_log.float())
 
 
 # =================================================================================================
@@ -336,13 +411,14 @@ def split_k_wgrad(a_mk, b_kn, splits, out_dtype=None):
 _HIP_WGRAD = _dbg_env("AUM_WGRAD", "hip") != "lib"
 
 
-def _wgrad_tm(dy2d, x2d, splits_hint, out_dtype, pending=None):
+def _wgrad_tm(dy2d, x2d, splits_hint, out_dtype, pending=None, home=None):
     """dW [N, K] = dy2d [T, N]^T @ x2d [T, K] for token-major operands.  pending: a _PendingSums of the caller -- the kernel's partial tiles
-    join it and the gradient is what its run() returns at the index this function returns (fp32 parameters only)"""
+    join it and the gradient is what its run() returns at the index this function returns (fp32 parameters only).  home: where the sum is
+    wanted (grad_home of the parameter)"""
     if _HIP_WGRAD and _HIP_GEMM and dy2d.is_cuda and aum_hip.gemm_wgrad_supported(dy2d, x2d):
         if pending is not None and out_dtype == torch.float32:
-            return pending.add(aum_hip.gemm_wgrad(dy2d, x2d, partials=True))
-        return aum_hip.gemm_wgrad(dy2d, x2d).to(out_dtype)
+            return pending.add(aum_hip.gemm_wgrad(dy2d, x2d, partials=True), out=home)
+        return aum_hip.gemm_wgrad(dy2d, x2d, out=home if out_dtype == torch.float32 else None).to(out_dtype)
     return split_k_wgrad(dy2d.t(), x2d, _pick_splits(x2d.shape[0], splits_hint), out_dtype)
 
 
@@ -351,15 +427,16 @@ class _PendingSums:
     the backward function instead of one 5-12 us launch each (aum_hip.sum_rows_multi; every set is added in the order a launch of its own uses)"""
 
     def __init__(self):
-        self.parts, self.tr = [], []
+        self.parts, self.tr, self.outs = [], [], []
 
-    def add(self, part, tr_cols=0):
+    def add(self, part, tr_cols=0, out=None):
         self.parts.append(part)
         self.tr.append(tr_cols)
+        self.outs.append(out)
         return _PendingIndex(len(self.parts) - 1)
 
     def run(self):
-        return aum_hip.sum_rows_multi(self.parts, self.tr) if self.parts else []
+        return aum_hip.sum_rows_multi(self.parts, self.tr, outs=self.outs) if self.parts else []
 
 
 class _PendingIndex(int):
@@ -520,6 +597,7 @@ class InProjTmFn(torch.autograd.Function):
         w_t = _weight_t_for_dgrad(weight, w, h.is_cuda) if ctx.needs_input_grad[1] else None
         ctx.save_for_backward(w, h, w_t)
         ctx.wdtype, ctx.hdtype = weight.dtype, hidden2d.dtype
+        ctx.wparam = weight
         return _gemm_rows(h, w, 1)
 
     @staticmethod
@@ -527,7 +605,8 @@ class InProjTmFn(torch.autograd.Function):
         w, h, w_t = ctx.saved_tensors
         dxz2d = dxz2d.to(w.dtype)
         dh = _gemm_dgrad(dxz2d, w, w_t, 8) if ctx.needs_input_grad[1] else None
-        dw = _wgrad_tm(dxz2d, h, _WGRAD_SPLITS[0], ctx.wdtype) if ctx.needs_input_grad[0] else None
+        home = grad_home(ctx.wparam)
+        dw = _homed(_wgrad_tm(dxz2d, h, _WGRAD_SPLITS[0], ctx.wdtype, home=home), home) if ctx.needs_input_grad[0] else None
         return dw, (None if dh is None else dh.to(ctx.hdtype))
 
 
@@ -543,6 +622,7 @@ class OutProjTmFn(torch.autograd.Function):
         w_t = _weight_t_for_dgrad(weight, w, y.is_cuda) if ctx.needs_input_grad[1] else None
         ctx.save_for_backward(w, y, w_t)
         ctx.wdtype, ctx.ydtype = weight.dtype, y2d.dtype
+        ctx.wparam = weight
         return _gemm_rows(y, w, 2)
 
     @staticmethod
@@ -550,7 +630,8 @@ class OutProjTmFn(torch.autograd.Function):
         w, y, w_t = ctx.saved_tensors
         dout2d = dout2d.to(w.dtype)
         dy = _gemm_dgrad(dout2d, w, w_t, 4) if ctx.needs_input_grad[1] else None
-        dw = _wgrad_tm(dout2d, y, _WGRAD_SPLITS[1], ctx.wdtype) if ctx.needs_input_grad[0] else None
+        home = grad_home(ctx.wparam)
+        dw = _homed(_wgrad_tm(dout2d, y, _WGRAD_SPLITS[1], ctx.wdtype, home=home), home) if ctx.needs_input_grad[0] else None
         return dw, (None if dy is None else dy.to(ctx.ydtype))
 
 
@@ -654,6 +735,9 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
     ctx.A_cached = (need_bwd and A.dtype == torch.float32 and A.is_contiguous() and A.data_ptr() in _A_CACHE_PTRS
                     and (A_b is None or (A_b.is_contiguous() and A_b.data_ptr() in _A_CACHE_PTRS)))
     ctx.tm = True
+    # the parameters behind this call's gradients (grad_home looks at them in the backward)
+    ctx.params = dict(conv_w=conv1d_weight, conv_b=conv1d_bias, x_proj=x_proj_param, dt_proj=delta_proj_param, out_proj=out_proj_param, D=D,
+                      dt_bias=delta_bias, A_log=_A_OWNER.get(A.data_ptr()), A_b_log=None if A_b is None else _A_OWNER.get(A_b.data_ptr()))
     ctx.delta_softplus, ctx.reverse = delta_softplus, reverse
     ctx.has_out_proj = out_proj_weight is not None
     ctx.out_proj_bias_is_None = out_proj_bias is None
@@ -680,10 +764,12 @@ def _inner_backward_tm(ctx, dout):
     dx, dz = dxz_t[:, :, :E], dxz_t[:, :, E:]
     dout_proj_weight = dout_proj_bias = None
     pend = _PendingSums()
+    H = {k: grad_home(v) for k, v in getattr(ctx, "params", {}).items()}          # where each parameter's gradient is wanted (or None)
+    H = {k: H.get(k) for k in ("conv_w", "conv_b", "x_proj", "dt_proj", "out_proj", "D", "dt_bias", "A_log", "A_b_log")}
     if ctx.has_out_proj:
         dout2 = dout.reshape(Bsz * L, -1).to(out_proj_weight.dtype)
         dout_z = _gemm_dgrad(dout2, out_proj_weight, out_proj_wt, 4).view(Bsz, L, E).to(conv_out.dtype)     # SSI:540
-        dout_proj_weight = _wgrad_tm(dout2, out_z.view(Bsz * L, E), _WGRAD_SPLITS[1], ctx.out_proj_wdtype, pend)     # SSI:563
+        dout_proj_weight = _wgrad_tm(dout2, out_z.view(Bsz * L, E), _WGRAD_SPLITS[1], ctx.out_proj_wdtype, pend, home=H["out_proj"])     # SSI:563
         dout_proj_bias = dout2.sum(0) if not ctx.out_proj_bias_is_None else None
     else:
         dout_z = dout.transpose(1, 2)
@@ -692,7 +778,8 @@ def _inner_backward_tm(ctx, dout):
     g = aum_hip.scan_tm_bwd(conv_out, delta.view(Bsz, L, E), A, x3[:, :, R:R + N], x3[:, :, R + N:], D, z, delta_bias, dout_z, out_pre,
                             ckpt, ctx.delta_softplus, ctx.reverse if A_b is None else False, A_b=A_b, dz_out=dz,
                             segments=tm_segments(Bsz, E, L, A_b is not None, True) if ctx.tm_cut else 1,
-                            want_dA_xA=ctx.A_cached)                                           # SSI:541-561
+                            want_dA_xA=ctx.A_cached,
+                            param_out=dict(dD=H["D"], ddelta_bias=H["dt_bias"], dA_xA=H["A_log"], dA_b_xA=H["A_b_log"]))        # SSI:541-561
     if ctx.A_cached:            # A came out of the forward's cache (neg_exp): its d A_log is ready (see _NegExpFn)
         _da_xa_put(g["dA"], g["dA_xA"], A)
         if A_b is not None:
@@ -709,8 +796,8 @@ def _inner_backward_tm(ctx, dout):
         splits = _pick_splits(Bsz * L, _WGRAD_SPLITS[1])
         if aum_hip.gemm_wgrad_supported(ddelta2, x_dbl[:, :R]) and aum_hip.gemm_wgrad_supported(conv2d, dx_dbl):
             # the partial sets join the function's one sum launch, which also stores the x_proj gradient in the parameter's (R + 2N, E) layout
-            ddelta_proj_weight = pend.add(aum_hip.gemm_wgrad(ddelta2, x_dbl[:, :R], partials=True))          # SSI:586  (E, R) fp32
-            dx_proj_weight = pend.add(aum_hip.gemm_wgrad(conv2d, dx_dbl, partials=True), R + 2 * N)          # SSI:589  (R + 2N, E) fp32
+            ddelta_proj_weight = pend.add(aum_hip.gemm_wgrad(ddelta2, x_dbl[:, :R], partials=True), out=H["dt_proj"])          # SSI:586  (E, R) fp32
+            dx_proj_weight = pend.add(aum_hip.gemm_wgrad(conv2d, dx_dbl, partials=True), R + 2 * N, out=H["x_proj"])          # SSI:589  (R + 2N, E) fp32
         else:
             ddelta_proj_weight = split_k_wgrad(ddelta2.t(), x_dbl[:, :R], splits, torch.float32)
             dx_proj_weight = split_k_wgrad(dx_dbl.t(), conv2d, splits, torch.float32)
@@ -723,13 +810,15 @@ def _inner_backward_tm(ctx, dout):
         dx_proj_weight = split_k_wgrad(dx_dbl.t(), conv2d, splits, torch.float32)            # SSI:589
         du2.addmm_(dx_dbl, x_proj_weight.to(dx_dbl.dtype))                                   # SSI:590
     _, dconv_w, dconv_b = aum_hip.conv1d_tm_bwd(x, conv_w, conv1d_bias, g["du"], True, ctx.reverse, dx_out=dx, partials=True)   # SSI:594
-    dconv_w, dconv_b = pend.add(dconv_w), (None if dconv_b is None else pend.add(dconv_b))
+    dconv_w, dconv_b = pend.add(dconv_w, out=H["conv_w"]), (None if dconv_b is None else pend.add(dconv_b, out=H["conv_b"]))
     sums = pend.run()
     dout_proj_weight, ddelta_proj_weight, dx_proj_weight, dconv_w, dconv_b = (
         sums[v] if isinstance(v, _PendingIndex) else v for v in (dout_proj_weight, ddelta_proj_weight, dx_proj_weight, dconv_w, dconv_b))
-    return dict(dxz=dxz_t.transpose(1, 2), dconv_w=dconv_w.reshape(E, 1, -1), dconv_b=dconv_b, dx_proj_w=dx_proj_weight,
-                ddt_proj_w=ddelta_proj_weight, dout_proj_w=dout_proj_weight, dout_proj_b=dout_proj_bias,
-                dA=g["dA"], dA_b=g.get("dA_b"), dD=g["dD"], ddelta_bias=g["ddelta_bias"], dB_proj_bias=None, dC_proj_bias=None)
+    return dict(dxz=dxz_t.transpose(1, 2), dconv_w=_homed(dconv_w.reshape(E, 1, -1), H["conv_w"]), dconv_b=_homed(dconv_b, H["conv_b"]),
+                dx_proj_w=_homed(dx_proj_weight, H["x_proj"]), ddt_proj_w=_homed(ddelta_proj_weight, H["dt_proj"]),
+                dout_proj_w=_homed(dout_proj_weight, H["out_proj"]), dout_proj_b=dout_proj_bias,
+                dA=g["dA"], dA_b=g.get("dA_b"), dD=_homed(g["dD"], H["D"]), ddelta_bias=_homed(g["ddelta_bias"], H["dt_bias"]),
+                dB_proj_bias=None, dC_proj_bias=None)
 
 
 def _dm2d(t):

@@ -63,6 +63,7 @@ class LayerNormFn(torch.autograd.Function):
         y, rstd, res_out = aum_hip.rmsnorm_fwd(x2, weight, r2, eps, residual_dtype=res_dtype)
         ctx.save_for_backward(res_out, weight, rstd)
         ctx.shape, ctx.has_residual, ctx.prenorm, ctx.x_dtype = shape, residual is not None, prenorm, x.dtype
+        ctx.wparam = weight
         y = y.reshape(shape)
         return (y, res_out.reshape(shape)) if prenorm else y
 
@@ -78,9 +79,11 @@ class LayerNormFn(torch.autograd.Function):
             if dres.stride(-1) != 1:
                 dres = dres.contiguous()
             dres = dres.to(x.dtype)
+        from mamba_ssm.ops.selective_scan_interface import _homed, grad_home
+        home = grad_home(ctx.wparam)          # the weight gradient's place in a DistributedDataParallel bucket, if the parameter has one
         dx, dw, dres_in = aum_hip.rmsnorm_bwd(dy2.to(ctx.x_dtype), x, weight, rstd, dres, ctx.has_residual,
-                                              x_dtype=ctx.x_dtype)
-        return (dx.reshape(ctx.shape), dw.to(weight.dtype), None,
+                                              x_dtype=ctx.x_dtype, dw_out=home)
+        return (dx.reshape(ctx.shape), _homed(dw.to(weight.dtype), home), None,
                 dres_in.reshape(ctx.shape) if ctx.has_residual else None, None, None, None, None)
 
 

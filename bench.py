@@ -232,6 +232,7 @@ def main():
 
     import aum_hip
     from aum.model import build_aum
+    import mamba_ssm.ops.selective_scan_interface as ssi_mod
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -265,12 +266,18 @@ def main():
     n_params = sum(p.numel() for p in model.parameters())
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-7, betas=(0.95, 0.999), eps=1e-8,
                            fused=True)                                         # TT:32-34
-    net = model
+    net, homes = model, None
     if dist is not None:
+        # bucket size: torch's default (25 MB, and a first bucket of 1 MB).  A custom cap drops the small first bucket, and the odd-sized
+        # head.bias (527 floats) then leaves every later view of a 64 MB bucket 12 bytes off a 16-byte boundary: 54 gradients the
+        # kernels cannot write in place (ssi.grad_home) and the fused Adam reads unaligned (profiles/r06_ddp_overhead.txt)
+        bucket_mb = int(os.environ["AUM_BENCH_BUCKET_MB"]) if os.environ.get("AUM_BENCH_BUCKET_MB") else None
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], gradient_as_bucket_view=True,
-                                                        bucket_cap_mb=64, broadcast_buffers=False)
+                                                        bucket_cap_mb=bucket_mb, broadcast_buffers=False)
         from aum.train import compress_gradients
-        compress_gradients(net, args.grad_compress)
+        homes = compress_gradients(net, args.grad_compress)
+        if os.environ.get("AUM_BENCH_NO_GRAD_HOMES") == "1":          # A/B: the reducer copies every gradient into its bucket, as torch does by default
+            homes = None
     loss_fn = torch.nn.BCEWithLogitsLoss()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     if args.no_frontend:
@@ -292,6 +299,8 @@ def main():
             logits = net(xin, frontend=fe)
             loss = loss_fn(logits.float(), y)
         loss.backward()
+        if homes is not None:
+            homes.after_backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
         return loss
@@ -351,7 +360,7 @@ def main():
             n_buckets = None
         if n_buckets is None:
             grad_bytes = sum(p.numel() * p.element_size() for p in model.parameters())
-            n_buckets = -(-grad_bytes // (64 << 20))          # bucket_cap_mb = 64 (the first bucket is smaller: DDP's 1 MB head start)
+            n_buckets = -(-grad_bytes // ((bucket_mb or 25) << 20))
     final_loss = float(loss.item())
     ktimes = aum_hip.timer.summary()
 
@@ -432,7 +441,8 @@ def main():
             "ms_per_step_without_optimizer": round(ms_no_opt, 3),
             "dist": {"world_size": world, "backend": (dist.get_backend() if dist is not None else None),
                      "rccl": bool(dist is not None and dist.get_backend() == "nccl"), "rank_ms_per_step": rank_ms,
-                     "ddp_buckets": n_buckets, "bucket_cap_mb": 64 if dist is not None else None,
+                     "ddp_buckets": n_buckets, "bucket_cap_mb": (bucket_mb or 25) if dist is not None else None,
+                     "grads_written_in_bucket": (ssi_mod.HOME_HITS[0] if dist is not None else None),
                      "grad_exchange_dtype": ("fp32" if args.grad_compress == "no" else args.grad_compress) if dist is not None else None},
             "kernel_ms_per_step": {k: round(v, 3) for k, v in sorted(per_step.items())},
             "final_loss": round(final_loss, 5),

@@ -590,7 +590,8 @@ int aum_hbm_copy(const void* src, void* dst, int64_t bytes, void* stream);
  * dst[b][i] = sum over o of src[b][o][i] in fp32 (ABI 6; batch = 1 for a plain sum, > 1 for the first stage of a two-stage sum): the fixed-order sum of the per-workgroup partial results that
  * aum_rmsnorm_bwd (dweight_partial) and aum_proj_bwd_weight (out) leave to the caller, and of split-K GEMM partial products
  * (SSI:563, 586, 589; the reference leaves the same kind of sum to torch: LN:333-372).  src: (batch, outer, inner) contiguous in
- * src_dtype (AUM_F32 / AUM_BF16 / AUM_F16), dst: (batch, inner) fp32.  inner % 8 == 0, 16-byte aligned pointers.
+ * src_dtype (AUM_F32 / AUM_BF16 / AUM_F16), dst: (batch, inner) fp32.  inner % 8 == 0; src 16-byte aligned, dst any float address (round 6: a parameter
+ * gradient's view inside a DistributedDataParallel bucket may sit behind an odd-sized parameter).
  */
 int aum_sum_rows(const void* src, float* dst, int64_t batch, int64_t outer, int64_t inner, int32_t src_dtype, void* stream);
 
@@ -600,7 +601,7 @@ int aum_sum_rows(const void* src, float* dst, int64_t batch, int64_t outer, int6
  * aum_conv1d_tm_bwd), and a 5 us launch per set is 5 us of the step.  Job q:  dst[i] = sum over o < outer of src[o][i],  i < inner  -- each job with
  * the row grouping aum_sum_rows (batch = 1) picks for it, i.e. the same additions in the same order as a launch of its own: bitwise the same result.  tr_cols > 0: the summed (inner / tr_cols, tr_cols) matrix is stored transposed, dst
  * (tr_cols, inner / tr_cols) -- the x_proj weight gradient leaves aum_gemm_wgrad as (dim, R + 2N) and the parameter is (R + 2N, dim).
- * 1 <= njobs <= AUM_SUM_MAX_JOBS, inner % 8 == 0, inner % tr_cols == 0, 16-byte aligned pointers; `jobs` is read on the host during the call.
+ * 1 <= njobs <= AUM_SUM_MAX_JOBS, inner % 8 == 0, inner % tr_cols == 0; src 16-byte aligned, dst any float address; `jobs` is read on the host during the call.
  */
 #define AUM_SUM_MAX_JOBS 8
 typedef struct AumSumJob {

@@ -38,22 +38,26 @@ def main():
     y.scatter_(1, torch.randint(0, n_class, (B, 2), device=dev, generator=g), 1.0)
     loss_fn = torch.nn.BCEWithLogitsLoss()
     assert not ssi.v2_two_streams(), "a process group without the joining hook: Bi-Bi stays on one stream"
+    ssi._TM_MIN_WAVES = 1          # the token-major block (the bench's) at this small batch: its kernels are the ones that write gradients in place
     for name, bim, comp in (("v1_fp32", "v1", "no"), ("v1_bf16", "v1", "bf16"), ("v2_fp32", "v2", "no")):
         torch.manual_seed(11)
         model = build_aum("base", depth=2, num_classes=n_class, bimamba_type=bim).to(dev)
         ref = copy.deepcopy(model)
-        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True, bucket_cap_mb=64,
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True,
                                                         broadcast_buffers=False)
-        compress_gradients(ddp, comp)          # registers ssi.ddp_join_streams_hook(...): from here on Bi-Bi may use its side stream
+        homes = compress_gradients(ddp, comp)  # registers the exchange hook (Bi-Bi: ssi.ddp_join_streams_hook(...): from here on it may use its side stream)
         opts = [torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=5e-7, betas=(0.95, 0.999), eps=1e-8, fused=True) for m in (model, ref)]
         rec = {"two_streams": bool(ssi.v2_two_streams()), "steps": []}
-        for step in range(2):
+        hits0 = ssi.HOME_HITS[0]
+        for step in range(4):
             losses = []
             for net, streams in ((ddp, True), (ref, False)):
                 ssi._V2_STREAMS = streams      # the un-wrapped comparison model runs Bi-Bi in line: two streams vs one, bit for bit
                 with torch.autocast("cuda", dtype=torch.bfloat16):
                     loss = loss_fn(net(x).float(), y)
                 loss.backward()
+                if net is ddp:
+                    adopted = homes.after_backward()       # from the next step on the kernels write into the reducer's buckets
                 losses.append(float(loss))
             ssi._V2_STREAMS = True
             torch.cuda.synchronize()
@@ -67,12 +71,14 @@ def main():
                 worst = max(worst, float((p.grad - want).abs().max()) / (float(want.abs().max()) + 1e-30))
                 n += 1
             views = sum(1 for p in model.parameters() if p.grad is not None and p.grad._is_view())
+            # gradients the kernels wrote straight into the reducer's bucket (ssi.grad_home): none in step 0, the blocks' parameters afterwards
+            in_home, hits0 = ssi.HOME_HITS[0] - hits0, ssi.HOME_HITS[0]
             for o in opts:
                 o.step()
                 o.zero_grad(set_to_none=True)
             torch.cuda.synchronize()
             same_w = all(torch.equal(p, q) for p, q in zip(model.parameters(), ref.parameters()))
-            rec["steps"].append({"loss": losses, "grads_equal": bool(equal), "worst_rel": worst, "n_grads": n, "bucket_views": views,
+            rec["steps"].append({"loss": losses, "grads_equal": bool(equal), "worst_rel": worst, "n_grads": n, "bucket_views": views, "in_home": in_home, "adopted": adopted,
                                  "params_equal": bool(same_w), "finite": bool(all(torch.isfinite(p).all() for p in model.parameters()))})
             if comp != "no":
                 break              # after a rounded exchange the two models differ by construction

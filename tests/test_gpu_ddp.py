@@ -39,11 +39,16 @@ def test_ddp_world1_rccl_reducer_bucket_views_hooks_two_streams():
     assert res["backend"] == "nccl" and res["world"] == 1 and res["all_reduce_ok"]
     for name in ("v1_fp32", "v2_fp32"):
         steps = res[name]["steps"]
-        assert len(steps) == 2
-        for s in steps:      # reducer + bucket views + hook leave exactly the un-wrapped model's gradients and parameters
+        assert len(steps) == 4
+        for i, s in enumerate(steps):      # reducer + bucket views + hook leave exactly the un-wrapped model's gradients and parameters
             assert s["grads_equal"] and s["params_equal"] and s["finite"] and s["n_grads"] > 20, (name, s)
-            assert s["bucket_views"] == s["n_grads"], (name, s)
+            # every gradient sits in a bucket: as the view the reducer made of it, or written there by the kernel that finished it (those the
+            # accumulator keeps as plain aliases of the bucket's storage)
+            assert s["bucket_views"] + s["in_home"] >= s["n_grads"] and (i > 1 or s["bucket_views"] == s["n_grads"]), (name, s)
             assert s["loss"][0] == s["loss"][1]
+            # round 6: from the second step on the blocks' kernels write their parameter gradients straight into the reducer's buckets
+            # (ssi.grad_home): 2 blocks x 11 parameters (+ the final norm's weight) -- and the gradients are still the un-wrapped model's, bit for bit
+            assert (s["in_home"] == 0) if i == 0 else (s["in_home"] >= 22), (name, i, s)
     assert res["v2_fp32"]["two_streams"], "Bi-Bi's side stream stays on under DDP once the joining hook is registered"
     s = res["v1_bf16"]["steps"][0]
     assert s["grads_equal"] and s["finite"], s           # == the un-wrapped gradient rounded to bf16, bit for bit

@@ -23,7 +23,7 @@ def run(tag, ddp, streams, join):
     net = model
     ssi._V2_STREAMS = streams
     if ddp:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True, bucket_cap_mb=64, broadcast_buffers=False)
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True, broadcast_buffers=False)
         if join:
             net.register_comm_hook(None, ssi.ddp_join_streams_hook())
         else:

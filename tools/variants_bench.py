@@ -30,7 +30,7 @@ def run(size, btype, train, batch=64, steps=6, warm=3, frames=1024, ddp=None):
             for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29547"), ("RANK", "0"), ("WORLD_SIZE", "1")):
                 os.environ.setdefault(k, v)
             dist.init_process_group("nccl", device_id=dev)
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True, bucket_cap_mb=64, broadcast_buffers=False)
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True, broadcast_buffers=False)
         compress_gradients(net, ddp)
     tabs = FbankTables(dev)
     wave = (torch.randn(batch, 400 + (frames - 1) * 160 if frames != 1024 else 160000, device=dev) * 0.1).clamp_(-1, 1)
