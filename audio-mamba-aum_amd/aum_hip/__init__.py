@@ -26,7 +26,7 @@ _ERR = {-1: "AUM_E_NULL", -2: "AUM_E_SHAPE", -3: "AUM_E_DTYPE", -4: "AUM_E_UNSUP
         -6: "AUM_E_LAUNCH"}
 
 _i64, _i32, _u32, _vp, _fp = C.c_int64, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class _Debug:
@@ -152,10 +152,6 @@ class XdtBwdArgs(C.Structure):
                 + [(n, _i32) for n in ("dim", "rank", "ncols", "ldd", "lddbc", "ldwdt", "ldwx", "ldu", "ldx", "dtype")])
 
 
-class GemmSkArgs(C.Structure):
-    _fields_ = [("base", GemmArgs), ("workspace", _vp), ("workspace_bytes", _i64), ("epoch", _u32), ("reserved", _u32)]
-
-
 class GemmWArgs(C.Structure):
     _fields_ = [("y", C.c_void_p), ("x", C.c_void_p), ("part", C.c_void_p), ("t", C.c_int64), ("ldy", C.c_int64), ("ldx", C.c_int64),
                 ("n", C.c_int32), ("k", C.c_int32), ("splits", C.c_int32), ("dtype", C.c_int32)]
@@ -193,7 +189,7 @@ EXPORTS = ["aum_gemm_tn", "aum_dtproj_tm_fwd", "aum_xdt_tm_fwd", "aum_proj_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows", "aum_sum_rows_multi",
            "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_ckpt_rows", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_scan_tm_seg_fwd", "aum_scan_tm_seg_bwd",
            "aum_scan_tm_seg_carry_bytes", "aum_scan_tm_seg_workspace_bytes", "aum_selftest_wave_sum32",
-           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_scan_tm_bwd_matrix_sums", "aum_gemm_wgrad", "aum_gemm_tn_sk", "aum_gemm_tn_sk_workspace_bytes", "aum_xdt_tm_bwd", "aum_causal_conv1d_update", "aum_selective_state_update"]
+           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_gemm_wgrad", "aum_xdt_tm_bwd", "aum_causal_conv1d_update", "aum_selective_state_update"]
 
 
 class Lib:
@@ -222,12 +218,8 @@ class Lib:
         self.c.aum_conv1d_tm_fwd.argtypes = [_vp, _vp]
         self.c.aum_conv1d_tm_bwd.argtypes = [_vp, _vp]
         self.c.aum_conv1d_tm_nparts.argtypes = [_i32, _i32]
-        self.c.aum_scan_tm_bwd_matrix_sums.argtypes = []
         self.c.aum_gemm_tn.argtypes = [_vp, _vp]
         self.c.aum_gemm_wgrad.argtypes = [_vp, _vp]
-        self.c.aum_gemm_tn_sk.argtypes = [_vp, _vp]
-        self.c.aum_gemm_tn_sk_workspace_bytes.restype = _i64
-        self.c.aum_gemm_tn_sk_workspace_bytes.argtypes = [_i64, _i32]
         self.c.aum_causal_conv1d_update.argtypes = [_vp, _vp]
         self.c.aum_selective_state_update.argtypes = [_vp, _vp]
         self.c.aum_dtproj_tm_fwd.argtypes = [_vp, _vp]
@@ -785,12 +777,13 @@ def gemm_tn_supported(a, b):
             and 512 * a.stride(0) < 2 ** 31 and 512 * b.stride(0) < 2 ** 31)
 
 
-GEMM_LOCKSTEP, GEMM_STAGGERED, GEMM_PERSISTENT, GEMM_PIPELINED, GEMM_W4, GEMM_RING, GEMM_PACED = 1, 2, 4, 32, 64, 128, 256
+GEMM_LOCKSTEP, GEMM_PIPELINED, GEMM_PACED = 1, 32, 256
 
 
-def gemm_tn(a, b, out=None, lib=None, flags=0, split_tail=None):
+def gemm_tn(a, b, out=None, lib=None, flags=0):
     """out[m][n] = sum_k a[m][k] b[n][k]: the in_proj / out_proj GEMM and their data gradients on token-major activations (MS:185-189,
-    SSI:517, 540).  a (m, k), b (n, k): 16-bit, K contiguous; out (m, n) rows contiguous (may be a column block of a wider tensor)."""
+    SSI:517, 540).  a (m, k), b (n, k): 16-bit, K contiguous; out (m, n) rows contiguous (may be a column block of a wider tensor).
+    flags: 0 (the library picks: the paced-store kernel from k = 448 on) or one of GEMM_LOCKSTEP / GEMM_PIPELINED / GEMM_PACED."""
     lib = lib or get()
     lib.check_tensor(a)
     lib.check_tensor(b)
@@ -808,38 +801,8 @@ def gemm_tn(a, b, out=None, lib=None, flags=0, split_tail=None):
     g.a, g.b, g.c = _ptr(a), _ptr(b), _ptr(out)
     g.m, g.n, g.k, g.lda, g.ldb, g.ldc, g.dtype = m, n, k, a.stride(0), b.stride(0), out.stride(0), _DT[a.dtype]
     g.flags = flags
-    # opt-in: a half-empty last round of tiles (n = 768 at 64 x 513 tokens: 387 tiles on 256 CUs) split along K between the workgroups
-    ws_bytes = int(lib.c.aum_gemm_tn_sk_workspace_bytes(m, n)) if (split_tail is None and not flags and _SPLIT_TAIL) or split_tail else 0
-    if ws_bytes > 0:
-        key = (lib.path, str(a.device))
-        ws = _sk_ws.get(key)
-        if ws is None or ws[0].numel() < ws_bytes:
-            ws = [torch.zeros((ws_bytes + 255) // 256 * 256, dtype=torch.uint8, device=a.device), 0]      # flags zero once; the epoch does the rest
-            _sk_ws[key] = ws
-        ws[1] = ws[1] % 0xfffffffe + 1
-        sk = GemmSkArgs()
-        sk.base = g
-        sk.workspace, sk.workspace_bytes, sk.epoch = _ptr(ws[0]), ws[0].numel(), ws[1]
-        _launch(lib.c.aum_gemm_tn_sk, sk, a, lib, "gemm_tn", (m, n, k))
-        return out
-    if split_tail:
-        raise RuntimeError(f"gemm_tn: the split tail does not apply to m = {m}, n = {n} on this device")
     _launch(lib.c.aum_gemm_tn, g, a, lib, "gemm_tn", (m, n, k))
     return out
-
-
-_sk_ws = {}            # (library, device) -> [workspace of aum_gemm_tn_sk, launch count]: launches are ordered by the stream they share
-# Measured in round 4 (profiles/r04_gemm_split_tail.txt): NOT faster than whole tiles -- the partial-tile hand-over (write, flag, read: a
-# serial chain of ~15-25 us behind half a tile of MFMAs) costs what the idle half round cost.  Opt-in: split_tail=True, or
-# AUM_DEBUG=1 AUM_GEMM_SPLIT_TAIL=1 for the dispatch of the model.
-_SPLIT_TAIL = os.environ.get("AUM_DEBUG") == "1" and os.environ.get("AUM_GEMM_SPLIT_TAIL", "0") == "1"
-
-
-def gemm_tn_sk_error(device, lib=None):
-    """nonzero if a split-tail launch on `device` ran out of its bounded wait (its result is then incomplete): word 0 of the workspace"""
-    lib = lib or get()
-    ws = _sk_ws.get((lib.path, str(torch.device(device) if not isinstance(device, torch.device) else device)))
-    return 0 if ws is None else int(ws[0][:4].view(torch.int32).item())
 
 
 def conv1d_update(x, conv_state, weight, bias=None, silu=True, lib=None):
@@ -1321,12 +1284,11 @@ def selftest_wave_scan(P, S, rev=False, lib=None):
 
 
 def selftest_wave_sum32(values, lib=None):
-    """values: (32, 64) fp32 -> (4, 64): row 0 the totals in the lane order of wave_sum32 (lane l: value 2 * (l & 15) + ((l >> 4) & 1)),
-    row 1 wave_sum16 of the first 16 values, rows 2 / 3 the matrix-pipe sums (terms rounded to bf16) of values 0..15 / 16..31 (lane l:
-    value 4 * (l >> 4) + bit3(l) + 2 * bit2(l) of the tile)"""
+    """values: (32, 64) fp32 -> (2, 64): row 0 the totals in the lane order of wave_sum32 (lane l: value 2 * (l & 15) + ((l >> 4) & 1)),
+    row 1 wave_sum16 of the first 16 values"""
     lib = lib or get()
     inp = values.float().contiguous()
-    out = torch.empty((4, 64), dtype=torch.float32, device=inp.device)
+    out = torch.empty((2, 64), dtype=torch.float32, device=inp.device)
     _chk(lib.c.aum_selftest_wave_sum32(_ptr(inp), _ptr(out), lib.stream(inp)), "aum_selftest_wave_sum32")
     return out
 

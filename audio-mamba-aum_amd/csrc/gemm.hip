@@ -2,8 +2,6 @@
 // the token-major block (dtproj_kernels.h, aum_dtproj_tm_fwd); include/aum_hip.h, ABI 9.
 #include <atomic>
 #include "gemm_kernels.h"
-#include "gemm_w4_kernels.h"
-#include "gemm_ring_kernels.h"
 #include "gemm_ps_kernels.h"
 #include "dtproj_kernels.h"
 #include "xdt_kernels.h"
@@ -29,137 +27,32 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
     const AumGemmArgs& g = *p;
     const int tiles = (g.m + aumg::BM - 1) / aumg::BM * (g.n / aumg::BN);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // CU count of the CURRENT device (one process may drive several devices from several threads): a small per-device cache, filled
-    // with relaxed atomics -- racing fillers write the same value
-    static std::atomic<int> ncu_of[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return AUM_E_LAUNCH;
-    int ncu = ncu_of[dev].load(std::memory_order_relaxed);
-    if (!ncu) {
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) return AUM_E_LAUNCH;
-        ncu_of[dev].store(ncu, std::memory_order_relaxed);
-    }
+    const int ncu = cu_count();
+    if (ncu <= 0) return AUM_E_LAUNCH;
     (void)hipGetLastError();        // a stale error of an earlier, unrelated launch must not be reported as this one's
-    // Which kernel: the persistent one pays off when a CU gets several tiles (cheap ragged row block, next tile prefetched under the stores:
-    // 774 / 1548 tiles at N = 1536 / 3072: 84.6 vs 94.2 us, 158.6 vs 169.1 us); with at most two tiles per CU (N = 768: 387 tiles) one
-    // workgroup per tile is as fast or faster (84.3 vs 87.4 us, 159.4 vs 162.2 us; profiles/r03_gemm_probe.txt) -- since round 4 with the
-    // software-pipelined K loop (SCHED 2: 74.6 / 134.7 us on the box where the persistent kernel took 82.7 / 154.2)
-    uint32_t flags = g.flags;
-    // default (no schedule named): the paced-store kernel of round 6 whenever a tile has the seven K-steps its store pacing needs (every
-    // projection of the model: k >= 768); shorter products keep the round-3 / round-4 kernels below
-    if (!(flags & (AUM_GEMM_LOCKSTEP | AUM_GEMM_STAGGERED | AUM_GEMM_PERSISTENT | AUM_GEMM_PIPELINED | AUM_GEMM_W4 | AUM_GEMM_RING | AUM_GEMM_PACED))
-        && g.k >= (aumg::PS_NST + 1) * aumg::BK)
-        flags |= AUM_GEMM_PACED;
+    // Which kernel: the paced-store kernel (round 6, gemm_ps_kernels.h: one workgroup per CU walking a tile list, a tile's stores under the
+    // next tile's K-steps) whenever a tile has the seven K-steps its store pacing needs -- every projection of the model (k >= 768);
+    // shorter products: one workgroup per tile, software-pipelined K loop (round 4).  AUM_GEMM_LOCKSTEP / _PIPELINED / _PACED name one.
+    uint32_t flags = g.flags & (AUM_GEMM_LOCKSTEP | AUM_GEMM_PIPELINED | AUM_GEMM_PACED);
+    if (!flags) flags = g.k >= (aumg::PS_NST + 1) * aumg::BK ? AUM_GEMM_PACED : AUM_GEMM_PIPELINED;
     if (flags & AUM_GEMM_PACED) {
         if (g.k < (aumg::PS_NST + 1) * aumg::BK) return AUM_E_UNSUPPORTED;
         aumg::GemmLaunch L;
         L.g = g;
-        L.full_rb = (g.m + aumg::BM - 1) / aumg::BM;
-        L.half_rb = 0;
-        L.nitems = L.full_rb * (g.n / aumg::BN);
+        aumg::gemm_ps_items(g.m, g.n, ncu, &L);
         const int grid = L.nitems < ncu ? L.nitems : ncu;
         if (g.dtype == AUM_BF16) hipLaunchKernelGGL(aumg::k_gemm_tn_ps<true>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
         else hipLaunchKernelGGL(aumg::k_gemm_tn_ps<false>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
         return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
     }
-    if (flags & AUM_GEMM_RING) {
-        if (g.n % aumg::RING_BN || g.k < 8 * aumg::RING_BK) return AUM_E_UNSUPPORTED;
-        aumg::GemmLaunch L;
-        L.g = g;
-        L.full_rb = (g.m + aumg::BM - 1) / aumg::BM;
-        L.half_rb = 0;
-        L.nitems = L.full_rb * (g.n / aumg::RING_BN);
-        const int grid = L.nitems < ncu ? L.nitems : ncu;
-        if (g.dtype == AUM_BF16) hipLaunchKernelGGL(aumg::k_gemm_tn_ring<true>, dim3(grid), dim3(aumg::W4_THREADS), 0, s, L);
-        else hipLaunchKernelGGL(aumg::k_gemm_tn_ring<false>, dim3(grid), dim3(aumg::W4_THREADS), 0, s, L);
-        return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
-    }
-    if (flags & AUM_GEMM_W4) {
-        if (g.n % 192 || g.k < 2 * aumg::BK) return AUM_E_UNSUPPORTED;
-        aumg::GemmLaunch L;
-        L.g = g;
-        L.full_rb = (g.m + aumg::BM - 1) / aumg::BM;
-        L.half_rb = 0;
-        L.nitems = L.full_rb * (g.n / 192);
-        const int grid = L.nitems < ncu ? L.nitems : ncu;
-        if (g.dtype == AUM_BF16) hipLaunchKernelGGL((aumg::k_gemm_tn_w4<true, 6>), dim3(grid), dim3(aumg::W4_THREADS), 0, s, L);
-        else hipLaunchKernelGGL((aumg::k_gemm_tn_w4<false, 6>), dim3(grid), dim3(aumg::W4_THREADS), 0, s, L);
-        return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
-    }
-    if (!(flags & (AUM_GEMM_LOCKSTEP | AUM_GEMM_STAGGERED | AUM_GEMM_PERSISTENT | AUM_GEMM_PIPELINED))) flags |= tiles > 2 * ncu ? AUM_GEMM_PERSISTENT : AUM_GEMM_PIPELINED;
-    if (flags & AUM_GEMM_PERSISTENT) {
-        aumg::GemmLaunch L;
-        L.g = g;
-        const int rem = g.m % aumg::BM;
-        L.full_rb = g.m / aumg::BM + (rem > 128 ? 1 : 0);            // a remainder above 128 rows is a full item whose last rows are out of range
-        L.half_rb = rem > 0 && rem <= 128 ? 1 : 0;
-        L.nitems = (L.full_rb + L.half_rb) * (g.n / aumg::BN);
-        const int grid = L.nitems < ncu ? L.nitems : ncu;
-        if (g.dtype == AUM_BF16) hipLaunchKernelGGL(aumg::k_gemm_tn_persistent<true>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
-        else hipLaunchKernelGGL(aumg::k_gemm_tn_persistent<false>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
-        return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
-    }
-    const bool lockstep = (flags & AUM_GEMM_LOCKSTEP) != 0;
+    const bool bf = g.dtype == AUM_BF16;
     if (flags & AUM_GEMM_PIPELINED) {
-        if (g.dtype == AUM_BF16) hipLaunchKernelGGL((aumg::k_gemm_tn<true, 2>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
+        if (bf) hipLaunchKernelGGL((aumg::k_gemm_tn<true, 2>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
         else hipLaunchKernelGGL((aumg::k_gemm_tn<false, 2>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
-        return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
-    }
-    if (g.dtype == AUM_BF16) {
-        if (lockstep) hipLaunchKernelGGL((aumg::k_gemm_tn<true, 0>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
-        else hipLaunchKernelGGL((aumg::k_gemm_tn<true, 1>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
     } else {
-        if (lockstep) hipLaunchKernelGGL((aumg::k_gemm_tn<false, 0>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
-        else hipLaunchKernelGGL((aumg::k_gemm_tn<false, 1>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
+        if (bf) hipLaunchKernelGGL((aumg::k_gemm_tn<true, 0>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
+        else hipLaunchKernelGGL((aumg::k_gemm_tn<false, 0>), dim3(tiles), dim3(aumg::THREADS), 0, s, g);
     }
-    return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
-}
-
-// split-tail geometry for (m, n) on `ncu` CUs: grid (a multiple of 8 workgroups), complete rounds, tail tiles; applies when the tail is
-// at least half a round (every tile then has at most SK_SLOTS + 1 contributors)
-static bool sk_geometry(int64_t m, int n, int ncu, int* grid, int* rounds, int* tail) {
-    if (m <= 0 || n <= 0 || n % aumg::BN) return false;
-    const int g8 = ncu / 8 * 8;
-    if (g8 < 8) return false;
-    const int64_t tiles = (m + aumg::BM - 1) / aumg::BM * (n / aumg::BN);
-    *grid = g8;
-    *rounds = (int)(tiles / g8);
-    *tail = (int)(tiles - (int64_t)*rounds * g8);
-    return *tail * 2 >= g8 && *tail < g8;
-}
-static int64_t sk_flag_bytes(int tail) { return ((int64_t)(tail * aumg::SK_SLOTS + 1) * 4 + 255) / 256 * 256; }
-
-extern "C" int64_t aum_gemm_tn_sk_workspace_bytes(int64_t m, int32_t n) {
-    const int ncu = cu_count();
-    int grid, rounds, tail;
-    if (ncu <= 0 || !sk_geometry(m, n, ncu, &grid, &rounds, &tail)) return 0;
-    return sk_flag_bytes(tail) + (int64_t)tail * aumg::SK_SLOTS * aumg::BM * aumg::BN * 4;
-}
-
-extern "C" int aum_gemm_tn_sk(const AumGemmSkArgs* p, void* stream) {
-    if (!p) return AUM_E_NULL;
-    const int rc = aumg::gemm_check(&p->base);
-    if (rc != AUM_OK) return rc;
-    if (!p->workspace || !p->epoch) return AUM_E_NULL;
-    const AumGemmArgs& g = p->base;
-    const int ncu = cu_count();
-    int grid, rounds, tail;
-    if (ncu <= 0) return AUM_E_LAUNCH;
-    if (!sk_geometry(g.m, g.n, ncu, &grid, &rounds, &tail)) return AUM_E_UNSUPPORTED;
-    const int64_t fb = sk_flag_bytes(tail);
-    if (((uintptr_t)p->workspace & 255u) || p->workspace_bytes < fb + (int64_t)tail * aumg::SK_SLOTS * aumg::BM * aumg::BN * 4) return AUM_E_WORKSPACE;
-    aumg::GemmSkLaunch L;
-    L.g = g;
-    L.err = static_cast<uint32_t*>(p->workspace);                  // word 0: set when a bounded wait ran out; flags behind it
-    L.flags = L.err + 1;
-    L.part = reinterpret_cast<float*>(static_cast<char*>(p->workspace) + fb);
-    L.epoch = p->epoch;
-    L.rounds = rounds;
-    L.tail = tail;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    (void)hipGetLastError();
-    if (g.dtype == AUM_BF16) hipLaunchKernelGGL(aumg::k_gemm_tn_sk<true>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
-    else hipLaunchKernelGGL(aumg::k_gemm_tn_sk<false>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
     return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
 }
 

@@ -43,12 +43,6 @@ typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 
-#ifndef AUM_GEMM_PRIO
-#define AUM_GEMM_PRIO 0     // A/B builds: 1 the second-dispatched half of the waves (4-7, the younger wave of every SIMD) holds priority 1; 2 the two waves of a SIMD take turns K-step by K-step
-#endif
-#ifndef AUM_GEMM_ABL
-#define AUM_GEMM_ABL 0      // timing experiments on the persistent kernel only (wrong results; tools/gemm_abl_probe.py): 1 no tile-end stores, 2 two dummy
-#endif                      // stores per wave in each of a tile's first eight K-steps (the paced-store pattern), 4 no DMA pieces inside the K loop, 8 no reads / MFMAs
 constexpr int NWAVES = 8, THREADS = NWAVES * 64;
 constexpr int TILE_BYTES = BM * BK * 2;                 // one operand, one K-step: 32 KB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;             // A | B
@@ -86,26 +80,17 @@ __device__ __forceinline__ int xcd_tile(int orig, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// SCHED 0: every wave stages, reads and multiplies K-step by K-step in lockstep, one barrier per step (the first version; kept for A/B:
-//          AUM_GEMM_LOCKSTEP).
-// SCHED 1: the two waves of a SIMD (wave w and w + 4 = the row halves wr = 0 / 1 of the tile) run half a K-step apart.  A phase = half a
-//          K-step (32 of the 64 k) = a LOAD segment (12 fragment reads, and on one phase per step the wave's 8 DMA pieces of the next
-//          step) and an MFMA segment (32 MFMAs at raised priority), a workgroup barrier after each; wr = 1 starts one barrier late, so
-//          between two barriers one wave of every SIMD feeds the matrix pipe while the other fetches.  With barriers B_0 .. B_2P
-//          (P = 2 nk phases) and segment s = the code between B_{s-1} and B_s:
-//              wr = 0:  load(p) in segment 2p,     MFMA(p) in segment 2p + 1        wr = 1:  load(p) in 2p + 1,  MFMA(p) in 2p + 2
-//          K-step t + 1 goes into the buffer step t - 1 was read from.  Its last reads (phase 2t - 1) have retired before B_{4t-1}
-//          (wr = 0: lgkmcnt(0) at the head of MFMA(2t-1), segment 4t - 1) and before B_{4t} (wr = 1, segment 4t), so pieces may be issued
-//          from segment 4t + 1 on; its first reads (phase 2t + 2) are in segment 4t + 4 (wr = 0), so the pieces must have landed before
-//          B_{4t+3}.  wr = 1 issues in segment 4t + 1 (its load(2t)) and waits at the end of segment 4t + 3 (its load(2t+1)); wr = 0 issues
-//          in segment 4t + 2 (its load(2t+1)) and waits at the end of segment 4t + 3 (its MFMA(2t+1)).
+// SCHED 0: every wave stages, reads and multiplies K-step by K-step in lockstep, one barrier per step (the first version: AUM_GEMM_LOCKSTEP).
+// SCHED 2: the fragments of the next half K-step are read under the current half's MFMAs (AUM_GEMM_PIPELINED, the default for products too
+//          short for the paced-store kernel of gemm_ps_kernels.h).
+// (Round 3 also had a staggered schedule -- the two waves of a SIMD half a K-step apart, 3-6 % slower -- and a persistent form of SCHED 0;
+// round 5 a four-wave and a ring division; round 4 a split-K tail: all measured slower than what is left here, removed in round 6 -- HISTORY.md.)
 template <bool BF16, int SCHED>
 __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
     __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
     const int lane = (int)(threadIdx.x & 63u);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = w >> 2, wc = w & 3;
-    if (AUM_GEMM_PRIO == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
     const int ntn = g.n / BN;
     const int tile = xcd_tile((int)blockIdx.x, (int)gridDim.x);
     const int tm = tile / ntn, tn = tile - tm * ntn;
@@ -159,7 +144,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
                     for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(bf[j], af[i], acc[i][j]);
             }
         }
-    } else if constexpr (SCHED == 2) {
+    } else {
+        static_assert(SCHED == 2, "schedules: 0 lockstep, 2 pipelined");
         // SCHED 2 (round 4, AUM_GEMM_PIPELINED; the default where a CU gets at most two tiles): same box, us, lockstep -> pipelined:
         //   N x K = 3072 x 768: 165.0 -> 156.5, 768 x 1536: 81.4 -> 74.6, 1536 x 768: 93.3 -> 87.4, 768 x 3072: 145.6 -> 134.7 (bitwise the same
         //   results).  The same loop inside the persistent kernel needs 243 registers and ran 2-18 % SLOWER than its 170-register loop: not kept.
@@ -175,7 +161,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) af[0][i] = lds_frag(lds, a_rd + i * 2048);
         for (int t = 0; t < nk; ++t) {
-            if (AUM_GEMM_PRIO == 2) { if ((t + (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
             const char* st = lds + (t & 1) * STAGE_BYTES;
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[1][j] = lds_frag(st, (b_rd ^ 64) + b_joff(j));
@@ -212,42 +197,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
         }
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                              // step 0 is in LDS
-        if (wr == 1) __builtin_amdgcn_s_barrier();                 // B_0: the second wave of every SIMD runs one segment behind
-        for (int t = 0; t < nk; ++t) {
-            const char* st = lds + (t & 1) * STAGE_BYTES;
-            const bool more = t + 1 < nk;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                // ---- load segment
-                s8v bf[4], af[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bf[j] = lds_frag(st, (b_rd ^ (kk * 64)) + b_joff(j));
-#pragma unroll
-                for (int i = 0; i < 8; ++i) af[i] = lds_frag(st, (a_rd ^ (kk * 64)) + i * 2048);
-                if (more && kk == 1 - wr) stage(ra, rb, voff_a, voff_b, (t + 1) * (BK * 2), rowstep_a, rowstep_b, lds + ((t + 1) & 1) * STAGE_BYTES, w);
-                if (more && kk == 1 && wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- MFMA segment
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(bf[j], af[i], acc[i][j]);
-                __builtin_amdgcn_s_setprio(0);
-                if (more && kk == 1 && wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (wr == 0) __builtin_amdgcn_s_barrier();                 // B_2P
     }
 
     // store: lane holds, for fragment row i, columns wc * 64 + 32 (j >> 1) + 8 kg + 4 (j & 1) + r (j, r = 0..3) of row wr * 128 + 16 i + rho
@@ -273,395 +222,40 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn(AumGemmArgs g) {
 }
 
 
-// ------------------------------------------------------------------------------------------------------------------------------------
-// Persistent form (the default).  One workgroup per CU walks a list of work items round-robin (item = blockIdx + round * gridDim):
-//   * full items: 256 x 256 tiles of the row blocks that are complete; in each round the 32 workgroups of an XCD take 32 consecutive
-//     tiles (2.7 row blocks of A x the column tiles: A comes from HBM once per XCD, the weight stays in L2 / MALL);
-//   * half items: the last m % 256 rows when they are at most 128 (the bench: 64 x 513 tokens = 128 row blocks + 64 rows) as 128 x 256
-//     tiles -- the two row halves of the wave grid take 64 rows each (4 fragment rows instead of 8), a half with no rows left skips its
-//     reads and MFMAs -- instead of a round of full-price tiles for a quarter of a tile's work (7 -> 6.3 rounds at N = 3072).
-//   * the K loop is the lockstep one (SCHED 0 above); in its LAST step, where a tile has nothing left to fetch, the wave issues the
-//     pieces of the NEXT item's first step, so the next tile's HBM round trip runs under this tile's stores, and the next tile's first
-//     wait is counted so that those stores stay in flight.
-// What bounds it (measured, profiles/r03_gemm_*): a K-step takes 1.54 us (1.39 PFLOP/s across the chip) whatever the shape, and every tile
-// pays 5.7 us on top -- its 128 KB of C leave the CU at HBM's pace while every matrix pipe idles, in all 256 CUs at the same moment
-// (tiles take equal time).  Tried: rounding a finished tile to 64 packed registers and storing it two stores per K-step under the next
-// tile (exact counted waits): 256 VGPRs + spills, the compiler falls back to one fragment read per four MFMAs, 210 us instead of 159;
-// deferring half of the tile (230 VGPRs, no spills): 162 us, the basic loop loses what the stores gain.  Not kept.
-// Buffer parity: step t of a tile uses buffer (par + t) & 1; the next tile starts at par' = (par + nk) & 1, the buffer the last-but-one
-// step was read from (free since the barrier of the last step).
-// ------------------------------------------------------------------------------------------------------------------------------------
+// work list of the paced-store kernel (gemm_ps_kernels.h).  Items [0, nwhole) are whole tiles: a 256-row block (the last one may be
+// ragged) x one column tile.  When the tile count leaves a last round at most half full (n = 768 at 64 x 513 tokens: 384 + 3 tiles on 256
+// CUs), the tiles of that round are SPLIT into two items of 128 rows each (items nwhole + 2 q, + 1 = the halves of tile nwhole + q): a
+// half runs as a ragged tile -- its rows beyond 128 read as zero and are not stored, it moves 3/4 of a tile's bytes and runs at the
+// matrix pipes' pace (0.65 of a whole tile) -- so the last round costs 0.65 instead of 1.  `fold` ragged rows (M mod 256, at most 64)
+// then belong to the second half of the last 256-row block (128 + fold rows) instead of being a row block of their own.
 struct GemmLaunch {
     AumGemmArgs g;
-    int full_rb;        // complete 256-row blocks handled as full items
-    int half_rb;        // 128-row blocks behind them (the last one may be ragged)
-    int nitems;
+    int nitems;         // nwhole + 2 * (split tiles)
+    int nwhole;
+    int fold;
 };
 
-struct GemmItem {
-    int m0, n0, rows;
-    bool half;
-};
-__device__ __forceinline__ GemmItem gemm_item(const GemmLaunch& L, int id, int ntn, int grid) {
-    GemmItem it;
-    const int nfull = L.full_rb * ntn;
-    if (id < nfull) {
-        int tile = id;
-        const int r0 = id / grid * grid;
-        if ((grid & 7) == 0 && r0 + grid <= nfull) {            // a complete round: XCD x (= workgroup % 8) takes tiles r0 + x * grid/8 ...
-            const int q = id - r0;
-            tile = r0 + (q & 7) * (grid >> 3) + (q >> 3);
-        }
-        const int tm = tile / ntn;
-        it.m0 = tm * BM;
-        it.n0 = (tile - tm * ntn) * BN;
-        it.rows = L.g.m - it.m0 < BM ? L.g.m - it.m0 : BM;       // < BM only for a last row block of 129 .. 255 rows (taken as a full item)
-        it.half = false;
+// the work list for (m, n) on `ncu` CUs (host side; gemm.hip).  Splitting applies when the whole tiles fill complete rounds and the rest
+// fits, as halves, into one: 0 < rem, 2 rem <= ncu.
+static inline void gemm_ps_items(int64_t m, int n, int ncu, GemmLaunch* L) {
+    const int ntn = n / BN;
+    const int full = (int)(m / BM), r = (int)(m % BM);
+    const bool can_fold = r > 0 && r <= 64 && full >= 1;
+    const int rb_all = full + (r > 0 ? 1 : 0);
+    const int rb = can_fold ? full : rb_all;
+    const int t = rb * ntn, rem = t % ncu;
+    // a ragged row block of 65 .. 128 rows would leave its second half empty: such shapes are not split
+#ifndef AUM_PS_SPLIT_TAIL
+#define AUM_PS_SPLIT_TAIL 1     // 0: A/B build (tools/build_gemm_variant.sh nosplit -DAUM_PS_SPLIT_TAIL=0): whole tiles only
+#endif
+    const bool ok = AUM_PS_SPLIT_TAIL && t > ncu && rem > 0 && 2 * rem <= ncu && (can_fold ? rem >= ntn : (r == 0 || r > 128));
+    if (ok) {
+        L->nwhole = t - rem;
+        L->nitems = t + rem;
+        L->fold = can_fold ? r : 0;
     } else {
-        const int h = id - nfull, hb = h / ntn;
-        it.m0 = L.full_rb * BM + hb * 128;
-        it.n0 = (h - hb * ntn) * BN;
-        it.rows = L.g.m - it.m0 < 128 ? L.g.m - it.m0 : 128;
-        it.half = true;
-    }
-    return it;
-}
-
-// A tile's K-steps.  stores16: the previous item of this workgroup was a full tile, i.e. behind the pieces of this tile's first step there
-// are exactly that tile's 16 stores per wave (memory operations retire in issue order) -- the first wait leaves them in flight.
-// (The body is written out here rather than in a helper: the same statements behind a function boundary compile to a 220-register
-// schedule that runs the persistent kernel 10 % slower -- check .vgpr_count = 170 and the step A/B after touching this.)
-template <bool BF16, int NI>
-__device__ __forceinline__ void gemm_steps(f4v (&acc)[8][4], int nk, int par, bool active, char* lds, int a_rd, int b_rd, __amdgpu_buffer_rsrc_t ra,
-                                           __amdgpu_buffer_rsrc_t rb, bool has_next, __amdgpu_buffer_rsrc_t ra_n, __amdgpu_buffer_rsrc_t rb_n,
-                                           int voff_a, int voff_b, int rowstep_a, int rowstep_b, int w, bool stores16, uint32_t L_flags,
-                                           char* abl_c = nullptr, int64_t abl_ldc2 = 0, int abl_row0 = 0, int abl_rows = 0) {
-    for (int t = 0; t < nk; ++t) {
-        if (AUM_GEMM_PRIO == 2) { if ((t + (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-        if (t == 0 && stores16 && !(L_flags & (AUM_GEMM_NO_COUNTED_WAIT | AUM_GEMM_NO_PREFETCH))) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if ((AUM_GEMM_ABL & 2) && t >= 1 && t <= NI) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // the previous step's two stores stay in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (AUM_GEMM_ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's ds_write of the step's pieces
-        __builtin_amdgcn_s_barrier();
-        char* nxt = lds + ((par + t + 1) & 1) * STAGE_BYTES;
-        u4v rg_a[4], rg_b[4];                        // AUM_GEMM_ABL & 16: the next step's pieces through registers (buffer_load -> ds_write_b128) instead of LDS-DMA
-        if (AUM_GEMM_ABL & 16) {
-            const bool nx = t + 1 < nk;
-            const __amdgpu_buffer_rsrc_t qa = nx ? ra : ra_n, qb = nx ? rb : rb_n;
-            const int kb = nx ? (t + 1) * (BK * 2) : 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                rg_a[j] = __builtin_amdgcn_raw_buffer_load_b128(qa, voff_a, kb + j * rowstep_a, 0);
-                rg_b[j] = __builtin_amdgcn_raw_buffer_load_b128(qb, voff_b, kb + j * rowstep_b, 0);
-            }
-        } else if (AUM_GEMM_ABL & 4) {
-        } else if (t + 1 < nk) stage(ra, rb, voff_a, voff_b, (t + 1) * (BK * 2), rowstep_a, rowstep_b, nxt, w);
-        else if (has_next && !(L_flags & AUM_GEMM_NO_PREFETCH)) stage(ra_n, rb_n, voff_a, voff_b, 0, rowstep_a, rowstep_b, nxt, w);
-        const char* st = lds + ((par + t) & 1) * STAGE_BYTES;
-        if ((AUM_GEMM_ABL & 2) && t < NI) {           // the paced-store pattern with whatever two registers hold: row block t of the tile, both halves
-            const int row = abl_row0 + t * 16;
-            if (row < abl_rows) {
-                u4v* dst = reinterpret_cast<u4v*>(abl_c + (int64_t)row * abl_ldc2);
-                dst[0] = __builtin_bit_cast(u4v, acc[0][0]);
-                dst[4] = __builtin_bit_cast(u4v, acc[0][1]);
-            }
-        }
-        if (active && !(AUM_GEMM_ABL & 8)) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                s8v bf[4], af[NI];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bf[j] = lds_frag(st, (b_rd ^ (kk * 64)) + b_joff(j));
-#pragma unroll
-                for (int i = 0; i < NI; ++i) af[i] = lds_frag(st, (a_rd ^ (kk * 64)) + i * 2048);
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(bf[j], af[i], acc[i][j]);
-            }
-        }
-        if (AUM_GEMM_ABL & 16) {
-            const int lane = (int)(threadIdx.x & 63u);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *reinterpret_cast<u4v*>(nxt + (j * 8 + w) * 1024 + lane * 16) = rg_a[j];
-                *reinterpret_cast<u4v*>(nxt + TILE_BYTES + (j * 8 + w) * 1024 + lane * 16) = rg_b[j];
-            }
-        }
-    }
-}
-template <bool BF16, int NI>
-__device__ __forceinline__ void gemm_store(const f4v (&acc)[8][4], char* c_rows, int64_t ldc2, int row0, int rows) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int row = row0 + i * 16;
-        if (row < rows) {
-            u4v lo, hi;
-            lo.x = pack2<BF16>(acc[i][0][0], acc[i][0][1]);
-            lo.y = pack2<BF16>(acc[i][0][2], acc[i][0][3]);
-            lo.z = pack2<BF16>(acc[i][1][0], acc[i][1][1]);
-            lo.w = pack2<BF16>(acc[i][1][2], acc[i][1][3]);
-            hi.x = pack2<BF16>(acc[i][2][0], acc[i][2][1]);
-            hi.y = pack2<BF16>(acc[i][2][2], acc[i][2][3]);
-            hi.z = pack2<BF16>(acc[i][3][0], acc[i][3][1]);
-            hi.w = pack2<BF16>(acc[i][3][2], acc[i][3][3]);
-            u4v* dst = reinterpret_cast<u4v*>(c_rows + (int64_t)row * ldc2);
-            dst[0] = lo;
-            dst[4] = hi;
-        }
-    }
-}
-
-template <bool BF16>
-__global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_persistent(GemmLaunch L) {
-    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
-    const AumGemmArgs& g = L.g;
-    const int lane = (int)(threadIdx.x & 63u);
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int wr = w >> 2, wc = w & 3;
-    if (AUM_GEMM_PRIO == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
-    const int ntn = g.n / BN, grid = (int)gridDim.x, nk = g.k / BK;
-
-    const int srow = w * 8 + (lane >> 3);
-    const int f_a = ((w & 1) * 4 + (lane >> 4)) & 7;
-    const int f_b = ((w & 3) << 1) | ((lane >> 4) & 1);
-    const int voff_a = srow * g.lda * 2 + (((lane & 7) ^ f_a) << 4);
-    const int voff_b = srow * g.ldb * 2 + (((lane & 7) ^ f_b) << 4);
-    const int rowstep_a = 64 * g.lda * 2, rowstep_b = 64 * g.ldb * 2;
-    const int rho = lane & 15, kg = lane >> 4;
-    const int a_swz = (kg ^ ((lane >> 1) & 7)) << 4;
-    const int b_row = wc * 64 + (rho >> 2) * 8 + (rho & 3);
-    const int b_rd = TILE_BYTES + b_row * 128 + ((kg ^ ((((rho >> 2) & 3) << 1) | ((rho >> 1) & 1))) << 4);
-
-    auto rsrc_a = [&](const GemmItem& it) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(g.a) + (int64_t)it.m0 * g.lda * 2), 0,
-                                                 it.rows * g.lda * 2, 0x00020000);
-    };
-    auto rsrc_b = [&](const GemmItem& it) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(g.b) + (int64_t)it.n0 * g.ldb * 2), 0,
-                                                 BN * g.ldb * 2, 0x00020000);
-    };
-
-    int id = (int)blockIdx.x;
-    if (id >= L.nitems) return;
-    GemmItem it = gemm_item(L, id, ntn, grid);
-    __amdgpu_buffer_rsrc_t ra = rsrc_a(it), rb = rsrc_b(it);
-    int par = 0;
-    bool stores16 = false;          // the previous item of this workgroup was a full tile
-    stage(ra, rb, voff_a, voff_b, 0, rowstep_a, rowstep_b, lds, w);
-    while (true) {
-        const int nid = id + grid;
-        const bool has_next = nid < L.nitems;
-        GemmItem itn = it;
-        if (has_next) itn = gemm_item(L, nid, ntn, grid);
-        const __amdgpu_buffer_rsrc_t ra_n = rsrc_a(itn), rb_n = rsrc_b(itn);
-
-        f4v acc[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
-        const int row_base = it.half ? wr * 64 : wr * 128;                // this wave's first row of the tile
-        const int a_rd = (row_base + rho) * 128 + a_swz;
-        char* c_rows = static_cast<char*>(g.c) + ((int64_t)it.m0 * g.ldc + it.n0 + wc * 64 + kg * 8) * 2;
-        if (!it.half) {
-            gemm_steps<BF16, 8>(acc, nk, par, true, lds, a_rd, b_rd, ra, rb, has_next, ra_n, rb_n, voff_a, voff_b, rowstep_a, rowstep_b, w,
-                                (AUM_GEMM_ABL & 1) ? false : stores16, g.flags, c_rows, (int64_t)g.ldc * 2, row_base + rho, it.rows);
-            if (!(AUM_GEMM_ABL & 1)) gemm_store<BF16, 8>(acc, c_rows, (int64_t)g.ldc * 2, row_base + rho, it.rows);
-            else {          // the accumulators stay live (no code): without a consumer the compiler deletes the MFMAs and their reads
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-            }
-        } else {
-            gemm_steps<BF16, 4>(acc, nk, par, row_base < it.rows, lds, a_rd, b_rd, ra, rb, has_next, ra_n, rb_n, voff_a, voff_b, rowstep_a,
-                                rowstep_b, w, stores16, g.flags);
-            gemm_store<BF16, 4>(acc, c_rows, (int64_t)g.ldc * 2, row_base + rho, it.rows);
-        }
-        if (!has_next) break;
-        stores16 = !it.half && it.rows == BM;         // every wave of a complete full tile issued its 16 stores
-        id = nid;
-        it = itn;
-        ra = ra_n;
-        rb = rb_n;
-        par = (par + nk) & 1;
-        if (g.flags & AUM_GEMM_NO_PREFETCH) stage(ra, rb, voff_a, voff_b, 0, rowstep_a, rowstep_b, lds + par * STAGE_BYTES, w);      // A/B: fetch at the tile's head
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------------------------------------------
-// Split tail (round 4; aum_gemm_tn_sk).  N = 768 at 64 x 513 tokens is 387 tiles on 256 CUs: a second round in which half of the CUs idle
-// (75 % of the chip over the launch), and the reason the two N = 768 GEMMs stayed with the library.  Here the complete rounds run as whole
-// tiles (one workgroup per CU, tile = blockIdx + round * grid) and the remaining `tail` tiles are split ALONG K between the workgroups:
-// the tail's K-steps (tail tiles x K / 64) are dealt out in equal contiguous ranges -- XCD x takes tiles [x T / 8, (x + 1) T / 8), its 32
-// workgroups equal shares of their K-steps -- so a workgroup computes the end of one tile and the beginning of the next.  The workgroup that
-// holds a tile's FIRST K-step finishes the tile: every workgroup walks its range upwards, so that part is the last thing it computes, while
-// the other contributors (one or two: ranges are at least a third of a tile) computed theirs first, wrote fp32 partial tiles to the workspace
-// (write-through stores: visible to every XCD) and raised a flag.  The finisher adds the partials to its accumulators and stores the tile.
-// Flags carry the launch's epoch (the host counts launches per workspace): nothing is cleared between launches.  No workgroup waits for
-// one that waits (contributors never wait), every workgroup is resident (grid <= CUs, one per CU), the wait is bounded all the same.
-// MEASURED (profiles/r04_gemm_split_tail.txt), parity-green and NOT faster: N = 768, K = 1536 / 3072: 113 / 187 us against 87 / 160 us for
-// whole tiles.  Ablations: the complete round alone 50 / 104 us; + the finishers' half tiles and their stores 88 / 152 us; + the hand-over
-// 113 / 187 us -- writing 256 KB per contributor, the flag, and reading it back is a serial chain of ~25 us behind half a tile's MFMAs, more
-// than the idle half round it replaces.  Kept as an opt-in entry point (aum_gemm_tn_sk) with its tests; the default stays whole tiles.
-// ------------------------------------------------------------------------------------------------------------------------------------
-constexpr int SK_SLOTS = 2;
-#ifndef AUM_SK_ABL
-#define AUM_SK_ABL 0        // timing experiments only (wrong results): 1 no partial exchange, 2 no tail at all, 3 no stores of finished tail tiles either
-#endif
-#ifndef AUM_SK_AUX
-#define AUM_SK_AUX 16       // cache policy of the partial-tile exchange: 16 = sc1 (agent scope: through the L2 to the memory side), 17 = system scope, 0 = plain
-#endif
-struct GemmSkLaunch {
-    AumGemmArgs g;
-    float* part;           // [tail][SK_SLOTS][BM * BN] fp32
-    uint32_t* flags;       // [tail][SK_SLOTS]
-    uint32_t* err;         // set to 1 when a wait ran out (the result is then incomplete)
-    uint32_t epoch;
-    int rounds;            // complete rounds of whole tiles: tiles [0, rounds * grid)
-    int tail;              // tiles after them
-};
-
-template <bool BF16>
-__global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_sk(GemmSkLaunch L) {
-    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
-    const AumGemmArgs& g = L.g;
-    const int lane = (int)(threadIdx.x & 63u);
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int wr = w >> 2, wc = w & 3;
-    const int ntn = g.n / BN, grid = (int)gridDim.x, nk = g.k / BK;
-    const int srow = w * 8 + (lane >> 3);
-    const int f_a = ((w & 1) * 4 + (lane >> 4)) & 7;
-    const int f_b = ((w & 3) << 1) | ((lane >> 4) & 1);
-    const int voff_a = srow * g.lda * 2 + (((lane & 7) ^ f_a) << 4);
-    const int voff_b = srow * g.ldb * 2 + (((lane & 7) ^ f_b) << 4);
-    const int rowstep_a = 64 * g.lda * 2, rowstep_b = 64 * g.ldb * 2;
-    const int rho = lane & 15, kg = lane >> 4;
-    const int a_rd = (wr * 128 + rho) * 128 + ((kg ^ ((lane >> 1) & 7)) << 4);
-    const int b_row = wc * 64 + (rho >> 2) * 8 + (rho & 3);
-    const int b_rd = TILE_BYTES + b_row * 128 + ((kg ^ ((((rho >> 2) & 3) << 1) | ((rho >> 1) & 1))) << 4);
-    int par = 0;
-
-    f4v acc[8][4];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
-    };
-    // K-steps [k0, k1) of tile `tile` into acc
-    auto run = [&](int tile, int k0, int k1) {
-        const int tm = tile / ntn, m0 = tm * BM, n0 = (tile - tm * ntn) * BN;
-        const int rows = g.m - m0 < BM ? g.m - m0 : BM;
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(g.a) + (int64_t)m0 * g.lda * 2), 0,
-                                                                            rows * g.lda * 2, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(g.b) + (int64_t)n0 * g.ldb * 2), 0,
-                                                                            BN * g.ldb * 2, 0x00020000);
-        // (the buffer written here was last read two steps ago: every wave has passed the barrier of the step in between)
-        stage(ra, rb, voff_a, voff_b, k0 * (BK * 2), rowstep_a, rowstep_b, lds + (par & 1) * STAGE_BYTES, w);
-        for (int t = k0; t < k1; ++t) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t + 1 < k1) stage(ra, rb, voff_a, voff_b, (t + 1) * (BK * 2), rowstep_a, rowstep_b, lds + ((par + 1) & 1) * STAGE_BYTES, w);
-            const char* st = lds + (par & 1) * STAGE_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                s8v bf[4], af[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bf[j] = lds_frag(st, (b_rd ^ (kk * 64)) + b_joff(j));
-#pragma unroll
-                for (int i = 0; i < 8; ++i) af[i] = lds_frag(st, (a_rd ^ (kk * 64)) + i * 2048);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(bf[j], af[i], acc[i][j]);
-            }
-            par ^= 1;
-        }
-    };
-    auto store_tile = [&](int tile) {
-        const int tm = tile / ntn, m0 = tm * BM, n0 = (tile - tm * ntn) * BN;
-        const int rows = g.m - m0 < BM ? g.m - m0 : BM;
-        char* c_rows = static_cast<char*>(g.c) + ((int64_t)m0 * g.ldc + n0 + wc * 64 + kg * 8) * 2;
-        gemm_store<BF16, 8>(acc, c_rows, (int64_t)g.ldc * 2, wr * 128 + rho, rows);
-    };
-    // this lane's piece of an fp32 partial tile: row wr * 128 + 16 i + rho, columns wc * 64 + 32 (j >> 1) + 8 kg + 4 (j & 1) .. + 3
-    const int p_lane = ((wr * 128 + rho) * BN + wc * 64 + kg * 8) * 4;
-    auto part_rsrc = [&](int tt, int slot) {
-        return __builtin_amdgcn_make_buffer_rsrc(L.part + ((int64_t)tt * SK_SLOTS + slot) * (BM * BN), 0, BM * BN * 4, 0x00020000);
-    };
-
-    // ---- complete rounds: whole tiles; the 32 workgroups of an XCD take 32 consecutive tiles of a round (A rows shared in its L2) ----
-    for (int r = 0; r < L.rounds; ++r) {
-        const int tile = r * grid + ((int)blockIdx.x & 7) * (grid >> 3) + ((int)blockIdx.x >> 3);
-        zero_acc();
-        run(tile, 0, nk);
-        store_tile(tile);
-    }
-    if (L.tail <= 0 || AUM_SK_ABL == 2) return;
-    // ---- the tail, split along K ------------------------------------------------------------------------------------------------
-    const int x = (int)blockIdx.x & 7, c = (int)blockIdx.x >> 3, cpx = grid >> 3;
-    const int tx0 = x * L.tail / 8, tx1 = (x + 1) * L.tail / 8;
-    const int S = (tx1 - tx0) * nk;                     // K-steps of this XCD's tail tiles
-    const int q = (S + cpx - 1) / cpx;                  // per workgroup
-    int pos = c * q;
-    const int end = pos + q < S ? pos + q : S;
-    const int tile0 = L.rounds * grid;
-    while (pos < end) {
-        const int tl = pos / nk, k0 = pos - tl * nk;
-        const int k1 = k0 + (end - pos) < nk ? k0 + (end - pos) : nk;
-        const int tt = tx0 + tl, tile = tile0 + tt;
-        zero_acc();
-        run(tile, k0, k1);
-        if (k0 == 0) {
-            // finisher: the other contributors are the workgroups c + 1 .. c_last of this XCD
-            const int c_last = ((tl + 1) * nk - 1) / q;
-            const int ncontrib = c_last - c < SK_SLOTS ? c_last - c : SK_SLOTS;
-            for (int sl = 0; sl < (AUM_SK_ABL ? 0 : ncontrib); ++sl) {
-                if (threadIdx.x == 0) {
-                    const uint32_t* f = L.flags + (int64_t)tt * SK_SLOTS + sl;
-                    int it = 0;
-                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != L.epoch) {
-                        __builtin_amdgcn_s_sleep(8);
-                        if (++it > (1 << 22)) {          // seconds: something is wrong -- report it instead of hanging the queue
-                            __hip_atomic_store(L.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
-                }
-                __builtin_amdgcn_s_barrier();
-                const __amdgpu_buffer_rsrc_t rp = part_rsrc(tt, sl);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const u4v v = __builtin_amdgcn_raw_buffer_load_b128(rp, p_lane + (i * 16 * BN + (j >> 1) * 32 + (j & 1) * 4) * 4, 0, AUM_SK_AUX);
-                        acc[i][j] = acc[i][j] + __builtin_bit_cast(f4v, v);
-                    }
-            }
-            if (AUM_SK_ABL != 3) store_tile(tile);
-        } else {
-            // contributor: slot = position among the workgroups behind the finisher
-            const int c_first = (tl * nk) / q;
-            const int sl = c - c_first - 1;
-            if (AUM_SK_ABL) {
-            } else if (sl >= 0 && sl < SK_SLOTS) {
-                const __amdgpu_buffer_rsrc_t rp = part_rsrc(tt, sl);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, acc[i][j]), rp, p_lane + (i * 16 * BN + (j >> 1) * 32 + (j & 1) * 4) * 4, 0, AUM_SK_AUX);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (threadIdx.x == 0) __hip_atomic_store(L.flags + (int64_t)tt * SK_SLOTS + sl, L.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (threadIdx.x == 0) {
-                __hip_atomic_store(L.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // more contributors than slots: the host's split rule was violated
-            }
-        }
-        pos += k1 - k0;
+        L->nwhole = L->nitems = rb_all * ntn;
+        L->fold = 0;
     }
 }
 
@@ -705,7 +299,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_wgrad(AumGemmWArgs g) {
     const int lane = (int)(threadIdx.x & 63u);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = w >> 2, wc = w & 3;
-    if (AUM_GEMM_PRIO == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
     const int ntn = g.n / 256, ntk = g.k / 256;
     // work item (split, tile) of this workgroup.  Every workgroup of a split streams the same token rows, so the items are numbered split-major
     // and each XCD (blockIdx % 8: its CUs share an L2) takes a contiguous run of them: its ~32 workgroups walk one or two token ranges in step and

@@ -55,21 +55,29 @@ template <bool BF16> __device__ __forceinline__ void ps_mfma0(f4v& c, const s8v&
 }
 template <int V> struct PsC { static constexpr int value = V; };
 
-// work item id -> tile: every item is a 256-row block (the last one may be ragged: its rows beyond M read as zero and are not stored) x
-// one 256-column tile; in a complete round of `grid` items XCD x (= workgroup % 8) takes grid / 8 consecutive tiles
+// work item id -> tile (GemmLaunch in gemm_kernels.h): a whole item is a 256-row block (the last one may be ragged: its rows beyond M read as
+// zero and are not stored) x one 256-column tile; a half item is 128 (the last one: 128 + fold) rows of a split tile, run as a ragged tile.
+// In a complete round of `grid` items XCD x (= workgroup % 8) takes grid / 8 consecutive items (both halves of a split tile on one XCD)
 // (the tile is handed back as plain integers: a struct captured by reference by the lambdas below is an alloca, the compiler moves it to
 // LDS, and every copy of it then waits for ALL outstanding DMA pieces -- vmcnt(0) at the head of the tile loop)
 __device__ __forceinline__ void ps_item(const GemmLaunch& L, int id, int ntn, int grid, int& m0, int& n0, int& rows) {
-    int tile = id;
+    int item = id;
     const int r0 = id / grid * grid;
     if ((grid & 7) == 0 && r0 + grid <= L.nitems) {
         const int q = id - r0;
-        tile = r0 + (q & 7) * (grid >> 3) + (q >> 3);
+        item = r0 + (q & 7) * (grid >> 3) + (q >> 3);
     }
+    const int h = item - L.nwhole;                      // >= 0: half h & 1 of tile nwhole + (h >> 1)
+    const int tile = h < 0 ? item : L.nwhole + (h >> 1);
     const int tm = tile / ntn;
     m0 = tm * BM;
     n0 = (tile - tm * ntn) * BN;
-    rows = L.g.m - m0 < BM ? L.g.m - m0 : BM;
+    int span = BM;
+    if (h >= 0) {
+        m0 += (h & 1) * (BM / 2);
+        span = BM / 2 + (((h & 1) && (tm + 1) * BM + L.fold == L.g.m) ? L.fold : 0);       // the fold rows: behind the last block's second half
+    }
+    rows = L.g.m - m0 < span ? L.g.m - m0 : span;
 }
 
 constexpr int PS_NST = 6;           // K-steps of a tile that carry the previous tile's stores (fragment rows 2 .. 7, two stores per wave each); rows 0, 1 leave

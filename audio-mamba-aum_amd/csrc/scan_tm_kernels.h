@@ -587,20 +587,8 @@ AUM_DEV void scant_seg_fwd(const AumScanTmFwdArgs& p, const ScanTSeg& sg, int wg
 // 1.4 ms kernel: one pass is shorter than a loaded HBM round trip and two waves per SIMD cannot hide the difference.
 // LDS tiles are planes of 8 rows x 128 bytes (lane l's 16 bytes of a load at l * 16), the order the direct loads write in.
 // ================================================================================================
-#ifndef AUM_SCANT_LSUM
-// 1 (opt-in builds, -DAUM_SCANT_LSUM=1 [-DAUM_LSUM_PUT_ASM=1]; round 5): 16-bit activations: the dB / dC channel sums of a pass through a
-// per-wave LDS tile (wave.h, lsum_*) instead of two transposing butterflies -- the butterflies are 58 half-rate DPP instructions of a
-// pass's 189 on the pipe that bounds the kernel, the LDS route costs the vector ALU 28 (4 rounds of 8 values: 3 packed adds + 1 add +
-// 3 DPP adds) and moves the transposition to ds_write_b32 / ds_write2st64_b32 + ds_read_b128 (154 vector-ALU instructions per pass
-// instead of 192, 263 instructions in all instead of 275).  The tile is the half of the entry-state strip that 16-bit checkpoints leave
-// unused (fp32 activations keep the butterflies: their checkpoints fill the strip).  Built, parity-green (emulator + 166 GPU tests of
-// the asm-put build) and measured: SLOWER -- same box, B = 64 bf16 Fo-Bi + softplus: butterflies 1.015 ms, LDS route 1.165 ms
-// (1.126 ms with the row pairs as one ds_write2st64_b32), bench 999 vs 958-962 clips/s; the ablation with no sums at all is 0.828 ms
-// (profiles/r05_ab_lsum.txt).  44 more LDS instructions per pass cost ~8 cycles of a wave's issue each and the in-order LDS queue puts
-// every fetch behind the row writes in front of it: with two waves per SIMD that is not hidden.  Default 0: the butterflies.
-#define AUM_SCANT_LSUM 0
-#endif
-#define AUM_SCANT_LSUM_ON (AUM_SCANT_LSUM != 0)
+// (Round 5 built the dB / dC channel sums of a pass through a per-wave LDS transposition tile, round 4 on the matrix pipe: both parity-green,
+// both measured slower than the transposing butterflies below -- profiles/r05_ab_lsum.txt, r04_ab_msum.txt, HISTORY.md.  Removed in round 6.)
 template <class T> AUM_HOSTDEV constexpr int scant_bwd_lds_wave_floats() {
     // u, delta, z, dout, ypre | du, ddelta, dz | B/C block | dB/dC block | u (odd blocks) | entry states [16][64] | A [16][64] | raw B, C pairs
     // (+ fp32 activations: the other direction's dB | dC row block of the second phase; 16-bit activations park it in the half of the
@@ -610,10 +598,9 @@ template <class T> AUM_HOSTDEV constexpr int scant_bwd_lds_wave_floats() {
 // Fo-Bi: the two directions of a channel group hand their dB | dC partial rows over like their du / ddelta partials -- the wave that runs a
 // time step in its SECOND phase adds the row block the other direction wrote there in its first -- so the reduce kernel sums one row per
 // channel group instead of two (round 5: 201 -> 101 MB read by k_scant_bwd_reduce).  Slots of a token's partial rows: [0, nparts / 2)
-// finished rows (second phase), [nparts / 2, nparts) first-phase partials.  Off in the -DAUM_SCANT_LSUM / -DAUM_SCANT_CK_F32 A/B builds
-// (they use the same LDS).
+// finished rows (second phase), [nparts / 2, nparts) first-phase partials.  Off in the -DAUM_SCANT_CK_F32 A/B build (it uses the same LDS).
 #ifndef AUM_SCANT_DBC_MERGE
-#if AUM_SCANT_LSUM_ON || defined(AUM_SCANT_CK_F32)
+#if defined(AUM_SCANT_CK_F32)
 #define AUM_SCANT_DBC_MERGE 0
 #else
 #define AUM_SCANT_DBC_MERGE 1       // -DAUM_SCANT_DBC_MERGE=0: both directions' rows go to the reduce kernel, as until round 4 (A/B builds)
@@ -631,15 +618,6 @@ struct ScanTBwdOut {
     unsigned long long* trace;      // -DAUM_SCANT_TRACE builds (tools/tm_trace.py): 16 x uint64 per wave behind the partials; else unused
 };
 
-#ifndef AUM_SCANT_MSUM
-// 1 (opt-in builds, -DAUM_SCANT_MSUM=1): the dB / dC channel sums of 16-bit activations on the matrix pipe (wave.h, wave_sum_mfma_*:
-// terms rounded to bf16, selector v_mfma_f32_16x16x32_bf16 + 16 masked DPP adds instead of two 32-instruction butterflies).  Built,
-// parity-green on the GPU (543 tests incl. the oracle check of the bench launch) and measured in round 4: 25 % fewer vector-ALU
-// instructions per pass, and NOT faster -- same box, B = 64: 1.04 / 1.13 ms against 1.05 / 1.10 ms (softplus outside / inside), bench
-// 962 vs 968 clips/s (profiles/r04_ab_msum.txt).  The kernel is bound by the issue time of its two waves per SIMD, and a matrix
-// instruction occupies the SIMD's issue for its 8 passes: four per pass cost what 32 DPP adds saved.  Default 0: the butterflies.
-#define AUM_SCANT_MSUM 0
-#endif
 #ifndef AUM_SCANT_TAIL2
 #define AUM_SCANT_TAIL2 1     // 0 (A/B builds): each butterfly complete where its terms exist, as in round 3
 #endif
@@ -715,33 +693,6 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
     const vi bc_slot = st_i * SCANT_BC_ROW + st_c * 2;
     const vi vo4 = ec * 4;
     const vi dbc_slot = (((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 4) & 1)) * SCANT_BC_ROW + ((lane >> 5) & 1);
-    // 16-bit activations: the 64-channel sums of the dB / dC products go through the matrix pipe (wave.h, wave_sum_mfma_*): lane l
-    // ends up with value 2 s + h = wave_sum_mfma_value_of_lane(l) -> step s = 2 bit4 + 4 bit5 + bit2, state 2 j + h with h = bit3
-    constexpr bool MSUM = AUM_SCANT_MSUM && sizeof(T) == 2 && !(AUM_SCANT_BABL & 1);
-    // the sums through LDS: lane l ends up with value l >> 3 of a round's eight = (step 4 r + (l >> 4), state 2 j + bit3(l))
-#ifdef AUM_SCANT_CK_F32
-    constexpr bool LSUM = false;
-#else
-    constexpr bool LSUM = AUM_SCANT_LSUM && sizeof(T) == 2 && !MSUM && !(AUM_SCANT_BABL & 1);
-#endif
-    float* t_x = t_ck + CKR * WAVE;            // 8 x 64 floats: rows CKR .. 2 CKR - 1 of the entry-state strip
-    static_assert(!LSUM || (CKR * WAVE + LSUM_TILE_FLOATS <= N * WAVE), "the transposition tile is the unused half of the entry-state strip");
-    const vi lsum_slot = (lane >> 4) * SCANT_BC_ROW + ((lane >> 3) & 1);
-    const unsigned lsum_addr = lsum_put_addr(t_x);
-    auto lsum_put2_step = [&](int s, const vf2& p) {       // s is an unrolled loop counter: the row pair is a compile-time offset
-        switch (s & 3) {
-            case 0: lsum_put2<0>(t_x, lsum_addr, p); break;
-            case 1: lsum_put2<2>(t_x, lsum_addr, p); break;
-            case 2: lsum_put2<4>(t_x, lsum_addr, p); break;
-            default: lsum_put2<6>(t_x, lsum_addr, p); break;
-        }
-    };
-    const vi dbc_slot_m = (((lane >> 4) & 1) * 2 + ((lane >> 5) & 1) * 4 + ((lane >> 2) & 1)) * SCANT_BC_ROW + ((lane >> 3) & 1);
-    const WaveSumSel wsel = wave_sum_mfma_sel();
-    WaveSumAcc wacc;
-    AUM_UNROLL
-    for (int i = 0; i < 8; ++i) wacc.d[i] = splat(0.f);
-
     // per-lane row of block `blk` in a global tensor: memory row st_r for blocks inside the phase (plus the scalar offset of the
     // block's lowest time step), the clamped row's time step for ragged ones
     struct Rows { vi rowt; int t_lo; vm valid; bool inside; };
@@ -977,24 +928,15 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             vf2 hj = mk2(vf16_get(hh, 2 * jr), vf16_get(hh, 2 * jr + 1)), dAj = mk2(vf16_get(dAacc, 2 * jr), vf16_get(dAacc, 2 * jr + 1));
             vf2 w[SCANT_CK], a[SCANT_CK];
             vf pc[16], pb[16];
-            vf2 pc2[SCANT_CK], pb2[SCANT_CK];
             // a = exp2(delta A2) of the eight steps: independent of the recurrences, used by both sweeps
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) a[s] = (AUM_SCANT_BABL & 2) ? bc_lo(P[s]) * A2j : vexp2_2(bc_lo(P[s]) * A2j);
             // forward sweep: steps 0 .. s_hi-1
-            LsumRaw rawA, rawB, rawC, rawD;        // LSUM: the four rounds of a pass (dC steps 0-3, 4-7; dB steps 4-7, 0-3)
-            // LSUM: the entry rows this pass reads (above) make room for the next block's HERE -- behind the sweep, as below, the request
-            // (a conditional LDS-DMA) would sit between the sweeps' LDS writes, the pass would be two basic blocks, and the packed-operand
-            // broadcasts of the second one are not folded (48 moves per pass).  Without LDS traffic in the sweep the compiler hoists it itself.
-            if constexpr (LSUM) {
-                if (cknext) request_entry(blk - 1, RPP * j, RPP * j + RPP);
-            }
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) {
                 if (!FULL) {
                     pc[2 * s] = pc[2 * s + 1] = splat(0.f);
                     pb[2 * s] = pb[2 * s + 1] = splat(0.f);
-                    pc2[s] = pb2[s] = spl2(splat(0.f));
                 }
                 vf2 pcs = spl2(splat(0.f));
                 if (FULL || s < s_hi) {
@@ -1002,37 +944,22 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                     x = vfma2(bc_hi(P[s]), mk2(qb[s][0], qb[s][1]), w[s]);
                     if (FULL || s >= s_lo) {
                         pcs = ((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1])) * x;
-                        if constexpr (MSUM) {
-                            pc2[s] = pcs;
-                        } else if constexpr (!LSUM) {
-                            pc[2 * s] = lo2(pcs);
-                            pc[2 * s + 1] = hi2(pcs);
-                        }
+                        pc[2 * s] = lo2(pcs);
+                        pc[2 * s + 1] = hi2(pcs);
                     }
-                }
-                if constexpr (LSUM) {
-                    lsum_put2_step(s, pcs);
-                    if (s == 3) rawA = lsum_fetch(t_x);
-                    if (s == 7) rawB = lsum_fetch(t_x);
                 }
             }
             // the entry rows this pass consumed make room for the next block's
-            if constexpr (!LSUM) {
-                if (cknext) request_entry(blk - 1, RPP * j, RPP * j + RPP);
-            }
+            if (cknext) request_entry(blk - 1, RPP * j, RPP * j + RPP);
             AUM_SCHED_FENCE();
             AUM_TMB_STAMP(3);
             vf dCsum = splat(0.f);
-            if constexpr (MSUM) wave_sum_mfma_add16(wacc, 0, wsel, pc2);
             vf hc[4], hb[4];
-            if constexpr (LSUM) lds_write(t_dbc, lsum_slot + 2 * j + N, lsum_total(rawA));
-            if constexpr (!MSUM && !LSUM) {
-                // the dC butterfly's 24 independent levels now (16 term registers -> 4); its serial tail runs after the reverse sweep,
-                // interleaved with the dB butterfly's (wave.h, wave_sum16_tail2)
-                if (AUM_SCANT_BABL & 1) hc[0] = pc[0] + pc[5];
-                else if (AUM_SCANT_TAIL2) wave_sum16_head(pc, hc);
-                else dCsum = wave_sum16(pc);
-            }
+            // the dC butterfly's 24 independent levels now (16 term registers -> 4); its serial tail runs after the reverse sweep,
+            // interleaved with the dB butterfly's (wave.h, wave_sum16_tail2)
+            if (AUM_SCANT_BABL & 1) hc[0] = pc[0] + pc[5];
+            else if (AUM_SCANT_TAIL2) wave_sum16_head(pc, hc);
+            else dCsum = wave_sum16(pc);
             AUM_SCHED_FENCE();
             AUM_TMB_STAMP(4);
             // reverse sweep: steps s_hi-1 .. s_lo
@@ -1042,74 +969,38 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                 if (FULL || (s >= s_lo && s < s_hi)) {
                     const vf2 g = vfma2((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1]), mk2(qc[s][0], qc[s][1]), hj);
                     pbs = g * bc_hi(P[s]);
-                    if constexpr (MSUM) {
-                        pb2[s] = pbs;
-                    } else if constexpr (!LSUM) {
-                        pb[2 * s] = lo2(pbs);
-                        pb[2 * s + 1] = hi2(pbs);
-                    }
+                    pb[2 * s] = lo2(pbs);
+                    pb[2 * s + 1] = hi2(pbs);
                     S1[s] = vfma2(g, mk2(qb[s][0], qb[s][1]), S1[s]);
                     const vf2 r = g * w[s];
                     S2[s] = vfma2(A2j, r, S2[s]);
                     dAj = vfma2(bc_lo(P[s]), r, dAj);
                     hj = a[s] * g;
                 }
-                if constexpr (LSUM) {
-                    lsum_put2_step(s, pbs);
-                    if (s == 4) {       // dB of steps 4-7 is on its way; dC of steps 4-7 (fetched at the end of the forward sweep) has arrived
-                        rawC = lsum_fetch(t_x);
-                        lds_write(t_dbc, lsum_slot + 4 * SCANT_BC_ROW + 2 * j + N, lsum_total(rawB));
-                    }
-                    if (s == 0) rawD = lsum_fetch(t_x);
-                }
             }
             AUM_SCHED_FENCE();
             AUM_TMB_STAMP(5);
-            if constexpr (MSUM) {
-                // dC of this pass (tile 0: its matrix instructions were issued before the reverse sweep) and dB of the PREVIOUS pass (tile 1,
-                // issued at the end of that pass) leave together -- the two tiles' DPP levels interleave -- then this pass's dB terms go into
-                // tile 1: four accumulator registers cross the pass boundary instead of eight.  Pass 0 finishes the previous block's stale
-                // tile 1 into pass 7's dB slots, which this block's own last lines overwrite: no branch in the pass.
-                AUM_SCHED_FENCE();
-                vf sC, sB;
-                wave_sum_mfma_finish(wacc, false, sC, sB);
-                lds_write(t_dbc, dbc_slot_m + 2 * j + N, sC);
-                lds_write(t_dbc, dbc_slot_m + 2 * ((j + N / 2 - 1) & (N / 2 - 1)), sB);
-                AUM_SCHED_FENCE();
-                wave_sum_mfma_add16(wacc, 1, wsel, pb2);
+            vf dBsum;
+            if (AUM_SCANT_BABL & 1) {
+                dBsum = pb[0] + pb[7];
+                dCsum = hc[0];
+            } else if (AUM_SCANT_TAIL2) {
+                wave_sum16_head(pb, hb);
+                wave_sum16_tail2(hc, hb, dCsum, dBsum);
+            } else {
+                dBsum = wave_sum16(pb);
             }
-            if constexpr (LSUM) {
-                lds_write(t_dbc, lsum_slot + 4 * SCANT_BC_ROW + 2 * j, lsum_total(rawC));
-                lds_write(t_dbc, lsum_slot + 2 * j, lsum_total(rawD));
-            }
-            if constexpr (!MSUM && !LSUM) {
-                vf dBsum;
-                if (AUM_SCANT_BABL & 1) {
-                    dBsum = pb[0] + pb[7];
-                    dCsum = hc[0];
-                } else if (AUM_SCANT_TAIL2) {
-                    wave_sum16_head(pb, hb);
-                    wave_sum16_tail2(hc, hb, dCsum, dBsum);
-                } else {
-                    dBsum = wave_sum16(pb);
-                }
-                // lane l holds the totals of value k = wave_sum16_value_of_lane(l) = (step k >> 1, state 2j + (k & 1)).  The four lanes of a
-                // quad hold the same total and all write it to the same slot: a lane mask here is a branch, and everything the scheduler
-                // sinks below it loses its packed-operand broadcasts (they are folded per basic block)
-                const vi slot = dbc_slot + 2 * j;
-                lds_write(t_dbc, slot, dBsum);
-                lds_write(t_dbc, slot + N, dCsum);
-            }
+            // lane l holds the totals of value k = wave_sum16_value_of_lane(l) = (step k >> 1, state 2j + (k & 1)).  The four lanes of a
+            // quad hold the same total and all write it to the same slot: a lane mask here is a branch, and everything the scheduler
+            // sinks below it loses its packed-operand broadcasts (they are folded per basic block)
+            const vi slot = dbc_slot + 2 * j;
+            lds_write(t_dbc, slot, dBsum);
+            lds_write(t_dbc, slot + N, dCsum);
             vf16_set(hh, 2 * jr, lo2(hj));
             vf16_set(hh, 2 * jr + 1, hi2(hj));
             vf16_set(dAacc, 2 * jr, lo2(dAj));
             vf16_set(dAacc, 2 * jr + 1, hi2(dAj));
             AUM_TMB_STAMP(6);
-        }
-        if constexpr (MSUM) {      // the last pass's dB tile (its matrix instructions may still be in flight: `fresh`; tile 0 is spent)
-            vf sC, sB;
-            wave_sum_mfma_finish(wacc, true, sC, sB);
-            lds_write(t_dbc, dbc_slot_m + 2 * (N / 2 - 1), sB);
         }
         // ---- the block's du, ddelta; partials / finish ----------------------------------------------------------
         // this block's partial du / ddelta are back (younger: the CKR entry rows requested during the passes)

@@ -39,8 +39,8 @@ constexpr uint32_t AUM_DBG_SKIP_STATES = 0, AUM_DBG_SKIP_LDS_ATOMICS = 0, AUM_DB
                    AUM_DBG_NO_STEP_BARRIER = 0;
 #endif
 // kernel selection for tests and A/B runs (host-side dispatch, not in any loop): 64-row workgroups in the chunked one-row backward
-// whatever the grid; the checkpointed L = 513 backward of scan_state_kernels.h instead of scan_row_kernels.h; its phase time stamps
-constexpr uint32_t AUM_DBG_CHUNKED_MAX_ROWS = 1u << 21, AUM_DBG_STATE_BWD = 1u << 22, AUM_DBG_TRACE = 1u << 23;
+// whatever the grid
+constexpr uint32_t AUM_DBG_CHUNKED_MAX_ROWS = 1u << 21;
 
 template <int K, int TAIL> struct ScanGeo {
     static constexpr int KT = K + TAIL;                    // slots per lane

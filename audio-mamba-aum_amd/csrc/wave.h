@@ -1278,226 +1278,8 @@ AUM_DEV vf wave_sum32(vf (&v)[32]) {
 }
 #endif
 
-// ------------------------------------------------------------------------------------------------
-// Sums over the 64 lanes THROUGH LDS (round 5).  A transposing butterfly is two vector-ALU instructions per value, each a half-rate DPP
-// add (profiles/r04_valu_probe.txt: 2.3 SIMD-ns against 1.2 for a plain add), on the pipe that bounds the time-serial backward scan.
-// The same transposition through a per-wave LDS tile costs the vector ALU 7 instructions per EIGHT values:
-//   put     a lane parks value v of its own channel at float index v * 64 + lane (value-major: a ds_write_b32 whose 64 lanes are 256
-//           contiguous bytes -- conflict-free; two values 256 bytes apart leave as one ds_write2st64_b32);
-//   fetch   lane l takes value l >> 3, channels 8 (l & 7) .. + 7: the 32 contiguous bytes at l * 32, as two ds_read_b128.  A 16-byte read
-//           is served 16 lanes at a time over 64 banks; lanes i and i + 8 of a service group would meet in the same four banks, so lanes
-//           with bit 3 set read their halves in the opposite order (every service group then covers all 64 banks exactly once);
-//   total   3 packed adds + 1 add inside the lane, then three DPP adds inside the 8-lane group (quad_perm xor 1, xor 2,
-//           row_half_mirror): all 8 lanes of group v hold the 64-channel total of value v.
-// The LDS executes a wave's instructions in order, so a tile is reused as soon as its fetch has been ISSUED.  Tile: 8 x 64 floats.
-// ------------------------------------------------------------------------------------------------
-constexpr int LSUM_TILE_FLOATS = 8 * WAVE;
-struct LsumRaw { vf f[8]; };
-#ifdef AUM_EMU
-inline unsigned lsum_put_addr(float*) { return 0; }
-template <int V> inline void lsum_put2(float* tile, unsigned, const vf2& p) {
-    AUM_LANES { tile[V * WAVE + l] = p.x.v[l]; tile[(V + 1) * WAVE + l] = p.y.v[l]; }
-}
-inline LsumRaw lsum_fetch(const float* tile) {
-    LsumRaw r;
-    AUM_LANES {
-        const int first = ((l >> 3) & 1) * 4;
-        for (int k = 0; k < 4; ++k) {
-            r.f[k].v[l] = tile[l * 8 + first + k];
-            r.f[4 + k].v[l] = tile[l * 8 + (first ^ 4) + k];
-        }
-    }
-    return r;
-}
-inline vf lsum_total(const LsumRaw& r) {
-    const vf a0 = r.f[0] + r.f[2], a1 = r.f[1] + r.f[3], b0 = r.f[4] + r.f[6], b1 = r.f[5] + r.f[7];
-    const vf t = (a0 + b0) + (a1 + b1);
-    vf t1, t2, t3;
-    AUM_LANES t1.v[l] = t.v[l] + t.v[l ^ 1];
-    AUM_LANES t2.v[l] = t1.v[l] + t1.v[l ^ 2];
-    AUM_LANES t3.v[l] = t2.v[l] + t2.v[(l & ~7) | (7 - (l & 7))];
-    return t3;
-}
-#else
-#ifndef AUM_LSUM_PUT_ASM
-#define AUM_LSUM_PUT_ASM 0
-#endif
-// addr: the LDS byte address of this lane's float in row 0 of the tile (lsum_put_addr), used by the assembly form only
-AUM_DEV unsigned lsum_put_addr(float* tile) {
-#ifdef __HIP_DEVICE_COMPILE__
-    return (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)tile + (threadIdx.x & 63u));
-#else
-    return 0;
-#endif
-}
-template <int V> AUM_DEV void lsum_put2(float* tile, unsigned addr, vf2 p) {
-#ifdef __HIP_DEVICE_COMPILE__
-    if (AUM_LSUM_PUT_ASM) {
-        // one ds_write2st64_b32 (rows 256 bytes apart).  Written out: hipcc leaves the pair as two ds_write_b32 in this kernel (it merges
-        // the same pair in a small one).  The compiler does not count this in lgkmcnt: its own waits then cover at least what they name.
-        asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(p.x), "v"(p.y), "n"(V), "n"(V + 1) : "memory");
-    } else {
-        const int l = (int)(threadIdx.x & 63u);
-        tile[V * WAVE + l] = p.x;
-        tile[(V + 1) * WAVE + l] = p.y;
-    }
-#endif
-}
-template <int CTRL> AUM_DEV vf dpp_take(vf x) {      // every lane has a source lane under CTRL
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
-}
-AUM_DEV LsumRaw lsum_fetch(const float* tile) {
-    const int l = (int)(threadIdx.x & 63u);
-    const int first = l * 32 + ((l >> 3) & 1) * 16;
-    const aum_f4 a = *reinterpret_cast<const aum_f4*>(reinterpret_cast<const char*>(tile) + first);
-    const aum_f4 b = *reinterpret_cast<const aum_f4*>(reinterpret_cast<const char*>(tile) + (first ^ 16));
-    LsumRaw r;
-    r.f[0] = a.x; r.f[1] = a.y; r.f[2] = a.z; r.f[3] = a.w;
-    r.f[4] = b.x; r.f[5] = b.y; r.f[6] = b.z; r.f[7] = b.w;
-    return r;
-}
-AUM_DEV vf lsum_total(const LsumRaw& r) {
-    const vf2 a = mk2(r.f[0], r.f[1]) + mk2(r.f[2], r.f[3]), b = mk2(r.f[4], r.f[5]) + mk2(r.f[6], r.f[7]);
-    const vf2 c = a + b;
-    vf t = lo2(c) + hi2(c);
-    // (old = 0 with bound_ctrl: the form the compiler folds into ONE v_add_f32_dpp; with old = src it stays a move + DPP move + add)
-    t = t + dpp_take<0xB1>(t);         // quad_perm [1,0,3,2]
-    t = t + dpp_take<0x4E>(t);         // quad_perm [2,3,0,1]
-    t = t + dpp_take<0x141>(t);        // row_half_mirror: the other quad of the 8-lane group (its four lanes hold the same sum)
-    return t;
-}
-#endif
-
-// ------------------------------------------------------------------------------------------------
-// Sums over the 64 lanes on the MATRIX pipe (round 4).  The time-serial backward scan is bound by the vector ALU and a quarter of its
-// instructions were the two transposing butterflies of a pass (wave_sum16: 2 instructions per value + the serial tail through the
-// swaps); the matrix pipe of the SIMD idles.  v_mfma_f32_16x16x32_bf16 computes D[i][j] = sum_k A[i][k] B[k][j] with k = 8 g + e spread
-// over the four 16-lane groups g (lane = 16 g + j holds B[8 g + e][j], e = 0..7 as four packed registers): with a SELECTOR as A
-// (A[i][8 g + e] = 1 iff e == i mod 8, rows 0-7 from one instruction, rows 8-15 accumulated by a second one) sixteen per-lane values
-// -- rounded to bf16, summed in fp32 -- are summed over the four lane groups by two matrix instructions, and D (lane 16 g + j,
-// register r: row 4 g + r, column j) is left with sixteen 16-lane partial sums that four masked DPP levels finish:
-//   per 16 values   8 v_cvt_pk_bf16_f32 + 2 v_mfma + 8 v_add_f32_dpp     instead of   32 VALU + 8 hazard s_nop in a serial tail.
-// Rounding the PRODUCTS to bf16 before the 64-channel sum costs 2^-9 relative per term, uncorrelated over 3072 terms (48 channel
-// groups): far below the one rounding of the 16-bit tensor the total is stored in (dx_dbl); fp32 activations keep wave_sum16.
-// wave_sum_mfma_add16: tile t of the accumulator <- sums over lane groups of the 16 values p[q] = (value 2q, value 2q + 1);
-// wave_sum_mfma_finish: both tiles -> (sum of tile 0, sum of tile 1), lane l holding the total of value
-//   wave_sum_mfma_value_of_lane(l) = 4 (l >> 4) + bit3(l) + 2 bit2(l)   (the four lanes of a quad hold the same total).
-// The matrix instruction's result may not be read by inline assembly (invisible to the hazard recogniser) for 12 issue slots: callers
-// finish a tile a pass later, or pass `fresh` (two s_nop 7 first); and never by a DPP instruction directly (wave_sum_mfma_finish).
-// ------------------------------------------------------------------------------------------------
-constexpr int wave_sum_mfma_value_of_lane(int l) { return 4 * (l >> 4) + ((l >> 3) & 1) + 2 * ((l >> 2) & 1); }
-AUM_DEV uint32_t f32_round_bf16_bits(float f) {
-    uint32_t u = f32_to_bits(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-struct WaveSumAcc { vf d[8]; };          // two accumulator tiles of four registers
-#ifdef AUM_EMU
-struct WaveSumSel { int unused; };
-inline WaveSumSel wave_sum_mfma_sel() { return WaveSumSel{0}; }
-inline void wave_sum_mfma_add16(WaveSumAcc& acc, int tile, const WaveSumSel&, const vf2 (&p)[8]) {
-    // the matrix instruction pair, lane by lane: D[i][j] = sum over the four lane groups of bf16(value i) at column j
-    for (int r = 0; r < 4; ++r)
-        AUM_LANES {
-            const int g = l >> 4, j = l & 15, i = 4 * g + r;
-            const vf& src = (i & 1) ? p[i >> 1].y : p[i >> 1].x;
-            float acc_ = 0.f;
-            for (int gg = 0; gg < 4; ++gg) acc_ += bits_to_f32(f32_round_bf16_bits(src.v[16 * gg + j]) << 16);
-            acc.d[4 * tile + r].v[l] = acc_;
-        }
-}
-inline void wave_sum_mfma_finish(WaveSumAcc& acc, bool, vf& s0, vf& s1) {
-    for (int t = 0; t < 2; ++t) {
-        vf r;
-        AUM_LANES {
-            const int reg = ((l >> 3) & 1) + 2 * ((l >> 2) & 1);
-            float a = 0.f;
-            for (int j = 0; j < 16; ++j) a += acc.d[4 * t + reg].v[(l & ~15) | j];
-            r.v[l] = a;
-        }
-        (t ? s1 : s0) = r;
-    }
-}
-#else
-typedef float wsum_f4 __attribute__((ext_vector_type(4)));
-typedef __bf16 wsum_b2 __attribute__((ext_vector_type(2)));
-typedef __bf16 wsum_b8 __attribute__((ext_vector_type(8)));
-typedef unsigned wsum_u4 __attribute__((ext_vector_type(4)));
-// Selector operands.  Kept as ONE register (bf16 1.0 in the odd / even half by lane parity); the eight selector registers of a tile's
-// two matrix instructions are formed where they are used by v_cndmask_b32 against literal lane masks (rows 0-7 <- element i of every
-// lane group: lanes i = 2 q, 2 q + 1 of each 16-lane row for register q; rows 8-15: the same eight lanes up).  Eight persistent selector
-// registers cost the 256-register kernel spills; eight selects per tile are 2 % of a pass.
-struct WaveSumSel { unsigned one; };
-AUM_DEV WaveSumSel wave_sum_mfma_sel() {
-    WaveSumSel s;
-    s.one = (threadIdx.x & 1u) ? 0x3f800000u : 0x00003f80u;
-    asm volatile("" : "+v"(s.one));
-    return s;
-}
-template <unsigned long long MASK> AUM_DEV unsigned wsum_sel_reg(unsigned one) {
-    unsigned r;
-    asm volatile("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(one), "s"(MASK));
-    return r;
-}
-AUM_DEV void wave_sum_mfma_add16(WaveSumAcc& acc, int tile, const WaveSumSel& sel, const vf2 (&p)[8]) {
-    wsum_u4 b0, b1;
-    AUM_UNROLL
-    for (int q = 0; q < 4; ++q) {
-        b0[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(p[q], wsum_b2));          // v_cvt_pk_bf16_f32
-        b1[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(p[4 + q], wsum_b2));
-    }
-    constexpr unsigned long long M0 = 0x0003000300030003ull;
-    wsum_u4 lo, hi;
-    lo[0] = wsum_sel_reg<M0>(sel.one);
-    lo[1] = wsum_sel_reg<(M0 << 2)>(sel.one);
-    lo[2] = wsum_sel_reg<(M0 << 4)>(sel.one);
-    lo[3] = wsum_sel_reg<(M0 << 6)>(sel.one);
-    const wsum_f4 z = {0.f, 0.f, 0.f, 0.f};
-    wsum_f4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wsum_b8, lo), __builtin_bit_cast(wsum_b8, b0), z, 0, 0, 0);
-    hi[0] = wsum_sel_reg<(M0 << 8)>(sel.one);
-    hi[1] = wsum_sel_reg<(M0 << 10)>(sel.one);
-    hi[2] = wsum_sel_reg<(M0 << 12)>(sel.one);
-    hi[3] = wsum_sel_reg<(M0 << 14)>(sel.one);
-    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wsum_b8, hi), __builtin_bit_cast(wsum_b8, b1), d, 0, 0, 0);
-    acc.d[4 * tile + 0] = d[0];
-    acc.d[4 * tile + 1] = d[1];
-    acc.d[4 * tile + 2] = d[2];
-    acc.d[4 * tile + 3] = d[3];
-}
-AUM_DEV void wave_sum_mfma_finish(WaveSumAcc& acc, bool fresh, vf& s0, vf& s1) {
-    // `fresh`: the tiles may have been written by a matrix instruction within the last 12 issue slots
-    if (fresh) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-    // levels over lane bits 3 and 2 inside a 16-lane row (masked DPP adds: bank_mask write-enables the lanes whose bit selects the
-    // register), then plain sums over bits 1 and 0; every read of a register is at least three issue slots behind its writer (the
-    // architecture asks for two between a vector-ALU write and a DPP read): the two tiles are interleaved, s_nop where that is not enough
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %4, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(acc.d[0]), "+v"(acc.d[1]), "+v"(acc.d[2]), "+v"(acc.d[3]), "+v"(acc.d[4]), "+v"(acc.d[5]), "+v"(acc.d[6]), "+v"(acc.d[7]));
-    s0 = acc.d[0];
-    s1 = acc.d[4];
-}
-#endif
-
+// (Round 5's sums through an LDS transposition tile and round 4's sums on the matrix pipe -- lsum_*, wave_sum_mfma_* -- lived here: parity-green,
+// measured slower than the butterflies of wave_sum16 / wave_sum32, removed in round 6: HISTORY.md, profiles/r05_ab_lsum.txt, r04_ab_msum.txt.)
 // ------------------------------------------------------------------------------------------------
 // The associative scan of the selective-scan recurrence x' = a*x + b over the 64 lanes.
 // Each lane holds the composition (P, S) of its own K steps:  x_out = P * x_in + S.

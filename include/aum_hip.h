@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AUM_ABI_VERSION 11  /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
+#define AUM_ABI_VERSION 12  /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
                                3: x_lane (lane-entry state checkpoint of the L = 513 row kernels) appended after it;
                                4: aug / noise (per-clip augmentation in the log-mel kernel's epilogue) appended to AumFbankArgs;
                                5: aum_frontend_tokens_fwd (waveform -> token sequence in one launch);
@@ -37,8 +37,11 @@ extern "C" {
                                9: aum_gemm_tn (the dense in_proj / out_proj GEMMs on token-major activations); aum_dtproj_tm_fwd, aum_xdt_tm_fwd; aum_scan_tm_ckpt_rows
                                   (packed 16-bit state checkpoints of the token-major scan for 16-bit activations);
                                10: aum_gemm_wgrad (weight gradients of the projections), aum_scan_tm_seg_fwd / _bwd (time segments: long rows at a small
-                                  batch), aum_causal_conv1d_update / aum_selective_state_update (streaming inference), aum_scan_tm_bwd_matrix_sums;
-                               11: aum_sum_rows_multi (several partial sets summed in one launch) */
+                                  batch), aum_causal_conv1d_update / aum_selective_state_update (streaming inference);
+                               11: aum_sum_rows_multi (several partial sets summed in one launch);
+                               12: experiment switches and entry points removed from the boundary (AUM_GEMM_STAGGERED / _PERSISTENT / _NO_COUNTED_WAIT /
+                                   _NO_PREFETCH / _W4 / _RING, aum_gemm_tn_sk, aum_gemm_tn_sk_workspace_bytes, aum_scan_tm_bwd_matrix_sums); AUM_GEMM_PACED;
+                                   aum_sum_rows / aum_sum_rows_multi take any float address as destination */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 
@@ -66,16 +69,11 @@ enum {
 #define AUM_CONV_SILU 1u
 #define AUM_CONV_REVERSE 2u  /* anti-causal: y[l] = act(b + sum_w W[w] x[l+(W-1)-w])                            */
 #define AUM_CONV_GENERIC 4u  /* force the any-width kernel (default: the vectorised width-4 kernel when width == 4)  */
-/* aum_gemm_tn picks its kernel by tile count (persistent when a CU gets more than two tiles, else one workgroup per tile); these force one: */
-#define AUM_GEMM_LOCKSTEP 1u   /* one workgroup per 256 x 256 tile, all waves in lockstep */
-#define AUM_GEMM_STAGGERED 2u  /* debug / A-B: one workgroup per tile, the two waves of a SIMD half a K-step apart (measured slower) */
-#define AUM_GEMM_PERSISTENT 4u /* one workgroup per CU walking a tile list; a ragged last row block of <= 128 rows as half tiles */
-#define AUM_GEMM_NO_COUNTED_WAIT 8u /* debug / A-B (persistent): a tile's first wait also drains the previous tile's stores */
-#define AUM_GEMM_PIPELINED 32u      /* one workgroup per tile, fragment reads of the next half K-step under the current half's MFMAs (the default up to two tiles per CU) */
-#define AUM_GEMM_NO_PREFETCH 16u    /* debug / A-B (persistent): a tile's first K-step is fetched at its head, not under the previous tile's last step */
-#define AUM_GEMM_W4 64u             /* round 5: four waves of 128 x 96 (one per SIMD, accumulators in AGPRs), 256 x 192 tiles, persistent; needs n % 192 == 0, k >= 128 */
-#define AUM_GEMM_PACED 256u         /* round 6: the 8-wave 256 x 256 x 64 kernel as one stream of K-steps with a hand-placed schedule; a tile's stores leave under the next tile's first eight steps; k >= 576 */
-#define AUM_GEMM_RING 128u          /* round 5: the W4 division as one stream of 32-deep K-steps through a five-stage LDS ring (pieces requested five steps ahead); n % 192 == 0, k >= 256 */
+/* aum_gemm_tn picks its kernel by the length of the K loop (the paced-store kernel from k = 448 on, else one workgroup per tile); these name one: */
+#define AUM_GEMM_LOCKSTEP 1u        /* one workgroup per 256 x 256 tile, one barrier per K-step */
+#define AUM_GEMM_PIPELINED 32u      /* one workgroup per tile, fragment reads of the next half K-step under the current half's MFMAs */
+#define AUM_GEMM_PACED 256u         /* one workgroup per CU walking a tile list as one stream of K-steps (hand-placed schedule, AGPR accumulators); a tile's
+                                       stores leave under the next tile's first K-steps; k >= 448 (else AUM_E_UNSUPPORTED) */
 #define AUM_NORM_PRENORM 1u  /* also return residual_out                                                        */
 #define AUM_NORM_GENERIC 2u  /* force the any-cols kernel (default: register-cached vector kernel, cols <= 2048)  */
 
@@ -417,9 +415,6 @@ typedef struct AumConvTmArgs {
 int aum_conv1d_tm_fwd(const AumConvTmArgs* args, void* stream);
 int aum_conv1d_tm_bwd(const AumConvTmArgs* args, void* stream);
 int32_t aum_conv1d_tm_nparts(int32_t batch, int32_t len);
-/* 1 when the library was built with -DAUM_SCANT_MSUM=1 (aum_scan_tm_bwd sums the dB / dC terms of 16-bit activations on the matrix
- * pipe, every term rounded to bf16 first); 0 for the default build (fp32 butterflies).  Used by the parity tests to pick the bound. */
-int32_t aum_scan_tm_bwd_matrix_sums(void);
 
 /*
  * Dense projection GEMM on token-major activations (ABI 9): the in_proj / out_proj matrix products of the Mamba block and their
@@ -440,28 +435,6 @@ typedef struct AumGemmArgs {
     uint32_t flags;
 } AumGemmArgs;
 int aum_gemm_tn(const AumGemmArgs* args, void* stream);
-
-/*
- * aum_gemm_tn with a SPLIT TAIL (ABI 10): the same product for shapes whose tile count leaves a half-empty last round of workgroups
- * (n = 768 at 64 x 513 tokens: 387 tiles of 256 x 256 on 256 CUs).  Complete rounds run as whole tiles; the remaining tiles are split along
- * K between the workgroups, partial tiles are exchanged through `workspace` and summed by the workgroup that owns a tile's first K-step
- * (fp32; the order of the at most three partial sums of a tile is fixed by the split, so results are bitwise repeatable for a given
- * device).  workspace: aum_gemm_tn_sk_workspace_bytes(m, n) bytes, ZERO-FILLED once by the caller and then reused; epoch: a number the
- * caller increases with every launch that uses the workspace (never 0).  Launches sharing a workspace must be ordered (one stream).
- * aum_gemm_tn_sk_workspace_bytes returns 0 where the split does not apply (no tail, a tail under half a round, n / k outside aum_gemm_tn's
- * limits): callers use aum_gemm_tn there.  Error AUM_E_WORKSPACE: workspace too small or not 256-byte aligned.  Word 0 of the workspace
- * becomes nonzero if a workgroup's (bounded) wait for a partial tile ran out -- the result is then incomplete; it never happens when all
- * workgroups of the launch are resident, which the launch geometry guarantees on an otherwise idle device.
- */
-typedef struct AumGemmSkArgs {
-    AumGemmArgs base;
-    void* workspace;
-    int64_t workspace_bytes;
-    uint32_t epoch;
-    uint32_t reserved;
-} AumGemmSkArgs;
-int aum_gemm_tn_sk(const AumGemmSkArgs* args, void* stream);
-int64_t aum_gemm_tn_sk_workspace_bytes(int64_t m, int32_t n);
 
 /*
  * Weight-gradient GEMM of the in / out projections on token-major operands (ABI 10; autograd of mamba_simple.py:185-189 and

@@ -29,10 +29,6 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void*) {
     return AUM_OK;
 }
 
-// aum_gemm_tn_sk on host pointers: the same product (the split is a scheduling matter of the device kernel); the split rule itself is
-// device-dependent, so the host build reports "does not apply" and callers take aum_gemm_tn
-extern "C" int aum_gemm_tn_sk(const AumGemmSkArgs* p, void* s) { return p ? aum_gemm_tn(&p->base, s) : AUM_E_NULL; }
-extern "C" int64_t aum_gemm_tn_sk_workspace_bytes(int64_t, int32_t) { return 0; }
 
 // aum_gemm_wgrad on host pointers: same arrangement (shared argument rules and split boundaries, arithmetic as a plain loop).
 extern "C" int aum_gemm_wgrad(const AumGemmWArgs* p, void*) {

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(so_path):
     lib = ctypes.CDLL(so_path)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.aum_abi_version() == aum_hip.ABI_VERSION == 11
+    assert lib.aum_abi_version() == aum_hip.ABI_VERSION == 12
     assert lib.aum_scan_max_single_pass_len() == 576
     assert lib.aum_rmsnorm_bwd_partials(32832) == 4096
 
@@ -62,7 +62,6 @@ def test_struct_layouts_match_header(tmp_path):
         "AumXdtBwdArgs": (aum_hip.XdtBwdArgs, ["ddelta", "dbc", "wdt_t", "wx_t", "du", "dx_dbl", "ntok", "dim", "rank", "ncols", "ldd", "lddbc", "ldwdt", "ldwx",
                                                "ldu", "ldx", "dtype"]),
         "AumGemmArgs": (aum_hip.GemmArgs, ["a", "b", "c", "m", "n", "k", "lda", "ldb", "ldc", "dtype", "flags"]),
-        "AumGemmSkArgs": (aum_hip.GemmSkArgs, ["base", "workspace", "workspace_bytes", "epoch"]),
         "AumGemmWArgs": (aum_hip.GemmWArgs, ["y", "x", "part", "t", "ldy", "ldx", "n", "k", "splits", "dtype"]),
         "AumSumJob": (aum_hip.SumJob, ["src", "dst", "outer", "inner", "tr_cols", "reserved"]),
         "AumScanTmSegFwdArgs": (aum_hip.ScanTmSegFwdArgs, ["base", "carry", "carry_bytes", "segments"]),

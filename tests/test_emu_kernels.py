@@ -58,16 +58,6 @@ def test_scan_row_kernels_lane_checkpoint(emu, case, mode):
     KC.check_scan(emu, "cpu", case, torch.float16, tol=2e-3, **kw)
 
 
-@pytest.mark.parametrize("case", [c for c in cases.SCAN_CASES if c[0] == "l513"] + cases.SCAN_ROW_CASES, ids=lambda c: c[0])
-@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
-def test_scan_state_kernel_backward(emu, case, mode, monkeypatch):
-    """scan_state_kernels.h (opt-in): waves own states, the workgroup's rows stream past them in a three-stage pipeline"""
-    monkeypatch.setattr(aum_hip.debug, "ablate", 64)
-    kw = dict(reverse=(mode == "rev"), bidir=(mode == "bidir"), lane_ckpt=True)
-    KC.check_scan(emu, "cpu", case, torch.float32, **kw)
-    KC.check_scan(emu, "cpu", case, torch.bfloat16, strided=True, **kw)
-
-
 def test_scan_lane_checkpoint_contract(emu):
     """x_lane exists only for rows the row kernels take; handing one to any other call is refused, not ignored"""
     assert aum_hip.scan_lane_ckpt(torch.zeros(2, 4, 65), 16, False, lib=emu) is None
@@ -330,15 +320,3 @@ def test_gemm_wgrad_contract(emu, case):
 def test_decode_kernels_contract(emu, dtype):
     """the host twins of the per-token kernels (tests/emu/aum_emu.cpp) against the reference's step arithmetic in fp64"""
     KC.check_decode_kernels(emu, "cpu", dtype)
-
-
-@pytest.mark.skipif(os.environ.get("AUM_TEST_VARIANTS") != "1", reason="opt-in build variant (a second 5-minute lane-array build): AUM_TEST_VARIANTS=1")
-@pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
-def test_scan_tm_backward_lds_channel_sums_variant(mode):
-    """-DAUM_SCANT_LSUM=1 (round 5, measured slower and not the default: profiles/r05_ab_lsum.txt): the dB / dC channel sums of the
-    time-serial backward through the per-wave LDS transposition tile (wave.h lsum_*) -- same oracle bars as the butterflies"""
-    import build_emu
-    lib = aum_hip.Lib(build_emu.build(("-DAUM_SCANT_LSUM=1",), "_lsum1"), host=True)
-    for case in cases.SCAN_TM_CASES[:4]:
-        for dt in (torch.bfloat16, torch.float16):
-            KC.check_scan_tm(lib, "cpu", case, dt, reverse=(mode == "rev"), bidir=(mode == "bidir"), xz_layout=True, backward=True)

@@ -1,4 +1,5 @@
-"""CPU: the tile layout of the MFMA GEMM kernel (audio-mamba-aum_amd/csrc/gemm_kernels.h), restated lane by lane in numpy -- the
+"""CPU: the tile layout of the MFMA GEMM kernels (audio-mamba-aum_amd/csrc/gemm_kernels.h; the paced-store kernel of gemm_ps_kernels.h shares it),
+restated lane by lane in numpy -- the
 LDS image the direct global->LDS pieces leave (lane-linear destination, XOR swizzle in the source address), the fragment reads with the
 same XOR, v_mfma_f32_16x16x32's operand / accumulator lane maps with the operand roles swapped, and the store map -- gives A . B^T for
 one 256 x 256 x 64 step, and every ds_read_b128 of it touches 16 distinct 16-byte slots per LDS lane group (no bank conflicts)."""
@@ -83,118 +84,55 @@ def test_xcd_tile_map_is_a_bijection():
         assert ids == list(range(nwg)), nwg
 
 
-def test_w4_tile_product_and_bank_slots():
-    """the four-wave form (csrc/gemm_w4_kernels.h, AUM_GEMM_W4): 256 x 192 workgroup tile, wave (wr, wc) of a 2 x 2 grid owns 128 rows x 96
-    columns (8 x 6 accumulator fragments); pieces c = 4 j + w (8 of A, 6 of B per wave); the same swizzles, MFMA roles and store map"""
-    NJ = 6
-    rng = np.random.default_rng(1)
-    A = rng.integers(-3, 4, (256, 64)).astype(np.float64)
-    B = rng.integers(-3, 4, (32 * NJ, 64)).astype(np.float64)
-    lds_a, lds_b = np.full((256, 8, 8), np.nan), np.full((32 * NJ, 8, 8), np.nan)
-    for w in range(4):
-        for j in range(8):
-            for lane in range(64):
-                r, s = (j * 4 + w) * 8 + (lane >> 3), lane & 7
-                fa = ((w & 1) * 4 + (lane >> 4)) & 7                         # the kernel's per-lane constants (independent of j)
-                fb = ((w & 3) << 1) | ((lane >> 4) & 1)
-                assert fa == f_a(r) and fb == f_b(r)
-                lds_a[r, s] = A[r, (s ^ fa) * 8:(s ^ fa) * 8 + 8]
-                if j < NJ:
-                    lds_b[r, s] = B[r, (s ^ fb) * 8:(s ^ fb) * 8 + 8]
-    assert not np.isnan(lds_a).any() and not np.isnan(lds_b).any()           # every row of both tiles is staged exactly by these pieces
-    C = np.full((256, 32 * NJ), np.nan)
-    for wr in range(2):
-        for wc in range(2):
-            acc = np.zeros((8, NJ, 64, 4))
-            for kk in range(2):
-                af, bf = np.zeros((8, 64, 8)), np.zeros((NJ, 64, 8))
-                addr_a, addr_b = np.zeros((8, 64), int), np.zeros((NJ, 64), int)
-                for lane in range(64):
-                    kg, rho = lane >> 4, lane & 15
-                    xa = (kg ^ ((lane >> 1) & 7)) ^ (4 * kk)
-                    xb = (kg ^ ((((rho >> 2) & 3) << 1) | ((rho >> 1) & 1))) ^ (4 * kk)
-                    for i in range(8):
-                        row = wr * 128 + i * 16 + rho
-                        af[i, lane], addr_a[i, lane] = lds_a[row, xa], row * 128 + xa * 16
-                    for j in range(NJ):
-                        row = wc * 16 * NJ + (rho >> 2) * 8 + (j >> 1) * 32 + (j & 1) * 4 + (rho & 3)
-                        bf[j, lane], addr_b[j, lane] = lds_b[row, xb], row * 128 + xb * 16
-                for grp in GROUPS:
-                    for addrs in list(addr_a) + list(addr_b):
-                        assert len({(int(addrs[l]) % 256) // 16 for l in grp}) == 16
-                for i in range(8):
-                    for j in range(NJ):
-                        a_op, b_op = np.zeros((16, 32)), np.zeros((32, 16))
-                        for lane in range(64):
-                            a_op[lane & 15, (lane >> 4) * 8:(lane >> 4) * 8 + 8] = bf[j, lane]
-                            b_op[(lane >> 4) * 8:(lane >> 4) * 8 + 8, lane & 15] = af[i, lane]
-                        D = a_op @ b_op
-                        for lane in range(64):
-                            acc[i, j, lane] += D[(lane >> 4) * 4:(lane >> 4) * 4 + 4, lane & 15]
-            for i in range(8):
-                for lane in range(64):
-                    m = wr * 128 + i * 16 + (lane & 15)
-                    for jp in range(NJ // 2):          # one 16-byte store per fragment pair: columns wc * 96 + 32 jp + 8 kg .. + 7
-                        n = wc * 16 * NJ + jp * 32 + (lane >> 4) * 8
-                        C[m, n:n + 4] = acc[i, 2 * jp, lane]
-                        C[m, n + 4:n + 8] = acc[i, 2 * jp + 1, lane]
-    assert np.array_equal(C, A @ B.T)
+def ps_items(m, n, ncu):
+    """gemm_kernels.h: gemm_ps_items (host side of the paced-store kernel's work list)"""
+    ntn, full, r = n // 256, m // 256, m % 256
+    can_fold = 0 < r <= 64 and full >= 1
+    rb_all = full + (1 if r else 0)
+    rb = full if can_fold else rb_all
+    t = rb * ntn
+    rem = t % ncu
+    ok = t > ncu and rem > 0 and 2 * rem <= ncu and ((rem >= ntn) if can_fold else (r == 0 or r > 128))
+    if ok:
+        return dict(nwhole=t - rem, nitems=t + rem, fold=r if can_fold else 0)
+    return dict(nwhole=rb_all * ntn, nitems=rb_all * ntn, fold=0)
 
 
-def test_ring_tile_product_and_bank_slots():
-    """the five-stage ring form (csrc/gemm_ring_kernels.h, AUM_GEMM_RING): one 32-deep K-step of a 256 x 192 tile.  LDS rows are 64 bytes
-    (four 16-byte slots), a DMA piece is 16 rows (lane l -> row 16 c + (l >> 2), physical slot l & 3, source slot ^ f(row));
-    f_A(row) = G[(row >> 2) & 3], f_B(row) = G[(row >> 3) & 3], G = {0, 3, 2, 1}: every ds_read_b128 service group covers the 16 slots
-    of a 256-byte bank row exactly once, and the MFMA / store maps give A . B^T"""
-    G, NJ = [0, 3, 2, 1], 6
-    rng = np.random.default_rng(2)
-    A = rng.integers(-3, 4, (256, 32)).astype(np.float64)
-    B = rng.integers(-3, 4, (32 * NJ, 32)).astype(np.float64)
-    lds_a, lds_b = np.full((256, 4, 8), np.nan), np.full((32 * NJ, 4, 8), np.nan)
-    for w in range(4):
-        for lane in range(64):
-            fa = G[(lane >> 4) & 3]                                          # the kernel's per-lane constants
-            fb = G[(2 * (w & 1) + (lane >> 5)) & 3]
-            for j in range(4):
-                r, p = (j * 4 + w) * 16 + (lane >> 2), lane & 3
-                assert fa == G[(r >> 2) & 3]
-                lds_a[r, p] = A[r, (p ^ fa) * 8:(p ^ fa) * 8 + 8]
-            for j in range(3):
-                r, p = (j * 4 + w) * 16 + (lane >> 2), lane & 3
-                assert fb == G[(r >> 3) & 3]
-                lds_b[r, p] = B[r, (p ^ fb) * 8:(p ^ fb) * 8 + 8]
-    assert not np.isnan(lds_a).any() and not np.isnan(lds_b).any()
-    C = np.full((256, 32 * NJ), np.nan)
-    for wr in range(2):
-        for wc in range(2):
-            af, bf = np.zeros((8, 64, 8)), np.zeros((NJ, 64, 8))
-            addr_a, addr_b = np.zeros((8, 64), int), np.zeros((NJ, 64), int)
-            for lane in range(64):
-                kg, rho = lane >> 4, lane & 15
-                slot = kg ^ G[rho >> 2]
-                for i in range(8):
-                    row = wr * 128 + i * 16 + rho
-                    assert G[(row >> 2) & 3] == G[rho >> 2]
-                    af[i, lane], addr_a[i, lane] = lds_a[row, slot], row * 64 + slot * 16
-                for j in range(NJ):
-                    row = wc * 16 * NJ + (rho >> 2) * 8 + (j >> 1) * 32 + (j & 1) * 4 + (rho & 3)
-                    assert G[(row >> 3) & 3] == G[rho >> 2]
-                    bf[j, lane], addr_b[j, lane] = lds_b[row, slot], row * 64 + slot * 16
-            for grp in GROUPS:
-                for addrs in list(addr_a) + list(addr_b):
-                    assert len({(int(addrs[l]) % 256) // 16 for l in grp}) == 16
-            for i in range(8):
-                for lane in range(64):
-                    pass
-            for i in range(8):
-                for j in range(NJ):
-                    a_op, b_op = np.zeros((16, 32)), np.zeros((32, 16))
-                    for lane in range(64):
-                        a_op[lane & 15, (lane >> 4) * 8:(lane >> 4) * 8 + 8] = bf[j, lane]
-                        b_op[(lane >> 4) * 8:(lane >> 4) * 8 + 8, lane & 15] = af[i, lane]
-                    D = a_op @ b_op
-                    for lane in range(64):
-                        m = wr * 128 + i * 16 + (lane & 15)
-                        n = wc * 16 * NJ + (j >> 1) * 32 + (lane >> 4) * 8 + (j & 1) * 4
-                        C[m, n:n + 4] = D[(lane >> 4) * 4:(lane >> 4) * 4 + 4, lane & 15]
-    assert np.array_equal(C, A @ B.T)
+def ps_item(L, m, ntn, grid, i):
+    """gemm_ps_kernels.h: ps_item (item id -> first row, first column, live rows)"""
+    item, r0 = i, i // grid * grid
+    if grid % 8 == 0 and r0 + grid <= L["nitems"]:
+        q = i - r0
+        item = r0 + (q & 7) * (grid >> 3) + (q >> 3)
+    h = item - L["nwhole"]
+    tile = item if h < 0 else L["nwhole"] + (h >> 1)
+    tm = tile // ntn
+    m0, n0, span = tm * 256, (tile - tm * ntn) * 256, 256
+    if h >= 0:
+        m0 += (h & 1) * 128
+        span = 128 + (L["fold"] if (h & 1) and (tm + 1) * 256 + L["fold"] == m else 0)
+    return m0, n0, min(m - m0, span)
+
+
+def test_paced_kernel_work_list_covers_the_result_once():
+    """every element of C belongs to exactly one item, every item has 1 .. 256 live rows, a split round fits the grid; the headline
+    n = 768 products (387 tiles on 256 CUs) become 256 whole tiles + 256 halves = two complete rounds"""
+    L = ps_items(64 * 513, 768, 256)
+    assert L == dict(nwhole=256, nitems=512, fold=64)
+    for m, n, ncu in [(64 * 513, 768, 256), (64 * 513, 1536, 256), (64 * 513, 3072, 256), (3 * 513, 3072, 256), (70000, 512, 256), (64 * 513, 768, 304),
+                      (25 * 256, 256, 16), (25 * 256 + 64, 256, 16), (25 * 256 + 65, 256, 16), (25 * 256 + 129, 256, 16), (18 * 256 + 1, 512, 32), (513, 768, 256),
+                      (32 * 513, 768, 256), (128 * 513, 768, 256), (8 * 4097, 768, 256)]:
+        L = ps_items(m, n, ncu)
+        ntn, grid = n // 256, min(L["nitems"], ncu)
+        cover = np.zeros(((m + 255) // 256 * 2 + 2, ntn), int)          # in units of 128-row halves (+ the ragged rows checked by count)
+        rows_total = 0
+        for i in range(L["nitems"]):
+            m0, n0, rows = ps_item(L, m, ntn, grid, i)
+            assert 0 < rows <= 256 and m0 % 128 == 0 and n0 % 256 == 0 and m0 + rows <= m, (m, n, ncu, i, m0, rows)
+            rows_total += rows
+            for hb in range(m0 // 128, (m0 + rows + 127) // 128):
+                cover[hb, n0 // 256] += 1
+        assert rows_total == m * ntn, (m, n, ncu)
+        assert (cover[:(m + 127) // 128] == 1).all() and (cover[(m + 127) // 128:] == 0).all(), (m, n, ncu)
+        if L["nitems"] > L["nwhole"]:
+            assert L["nwhole"] % ncu == 0 and L["nitems"] - L["nwhole"] <= ncu

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""GPU: where a projection GEMM's time goes -- the persistent aum_gemm_tn kernel against ablation builds of it (tools/build_gemm_variant.sh
-gabl<bits> -DAUM_GEMM_ABL=<bits>; wrong results, timing only) and any other variant library, all in one process, interleaved rounds.
-  python tools/gemm_abl_probe.py [--variants gabl1,gabl3,...] [--flags 4] [--vflags name=flags,...]
+"""GPU: where a projection GEMM's time goes -- aum_gemm_tn (the paced-store kernel) against ablation builds of it (tools/build_gemm_variant.sh
+ps<bits> -DAUM_PS_ABL=<bits>; wrong results, timing only), any other variant library, other schedules (--vflags) and the library GEMM, all in
+one process, interleaved rounds; --check name,... asserts bit-equality with the default build.
+  python tools/gemm_abl_probe.py [--variants ps1,ps2,...] [--flags 0] [--vflags default_lockstep=1,...]
 prints one line per shape: us (median) per build.  Writes gpurun_out/gemm_abl_probe.json."""
 import argparse
 import json
@@ -21,8 +22,8 @@ def main():
     ap.add_argument("--tokens", type=int, default=64 * 513)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--variants", default="gabl1,gabl3,gabl5,gabl9,gabl13")
-    ap.add_argument("--flags", type=int, default=aum_hip.GEMM_PERSISTENT)
+    ap.add_argument("--variants", default="", help="comma list of variant libraries (tools/build_gemm_variant.sh <name> -DAUM_PS_ABL=<bits> ...)")
+    ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--vflags", default="", help="name=flags,... : per-variant flags (default --flags)")
     ap.add_argument("--lib", type=int, default=1, help="also time the library GEMM (TunableOp picks)")
     ap.add_argument("--check", default="", help="comma list of builds whose result must equal the default build's bit for bit")
@@ -48,7 +49,7 @@ def main():
         x = torch.randn(M, K, device=dev).to(torch.bfloat16)
         wt = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        fns = {k: (lambda L=L, fl=fl: aum_hip.gemm_tn(x, wt, out=out, lib=L, flags=fl, split_tail=False)) for k, (L, fl) in libs.items()}
+        fns = {k: (lambda L=L, fl=fl: aum_hip.gemm_tn(x, wt, out=out, lib=L, flags=fl)) for k, (L, fl) in libs.items()}
         if a.lib:
             fns["library"] = lambda: torch.matmul(x, wt.t())
         if a.check:

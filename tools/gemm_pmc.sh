@@ -8,7 +8,7 @@ rm -rf $OUT; mkdir -p $OUT
 SHAPE=${1:-in_proj_fwd}
 run() {   # name, counters...
   n=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -o pmc -- python tools/gemm_probe.py --shapes $SHAPE --rounds 2 --iters 5 > $OUT/$n.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -o pmc -- python tools/gemm_abl_probe.py --shapes $SHAPE --rounds 2 --iters 5 > $OUT/$n.log 2>&1
   find $OUT/$n -name "*counter_collection.csv" -exec cp {} $OUT/$n.csv \;
 }
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
@@ -27,7 +27,7 @@ for f in ("mfma", "lds", "fetch", "write"):
                 acc[k[:64]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     except FileNotFoundError:
         pass
-print(f"# tools/gemm_pmc.sh {shape}: rocprofv3 --pmc passes over tools/gemm_probe.py --shapes {shape} (bf16, 32832 tokens); means over launches")
+print(f"# tools/gemm_pmc.sh {shape}: rocprofv3 --pmc passes over tools/gemm_abl_probe.py --shapes {shape} (bf16, 32832 tokens); means over launches")
 print("# MFMA% = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); conflict% = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE;")
 print("# HBM MB per launch: FETCH_SIZE x 2 KiB (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md), WRITE_SIZE x 1 KiB; separate passes")
 print("%-66s %6s %7s %10s %10s %10s" % ("kernel", "calls", "MFMA%", "conflict%", "fetch_MB", "write_MB"))

@@ -122,14 +122,6 @@ def main():
         _, pre1, _ = aum_hip.scan_fwd(u, delta, A, Bm, Cm, D, z, bias, True, want_out_pre=True, x_lane=ck1)
         rec("scan_bwd_uni_ck", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre1, True, x_lane=ck1), iters=10),
             bw_bytes + ck1.numel() * 4)
-        aum_hip.debug.ablate = 64       # AUM_DBG_STATE_BWD: waves own states, rows stream (scan_state_kernels.h)
-        rec("scan_bwd_bidir_state", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre2, True, A_b=A_b, x_lane=ck2), iters=10),
-            bw_bytes + ck2.numel() * 4)
-        rec("scan_bwd_uni_state", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre1, True, x_lane=ck1), iters=10),
-            bw_bytes + ck1.numel() * 4)
-        aum_hip.debug.ablate = 64 + 1
-        rec("ablate_bwd_uni_state_no_states", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre1, True, x_lane=ck1), iters=5), 1)
-        aum_hip.debug.ablate = 0
         for bits, label in ((1, "no_states"), (2, "no_rmw"), (16, "no_step_barrier")):
             aum_hip.debug.ablate = bits
             rec(f"ablate_bwd_bidir_ck_{label}", timeit(lambda: aum_hip.scan_bwd(u, delta, A, Bm, Cm, D, z, bias, dout, pre2, True, A_b=A_b, x_lane=ck2), iters=5), 1)
