@@ -35,6 +35,9 @@
 
 namespace aumg {
 
+#ifndef AUM_PS_DEAD_WAVES
+#define AUM_PS_DEAD_WAVES 1     // 0: A/B build -- waves without live rows multiply zeros (as until the split last round)
+#endif
 #ifndef AUM_PS_ABL
 #define AUM_PS_ABL 0        // timing experiments only (wrong results): 1 no DMA pieces in the steps, 2 no stores, 4 no MFMAs, 8 every store dropped by the range check,
                             // 16 every tile reads the activation rows of row block 0 (L2 hits), 32 the weight rows of column tile 0 (first kernel only)
@@ -267,6 +270,37 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_ps(GemmLaunch L) {
             }
             par ^= 1;
         };
+        // A wave whose 128 rows all lie beyond the item's rows (the lower wave row of a half item or of a ragged row block of at most 128
+        // rows -- always the workgroup's LAST item: both kinds sit in the last round) has nothing to multiply: it keeps its share of the
+        // pieces, the previous tile's paced stores and the barriers, and leaves the SIMD's matrix pipe to the wave that has rows.
+        if (AUM_PS_DEAD_WAVES && wr == 1 && rows <= BM / 2 && !has_next) {
+            auto kdead = [&](auto st_c, int t) {
+                constexpr int ST = decltype(st_c)::value;
+                char* cur = lds + par * STAGE_BYTES;
+                char* oth = lds + (par ^ 1) * STAGE_BYTES;
+                const bool same1 = t + 1 < nk, same2 = t + 2 < nk;
+#pragma unroll
+                for (int n = 4; n < 8; ++n) piece(same1 ? ra : r_null, same1 ? rb : r_null, (same1 ? t + 1 : 0) * (BK * 2), oth, n);
+                if constexpr (ST >= 0 && !(AUM_PS_ABL & 2)) {
+                    __builtin_amdgcn_raw_buffer_store_b128(pend[ST][0], rc_prev, c_voff + (ST + 2) * 16 * ldc2, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(pend[ST][1], rc_prev, c_voff + (ST + 2) * 16 * ldc2 + 64, 0, 0);
+                }
+                constexpr int NSTO = (AUM_PS_ABL & 2) ? 0 : ST >= 0 ? 2 : 0;
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSTO) : "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int n = 0; n < 4; ++n) piece(same2 ? ra : r_null, same2 ? rb : r_null, (same2 ? t + 2 : 0) * (BK * 2), cur, n);
+                par ^= 1;
+            };
+            kdead(PsC<0>{}, 0);
+            kdead(PsC<1>{}, 1);
+            kdead(PsC<2>{}, 2);
+            kdead(PsC<3>{}, 3);
+            kdead(PsC<4>{}, 4);
+            kdead(PsC<5>{}, 5);
+            for (int t = PS_NST; t < nk; ++t) kdead(PsC<-1>{}, t);
+            return;                                     // nothing of this item to store: its rows of C are all out of range
+        }
         kstep(PsC<1>{}, PsC<0>{}, PsC<0>{}, 0);
         kstep(PsC<0>{}, PsC<1>{}, PsC<0>{}, 1);
         kstep(PsC<0>{}, PsC<2>{}, PsC<0>{}, 2);

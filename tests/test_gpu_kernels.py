@@ -414,6 +414,41 @@ def test_scan_tm_headline_grid_b64(lib):
     print("scan_tm headline grid, worst errors:", {k: float("%.3g" % v) for k, v in sorted(worst.items())})
 
 
+@pytest.mark.parametrize("dout_mag", [2.0 ** -12, 16.0], ids=["unscaled", "gradscaler_2p16"])
+def test_scan_tm_headline_grid_b64_fp16(lib, dout_mag):
+    """the reference trains in fp16 + GradScaler (`--mixed_precision=fp16`, exps/audioset/aum-base_scratch-audioset.sh:54).
+    The bench launch (B = 64, E = 1536, L = 513) in float16 -- packed fp16 state checkpoints and 16-bit partial hand-overs with 5
+    exponent bits -- against the fp64 oracle at the 16-bit bar, once with a realistic unscaled gradient magnitude (2^-12: the
+    backward's outputs live among fp16's subnormals, so only the forward and finiteness are held to the bar there) and once with that
+    gradient as GradScaler's initial scale 2^16 delivers it (16): every gradient finite and equal to 2^16 x the unscaled fp64 gradient
+    at the bar, i.e. nothing overflows on the way and GradScaler has no inf to skip on at this magnitude."""
+    rows = {0: [0, 63, 64, 700], 17: [64 * 3 + 63, 64 * 4], 40: [1000, 1001], 63: [0, 777, 1535]}
+    if dout_mag < 1:
+        # unscaled: du / ddelta / dz of a 2^-12 gradient are fp16 subnormals (absolute step 2^-24 ~ 2.4e-4 of 2^-12): a relative bar means
+        # nothing there -- this is exactly why the reference scales.  Held here: the forward at the bar and finite gradients.
+        import aum_hip
+        torch.manual_seed(5)
+        Bsz, L, E, N = 64, 513, 1536, 16
+        h = lambda t: t.half()
+        u, z, dl = h(torch.randn(Bsz, L, E, device="cuda")), h(torch.randn(Bsz, L, E, device="cuda")), h(0.5 * torch.randn(Bsz, L, E, device="cuda"))
+        Bm, Cm = h(torch.randn(Bsz, L, N, device="cuda")), h(torch.randn(Bsz, L, N, device="cuda"))
+        A = -torch.arange(1, N + 1, device="cuda", dtype=torch.float32).repeat(E, 1)
+        D, bias = torch.ones(E, device="cuda"), torch.full((E,), -4.0, device="cuda")
+        dout = h(dout_mag * torch.randn(Bsz, L, E, device="cuda"))
+        ck = aum_hip.scan_tm_ckpt(Bsz, L, E, N, True, "cuda", dtype=torch.float16)
+        out, pre = aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, D, z, bias, True, A_b=A * 1.1, want_out_pre=True, ckpt=ck, lib=lib)
+        g = aum_hip.scan_tm_bwd(u, dl, A, Bm, Cm, D, z, bias, dout, pre, ck, True, A_b=A * 1.1, lib=lib)
+        assert bool(torch.isfinite(out).all()) and all(v is None or bool(torch.isfinite(v).all()) for v in g.values())
+        # the fp32 parameter sums do not underflow: 2^16 x them equals the scaled run's sums up to the 16-bit inputs' rounding
+        g16 = aum_hip.scan_tm_bwd(u, dl, A, Bm, Cm, D, z, bias, h(dout.float() * 65536.0), pre, ck, True, A_b=A * 1.1, lib=lib)
+        for k in ("dA", "dA_b", "dD", "ddelta_bias", "dBC"):
+            a, b = g[k].float() * 65536.0, g16[k].float()
+            assert (a - b).abs().max() <= 2e-2 * b.abs().max(), (k, float((a - b).abs().max()), float(b.abs().max()))
+        return
+    worst = KC.check_scan_tm_grid(lib, "cuda", 64, 513, 1536, rows, (0, 63), [0, 63, 64, 1535], 8, dtype=torch.float16, dout_mag=dout_mag)
+    print("scan_tm headline grid fp16, dout x 2^16, worst errors:", {k: float("%.3g" % v) for k, v in sorted(worst.items())})
+
+
 @pytest.mark.parametrize("case", [c for c in cases.SCAN_TM_CASES if c[3] >= 9], ids=lambda c: c[0])
 @pytest.mark.parametrize("mode", ["fwd", "rev", "bidir"])
 @pytest.mark.parametrize("segments", [2, 3, 5])

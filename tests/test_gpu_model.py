@@ -421,6 +421,18 @@ def test_aum_base_headline_fp32_vs_reference():
 
 @pytest.mark.parametrize("gemm_mode", ["auto", "hip", "lib"])
 def test_aum_base_headline_bench_batch_bf16_vs_reference(gemm_mode, monkeypatch):
+    _headline_lowp_vs_reference(gemm_mode, monkeypatch, torch.bfloat16, "bf16")
+
+
+def test_aum_base_headline_bench_batch_fp16_vs_reference(monkeypatch):
+    """the reference's OWN training precision.  Every exps/**/aum-*.sh launches `--mixed_precision=fp16`
+    (exps/audioset/aum-base_scratch-audioset.sh:54); golden/headline_fp16.npz is the reference's AudioMamba under float16 autocast
+    (make_golden.py --headline-fp16: fp32 scan interior as `custom_fwd` leaves it).  Same three distances and the same bars as the bf16
+    twin: the product's fp16 run is no further from the fp32 truth than 1.5 x the reference's own fp16 run."""
+    _headline_lowp_vs_reference("auto", monkeypatch, torch.float16, "fp16")
+
+
+def _headline_lowp_vs_reference(gemm_mode, monkeypatch, lowp, tag):
     """(gemm_mode: the projection-GEMM dispatch of selective_scan_interface -- `hip` runs in_proj / out_proj forward and both data
     gradients of all 24 blocks on aum_gemm_tn, `lib` none of them, `auto` the default -- the same bars for all three.)
     the bench's own launch shapes against the reference: the golden clip repeated 64 times under bf16 autocast goes through the
@@ -438,7 +450,7 @@ def test_aum_base_headline_bench_batch_bf16_vs_reference(gemm_mode, monkeypatch)
     aum_hip.timer.reset()
     aum_hip.timer.only, aum_hip.timer.enabled = {"gemm_tn"}, True
     try:
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=lowp):
             lb = model(x)
         n_fwd = aum_hip.timer.summary().get("gemm_tn", {"launches": 0})["launches"]
         (lb.float() * torch.tensor(d["dlogits"], device=DEV)).sum().backward()
@@ -460,7 +472,7 @@ def test_aum_base_headline_bench_batch_bf16_vs_reference(gemm_mode, monkeypatch)
     # distances per quantity: product-bf16 to reference-fp32 (e_*), reference-bf16 to reference-fp32 (r_*: what rounding the
     # activations of 24 blocks to bf16 costs the REFERENCE), product-bf16 to reference-bf16 (p_*: two different placements of the same
     # roundings).  The bars are the reference's own distances, not a depth-scaled constant.
-    h = load_golden("headline_bf16")
+    h = load_golden("headline_" + tag)
     assert abs(float(h[name + ".checksum"]) - float(g[name + ".checksum"])) <= 1e-6 * abs(float(g[name + ".checksum"]))
     ref16 = h[name + ".logits"]
     r_logits, p_logits = rel_err(ref16, ref), max(rel_err(r, ref16) for r in rows)
@@ -473,7 +485,7 @@ def test_aum_base_headline_bench_batch_bf16_vs_reference(gemm_mode, monkeypatch)
             r_elem[k] = rel_err(h[f"{name}.grad.{k}"], g[f"{name}.grad.{k}"])
             p_elem[k] = rel_err(p_.grad.cpu().numpy() / reps, h[f"{name}.grad.{k}"])
     med = lambda d_: float(np.median(list(d_.values())))
-    _err_report(name + ".bf16_b64." + gemm_mode, {
+    _err_report(name + f".{tag}_b64." + gemm_mode, {
         "logits": max(e_rows), "gnorm_max": [wn, e_norm[wn]], "grad_elem_max": [we, e_elem[we]], "gnorm_median": med(e_norm),
         "ref_bf16_vs_ref_fp32": {"logits": r_logits, "gnorm_max": max(r_norm.values()), "gnorm_median": med(r_norm), "grad_elem_max": max(r_elem.values())},
         "product_bf16_vs_ref_bf16": {"logits": p_logits, "gnorm_max": max(p_norm.values()), "gnorm_median": med(p_norm), "grad_elem_max": max(p_elem.values())}})
