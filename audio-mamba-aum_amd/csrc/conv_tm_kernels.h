@@ -63,6 +63,11 @@ template <class T, bool BWD> AUM_DEV void convt_store_m(const gbuf<T>& b, vi vof
     if constexpr (convt_nb<T, BWD>() == 16) gbuf_store16_m(b, voff_bytes, soff_bytes, vq_pack<T>(v), m);
     else gbuf_store8_m(b, voff_bytes, soff_bytes, vh_pack<T>(v), m);
 }
+template <class T, bool BWD> AUM_DEV void convt_store(const gbuf<T>& b, vi voff_bytes, int soff_bytes, const vf (&v)[convt_vec<T, BWD>()]) {
+    if constexpr (convt_nb<T, BWD>() == 16) gbuf_store16(b, voff_bytes, soff_bytes, vq_pack<T>(v));
+    else gbuf_store8(b, voff_bytes, soff_bytes, vh_pack<T>(v));
+}
+template <bool V> struct ConvtTag { static constexpr bool value = V; };
 template <class T, bool BWD> AUM_HOSTDEV int convt_cblocks(int dim) { return (dim + WAVE * convt_vec<T, BWD>() - 1) / (WAVE * convt_vec<T, BWD>()); }
 AUM_HOSTDEV inline int convt_nparts(int batch, int len) { return batch * convt_chunks<true>(len); }      // the backward's partial rows: one per (batch entry, chunk)
 
@@ -131,18 +136,33 @@ AUM_DEV void convt_fwd_wave(const AumConvTmArgs& a, int wg) {
     auto tok = [&](int it) { return rev ? L - 1 - it : it; };
     const int tc = convt_tc<false>(L);
     const int it0 = ch * tc, it1 = it0 + tc < L ? it0 + tc : L;
-    vf xw[CONVT_W][V];
+    // channel pairs (2 p, 2 p + 1) of the lane on packed fp32 (the same IEEE operations in the same order as one by one: bit-equal), the
+    // window as a ring indexed at compile time: at step j of a block x[it - 3 + k] sits in slot (k + j) & 3, the row entering at k = 3 takes
+    // the slot of the row that left at k = 0 (round 6; the shifting window was 20 of ~90 vector-ALU slots per step)
+    constexpr int NP = V / 2;
+    vf2 w2[CONVT_W][NP], bias2[NP], xr[CONVT_W][NP];
+    AUM_UNROLL
+    for (int p = 0; p < NP; ++p) {
+        bias2[p] = mk2(ln.bias[2 * p], ln.bias[2 * p + 1]);
+        AUM_UNROLL
+        for (int k = 0; k < CONVT_W; ++k) {
+            w2[k][p] = mk2(ln.w[k][2 * p], ln.w[k][2 * p + 1]);
+            xr[k][p] = spl2(splat(0.f));
+        }
+    }
+    auto unpack2 = [&](const convt_raw<T, false>& q, vf2 (&o)[NP]) {
+        vf t[V];
+        convt_unpack<T, false>(q, t);
+        AUM_UNROLL
+        for (int p = 0; p < NP; ++p) o[p] = mk2(t[2 * p], t[2 * p + 1]);
+    };
     // the window before the chunk: steps it0 - 3 .. it0 - 1 (zero padding before the sequence)
     AUM_UNROLL
     for (int k = 0; k < CONVT_W - 1; ++k) {
         const int it = it0 - (CONVT_W - 1) + k;
-        if (it >= 0) {
-            convt_unpack<T, false>(convt_load<T, false>(xb, coff, tok(it) * x_tb), xw[k + 1]);
-        } else {
-            AUM_UNROLL
-            for (int v = 0; v < V; ++v) xw[k + 1][v] = splat(0.f);
-        }
+        if (it >= 0) unpack2(convt_load<T, false>(xb, coff, tok(it) * x_tb), xr[k]);
     }
+    const bool all_live = a.dim % (WAVE * V) == 0;
     // Two blocks of CONVT_UB steps are in flight: the rows of the block after next are requested before a block is computed (a wave that
     // fetched a block, waited, computed and only then fetched again left the memory pipe idle for the arithmetic of every block -- there
     // are fewer than two waves per SIMD to fill the gap at the bench shape).  Requests past the chunk are clamped to its last row: no
@@ -154,25 +174,25 @@ AUM_DEV void convt_fwd_wave(const AumConvTmArgs& a, int wg) {
             raw[j] = convt_load<T, false>(xb, coff, tok(it) * x_tb);
         }
     };
+    static_assert(CONVT_UB % CONVT_W == 0, "a block returns the ring to its phase");
     auto comp_blk = [&](int itb, const convt_raw<T, false> (&raw)[CONVT_UB]) {
         AUM_UNROLL
         for (int j = 0; j < CONVT_UB; ++j) {
             if (itb + j < it1) {
-                AUM_UNROLL
-                for (int k = 0; k < CONVT_W - 1; ++k) {
-                    AUM_UNROLL
-                    for (int v = 0; v < V; ++v) xw[k][v] = xw[k + 1][v];
-                }
-                convt_unpack<T, false>(raw[j], xw[CONVT_W - 1]);
+                auto X = [&](int k) -> vf2 (&)[NP] { return xr[(k + j) & (CONVT_W - 1)]; };
+                unpack2(raw[j], X(CONVT_W - 1));
                 vf y[V];
                 AUM_UNROLL
-                for (int v = 0; v < V; ++v) {
-                    vf acc = ln.bias[v];
+                for (int p = 0; p < NP; ++p) {
+                    vf2 acc = bias2[p];
                     AUM_UNROLL
-                    for (int k = 0; k < CONVT_W; ++k) acc = vfma(ln.w[k][v], xw[k][v], acc);
-                    y[v] = SILU ? convt_silu(acc) : acc;
+                    for (int k = 0; k < CONVT_W; ++k) acc = vfma2(w2[k][p], X(k)[p], acc);
+                    if (SILU) acc = acc * vsigmoid2(acc);
+                    y[2 * p] = lo2(acc);
+                    y[2 * p + 1] = hi2(acc);
                 }
-                convt_store_m<T, false>(yb, coff, tok(itb + j) * y_tb, y, ln.live);
+                if (all_live) convt_store<T, false>(yb, coff, tok(itb + j) * y_tb, y);
+                else convt_store_m<T, false>(yb, coff, tok(itb + j) * y_tb, y, ln.live);
             }
         }
     };
@@ -189,10 +209,14 @@ AUM_DEV void convt_fwd_wave(const AumConvTmArgs& a, int wg) {
 // (The backward keeps one block of eight steps in flight: two tensors and a wider register window leave room for two blocks of four only,
 // and that measured slower -- 2.18 against 2.00 ms per step of the bench.)
 // backward: steps it1 - 1 down to it0; the three steps after the chunk are recomputed first (their dpre enters dx of the chunk's
-// last steps), their dw / dbias terms belong to the next chunk
+// last steps), their dw / dbias terms belong to the next chunk.
+// Round 6: the arithmetic on PAIRS of channels (v_pk_fma_f32 / v_pk_mul_f32: the same IEEE operations in the same order, two per issue
+// slot -- bit-equal to the one-by-one form) and the windows as compile-time rings (the listing of round 5 was ~120 vector-ALU slots per step
+// for four channels, 22 of them window moves: as much SIMD time as the kernel's bytes take at the copy rate).  A second copy of the block
+// without per-step conditions was built too: 182 registers against 114 (the third wave per SIMD lost), not kept.
 template <class T, bool SILU>
 AUM_DEV void convt_bwd_wave(const AumConvTmArgs& a, int wg) {
-    constexpr int V = convt_vec<T, true>(), ES = (int)sizeof(T);
+    constexpr int V = convt_vec<T, true>(), NP = V / 2, ES = (int)sizeof(T);
     const int ncb = convt_cblocks<T, true>(a.dim), nch = convt_chunks<true>(a.len), L = a.len;
     const int cb = wg % ncb, ch = (wg / ncb) % nch, b = wg / (ncb * nch);
     const bool rev = (a.flags & AUM_CONV_REVERSE) != 0;
@@ -207,27 +231,37 @@ AUM_DEV void convt_bwd_wave(const AumConvTmArgs& a, int wg) {
     const int tc = convt_tc<true>(L);
     const int it0 = ch * tc, it1 = it0 + tc < L ? it0 + tc : L;
     const int itop = it1 + (CONVT_W - 1) < L ? it1 + (CONVT_W - 1) : L;        // first step NOT recomputed
-    // xw[k] = x[it - 3 + k] of the step being processed (walking down, a new x[it - 3] enters at k = 0); dp[k] = dpre[it + k]
-    vf xw[CONVT_W][V], dp[CONVT_W][V], dw[CONVT_W][V], db[V];
+    const bool all_live = a.dim % (WAVE * V) == 0;                              // no lane past the last channel: stores need no mask
+    // channel pairs (2 p, 2 p + 1) of the lane
+    vf2 w2[CONVT_W][NP], bias2[NP];
     AUM_UNROLL
-    for (int v = 0; v < V; ++v) {
-        db[v] = splat(0.f);
+    for (int p = 0; p < NP; ++p) {
+        bias2[p] = mk2(ln.bias[2 * p], ln.bias[2 * p + 1]);
         AUM_UNROLL
-        for (int k = 0; k < CONVT_W; ++k) {
-            dw[k][v] = splat(0.f);
-            dp[k][v] = splat(0.f);
-        }
+        for (int k = 0; k < CONVT_W; ++k) w2[k][p] = mk2(ln.w[k][2 * p], ln.w[k][2 * p + 1]);
+    }
+    auto unpack2 = [&](const convt_raw<T, true>& q, vf2 (&o)[NP]) {
+        vf t[V];
+        convt_unpack<T, true>(q, t);
+        AUM_UNROLL
+        for (int p = 0; p < NP; ++p) o[p] = mk2(t[2 * p], t[2 * p + 1]);
+    };
+    const vf2 zero2 = spl2(splat(0.f)), one2 = spl2(splat(1.f));
+    // Windows as RINGS indexed at compile time (a shifting window is 12 register-pair moves per step wherever a step is conditional): at
+    // step j of a block (it = itb - j) x[it - 3 + k] sits in slot (k - j) & 3 of xr, dpre[it + k] in slot (k - j) & 3 of dr; the row that
+    // enters at k = 0 takes the slot of the row that left at k = 3, and a block of eight steps ends where it began.
+    vf2 xr[CONVT_W][NP], dr[CONVT_W][NP], dw[CONVT_W][NP], db[NP];
+    AUM_UNROLL
+    for (int p = 0; p < NP; ++p) {
+        db[p] = zero2;
+        AUM_UNROLL
+        for (int k = 0; k < CONVT_W; ++k) dw[k][p] = dr[k][p] = xr[k][p] = zero2;
     }
     // window of the first step processed (itop - 1): x[itop - 4 .. itop - 1]; its k = 0 row is loaded in the loop, rows 1..3 here
     AUM_UNROLL
     for (int k = 1; k < CONVT_W; ++k) {
         const int it = itop - 1 - (CONVT_W - 1) + k;
-        if (it >= 0) {
-            convt_unpack<T, true>(convt_load<T, true>(xb, coff, tok(it) * x_tb), xw[k - 1]);       // stored one slot low: the loop shifts up before use
-        } else {
-            AUM_UNROLL
-            for (int v = 0; v < V; ++v) xw[k - 1][v] = splat(0.f);
-        }
+        if (it >= 0) unpack2(convt_load<T, true>(xb, coff, tok(it) * x_tb), xr[k]);
     }
     auto load_blk = [&](int itb, convt_raw<T, true> (&rx)[CONVT_UB], convt_raw<T, true> (&rg)[CONVT_UB]) {
         AUM_UNROLL
@@ -242,49 +276,54 @@ AUM_DEV void convt_bwd_wave(const AumConvTmArgs& a, int wg) {
         AUM_UNROLL
         for (int j = 0; j < CONVT_UB; ++j) {
             const int it = itb - j;
-            if (it >= it0) {
-                AUM_UNROLL
-                for (int k = CONVT_W - 1; k > 0; --k) {
-                    AUM_UNROLL
-                    for (int v = 0; v < V; ++v) {
-                        xw[k][v] = xw[k - 1][v];
-                        dp[k][v] = dp[k - 1][v];
-                    }
-                }
-                if (it - (CONVT_W - 1) >= 0) {
-                    convt_unpack<T, true>(rx[j], xw[0]);
+            if (it >= it0) {                                    // (false for the rest of the block once false: the rings' phase is never observed again)
+                constexpr int W = CONVT_W;
+                auto X = [&](int k) -> vf2 (&)[NP] { return xr[(k - j) & (W - 1)]; };
+                auto Dp = [&](int k) -> vf2 (&)[NP] { return dr[(k - j) & (W - 1)]; };
+                if (it - (W - 1) >= 0) {
+                    unpack2(rx[j], X(0));
                 } else {
                     AUM_UNROLL
-                    for (int v = 0; v < V; ++v) xw[0][v] = splat(0.f);
+                    for (int p = 0; p < NP; ++p) X(0)[p] = zero2;
                 }
-                vf g[V], dxv[V];
-                convt_unpack<T, true>(rg[j], g);
+                vf2 g[NP], dxv[NP];
+                unpack2(rg[j], g);
                 const bool own = it < it1;
                 AUM_UNROLL
-                for (int v = 0; v < V; ++v) {
-                    vf d = g[v];
+                for (int p = 0; p < NP; ++p) {
+                    vf2 d = g[p];
                     if (SILU) {
-                        vf pre = ln.bias[v];
+                        vf2 pre = bias2[p];
                         AUM_UNROLL
-                        for (int k = 0; k < CONVT_W; ++k) pre = vfma(ln.w[k][v], xw[k][v], pre);
-                        const vf sg = vsigmoid(pre);
-                        d = d * (sg * vfma(pre, splat(1.f) - sg, splat(1.f)));
+                        for (int k = 0; k < W; ++k) pre = vfma2(w2[k][p], X(k)[p], pre);
+                        const vf2 sg = vsigmoid2(pre);
+                        d = d * (sg * vfma2(pre, one2 - sg, one2));
                     }
-                    dp[0][v] = d;
+                    Dp(0)[p] = d;
                     if (own) {
-                        db[v] = db[v] + d;
+                        db[p] = db[p] + d;
                         AUM_UNROLL
-                        for (int k = 0; k < CONVT_W; ++k) dw[k][v] = vfma(d, xw[k][v], dw[k][v]);
-                        vf s = splat(0.f);
+                        for (int k = 0; k < W; ++k) dw[k][p] = vfma2(d, X(k)[p], dw[k][p]);
+                        vf2 s = zero2;
                         AUM_UNROLL
-                        for (int k = 0; k < CONVT_W; ++k) s = vfma(ln.w[k][v], dp[CONVT_W - 1 - k][v], s);
-                        dxv[v] = s;
+                        for (int k = 0; k < W; ++k) s = vfma2(w2[k][p], Dp(W - 1 - k)[p], s);
+                        dxv[p] = s;
                     }
                 }
-                if (own) convt_store_m<T, true>(dxb, coff, tok(it) * dx_tb, dxv, ln.live);
+                if (own) {
+                    vf o[V];
+                    AUM_UNROLL
+                    for (int p = 0; p < NP; ++p) {
+                        o[2 * p] = lo2(dxv[p]);
+                        o[2 * p + 1] = hi2(dxv[p]);
+                    }
+                    if (all_live) convt_store<T, true>(dxb, coff, tok(it) * dx_tb, o);
+                    else convt_store_m<T, true>(dxb, coff, tok(it) * dx_tb, o, ln.live);
+                }
             }
         }
     };
+    static_assert(CONVT_UB % CONVT_W == 0, "a block returns the rings to their phase");
 #if AUM_CONVT_BWD_BLOCKS == 2
     // two blocks in flight, as in the forward: with 8 bytes per lane the second block's 32 raw registers fit under the three-waves-per-SIMD limit
     convt_raw<T, true> ax[CONVT_UB], ag[CONVT_UB], bx[CONVT_UB], bg[CONVT_UB];
@@ -310,9 +349,9 @@ AUM_DEV void convt_bwd_wave(const AumConvTmArgs& a, int wg) {
         AUM_UNROLL
         for (int k = 0; k < CONVT_W; ++k) {
             const int kk = k - (CONVT_W - a.width);
-            if (kk >= 0) gstore(a.dw_part + (int64_t)part * a.dim * a.width + kk, (ln.c0 + v) * a.width, dw[k][v], ln.live);
+            if (kk >= 0) gstore(a.dw_part + (int64_t)part * a.dim * a.width + kk, (ln.c0 + v) * a.width, (v & 1) ? hi2(dw[k][v >> 1]) : lo2(dw[k][v >> 1]), ln.live);
         }
-        if (a.db_part) gstore(a.db_part + (int64_t)part * a.dim, ln.c0 + v, db[v], ln.live);
+        if (a.db_part) gstore(a.db_part + (int64_t)part * a.dim, ln.c0 + v, (v & 1) ? hi2(db[v >> 1]) : lo2(db[v >> 1]), ln.live);
     }
 }
 

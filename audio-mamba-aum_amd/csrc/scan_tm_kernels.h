@@ -763,6 +763,9 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
 #if defined(AUM_SCANT_TRACE) && !defined(AUM_EMU)
 #define AUM_TMB_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - stamp_; stamp_ = now_; } while (0)
     unsigned long long stamp_ = __builtin_readcyclecounter();
+#elif defined(AUM_SCANT_MARKS) && !defined(AUM_EMU)
+    // listings only (tools/isa_mix_tm.py --marks): a comment line in the assembly where a stage of the block begins
+#define AUM_TMB_STAMP(k) asm volatile("; AUM_MARK " #k)
 #else
 #define AUM_TMB_STAMP(k) do { } while (0)
 #endif
@@ -818,12 +821,16 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
         AUM_TMB_STAMP(9);
         convert_bc();
         // ---- per-step registers of the block; dz of its steps --------------------------------------------------
-        // P[s] = (delta_s, delta_s u_s), Q[i] = (dy_2i, dy_2i+1): pairs of DIFFERENT values -- a packed instruction broadcasts either half
-        // of a register pair as an operand modifier, whereas a (d, d) operand kept across the pass loop is two registers
-        vf2 P[SCANT_CK], Q[SCANT_CK / 2];
+        // Pd[i] = (delta_2i, delta_2i+1), Pu[i] = (delta u)_2i, _2i+1, Q[i] = (dy_2i, dy_2i+1): pairs of DIFFERENT values -- a packed instruction
+        // broadcasts either half of a register pair as an operand modifier, whereas a (d, d) operand kept across the pass loop is two registers.
+        // Pairs over STEPS (round 6; until round 5 one pair per step: (delta_s, (delta u)_s)): the arithmetic of this stage and of the block's
+        // last lines then runs on two steps per packed instruction -- the same IEEE operations in the same order, bit-equal results -- and
+        // the passes pick a step's half exactly as they always did for Q.  (profiles/r06_isa_mix_tm.txt: a quarter of the kernel's vector-ALU
+        // instructions are outside the passes.)
+        vf2 Pd[SCANT_CK / 2], Pu[SCANT_CK / 2], Q[SCANT_CK / 2];
         float* const t_u = t_u_of(blk);
         {
-            // all LDS reads first (raw: 40 registers that are free here), then the arithmetic step by step
+            // all LDS reads first (raw: 40 registers that are free here), then the arithmetic pair of steps by pair of steps
             vi ru[SCANT_CK], rd[SCANT_CK], rg[SCANT_CK], rz[SCANT_CK], ry[SCANT_CK];
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) {
@@ -835,30 +842,34 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                 if (HAS_Z && FINAL) ry[s] = lds_read_raw<T>(t_y, off);
             }
             AUM_SCHED_FENCE();
-            vf dyv[SCANT_CK];
+            const vf2 bias2 = spl2(biasv), one2 = spl2(splat(1.f));
             AUM_UNROLL
-            for (int s = 0; s < SCANT_CK; ++s) {
-                const vi off = el_off + s * LROW;
-                const vf us = raw_to_f32<T>(ru[s]);
-                vf d = raw_to_f32<T>(rd[s]) + biasv;
-                if (SP) d = vsoftplus(d);
-                P[s] = mk2(d, d * us);
-                const vf go = raw_to_f32<T>(rg[s]);
+            for (int i = 0; i < SCANT_CK / 2; ++i) {
+                const int s0 = 2 * i, s1 = 2 * i + 1;
+                const vf2 us = mk2(raw_to_f32<T>(ru[s0]), raw_to_f32<T>(ru[s1]));
+                vf2 d = mk2(raw_to_f32<T>(rd[s0]), raw_to_f32<T>(rd[s1])) + bias2;
+                if (SP) d = vsoftplus2(d);
+                Pd[i] = d;
+                Pu[i] = d * us;
+                const vf2 go = mk2(raw_to_f32<T>(rg[s0]), raw_to_f32<T>(rg[s1]));
                 if (HAS_Z) {
-                    const vf zz = raw_to_f32<T>(rz[s]);
-                    const vf sg = vsigmoid(zz);
-                    dyv[s] = go * (zz * sg);
+                    const vf2 zz = mk2(raw_to_f32<T>(rz[s0]), raw_to_f32<T>(rz[s1]));
+                    const vf2 sg = vsigmoid2(zz);
+                    Q[i] = go * (zz * sg);
                     if (FINAL) {        // dz = dout ytot d(z sigmoid(z))/dz  (direction-independent: written by whoever finishes the step)
-                        const vf yt = raw_to_f32<T>(ry[s]);
-                        lds_write_elem<T>(t_dz, off, go * yt * (sg * vfma(zz, splat(1.f) - sg, splat(1.f))));
+                        const vf2 yt = mk2(raw_to_f32<T>(ry[s0]), raw_to_f32<T>(ry[s1]));
+                        const vf2 dzv = go * yt * (sg * vfma2(zz, one2 - sg, one2));
+                        lds_write_elem<T>(t_dz, el_off + s0 * LROW, lo2(dzv));
+                        lds_write_elem<T>(t_dz, el_off + s1 * LROW, hi2(dzv));
                     }
                 } else {
-                    dyv[s] = go;
+                    Q[i] = go;
                 }
             }
-            AUM_UNROLL
-            for (int i = 0; i < SCANT_CK / 2; ++i) Q[i] = mk2(dyv[2 * i], dyv[2 * i + 1]);
         }
+        // a step's delta / delta u as a broadcast operand
+        auto DS = [&](int s) { return (s & 1) ? bc_hi(Pd[s >> 1]) : bc_lo(Pd[s >> 1]); };
+        auto US = [&](int s) { return (s & 1) ? bc_hi(Pu[s >> 1]) : bc_lo(Pu[s >> 1]); };
         AUM_TMB_STAMP(10);
         vf2 S1[SCANT_CK], S2[SCANT_CK];      // per state PAIR: one packed fma per step and sum; the two halves are added once per block
         AUM_UNROLL
@@ -921,16 +932,18 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             // the per-step values are loop invariants, and a packed operand (d, d) built OUTSIDE the loop is a real register pair
             // (48 registers for 24 values); opaque to the compiler here, the broadcast is an operand modifier of the packed instruction
             AUM_UNROLL
-            for (int s = 0; s < SCANT_CK; ++s) pin_value2(P[s]);
-            AUM_UNROLL
-            for (int i = 0; i < SCANT_CK / 2; ++i) pin_value2(Q[i]);
+            for (int i = 0; i < SCANT_CK / 2; ++i) {
+                pin_value2(Pd[i]);
+                pin_value2(Pu[i]);
+                pin_value2(Q[i]);
+            }
             const int jr = (AUM_SCANT_BABL & 4) ? 0 : j;
             vf2 hj = mk2(vf16_get(hh, 2 * jr), vf16_get(hh, 2 * jr + 1)), dAj = mk2(vf16_get(dAacc, 2 * jr), vf16_get(dAacc, 2 * jr + 1));
             vf2 w[SCANT_CK], a[SCANT_CK];
             vf pc[16], pb[16];
             // a = exp2(delta A2) of the eight steps: independent of the recurrences, used by both sweeps
             AUM_UNROLL
-            for (int s = 0; s < SCANT_CK; ++s) a[s] = (AUM_SCANT_BABL & 2) ? bc_lo(P[s]) * A2j : vexp2_2(bc_lo(P[s]) * A2j);
+            for (int s = 0; s < SCANT_CK; ++s) a[s] = (AUM_SCANT_BABL & 2) ? DS(s) * A2j : vexp2_2(DS(s) * A2j);
             // forward sweep: steps 0 .. s_hi-1
             AUM_UNROLL
             for (int s = 0; s < SCANT_CK; ++s) {
@@ -941,7 +954,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                 vf2 pcs = spl2(splat(0.f));
                 if (FULL || s < s_hi) {
                     w[s] = a[s] * x;
-                    x = vfma2(bc_hi(P[s]), mk2(qb[s][0], qb[s][1]), w[s]);
+                    x = vfma2(US(s), mk2(qb[s][0], qb[s][1]), w[s]);
                     if (FULL || s >= s_lo) {
                         pcs = ((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1])) * x;
                         pc[2 * s] = lo2(pcs);
@@ -968,13 +981,13 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                 vf2 pbs = spl2(splat(0.f));
                 if (FULL || (s >= s_lo && s < s_hi)) {
                     const vf2 g = vfma2((s & 1) ? bc_hi(Q[s >> 1]) : bc_lo(Q[s >> 1]), mk2(qc[s][0], qc[s][1]), hj);
-                    pbs = g * bc_hi(P[s]);
+                    pbs = g * US(s);
                     pb[2 * s] = lo2(pbs);
                     pb[2 * s + 1] = hi2(pbs);
                     S1[s] = vfma2(g, mk2(qb[s][0], qb[s][1]), S1[s]);
                     const vf2 r = g * w[s];
                     S2[s] = vfma2(A2j, r, S2[s]);
-                    dAj = vfma2(bc_lo(P[s]), r, dAj);
+                    dAj = vfma2(DS(s), r, dAj);
                     hj = a[s] * g;
                 }
             }
@@ -1019,27 +1032,59 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             }
         }
         AUM_SCHED_FENCE();
-        AUM_UNROLL
-        for (int s = 0; s < SCANT_CK; ++s) {
-            if (FULL || (s >= s_lo && s < s_hi)) {
-                const vi off = el_off + s * LROW;
-                const vf dls = lo2(P[s]), dys = (s & 1) ? hi2(Q[s >> 1]) : lo2(Q[s >> 1]);
-                const vf us = raw_to_f32<T>(rus[s]);
-                const vf s1 = lo2(S1[s]) + hi2(S1[s]), s2 = lo2(S2[s]) + hi2(S2[s]);
-                vf du = dls * s1;
-                vf dd = vfma(us, s1, s2 * LN2);
+        if constexpr (FULL) {
+            // two steps per packed instruction; the two running sums (dD, dbias) keep their step order (one fma / add per step): bit-equal to the
+            // step-by-step form below
+            const vf2 Dv2 = spl2(Dv), one2 = spl2(splat(1.f));
+            AUM_UNROLL
+            for (int i = 0; i < SCANT_CK / 2; ++i) {
+                const int s0 = 2 * i, s1 = 2 * i + 1;
+                const vf2 dls = Pd[i], dys = Q[i];
+                const vf2 us = mk2(raw_to_f32<T>(rus[s0]), raw_to_f32<T>(rus[s1]));
+                const vf2 s1v = mk2(lo2(S1[s0]) + hi2(S1[s0]), lo2(S1[s1]) + hi2(S1[s1]));
+                const vf2 s2v = mk2(lo2(S2[s0]) + hi2(S2[s0]), lo2(S2[s1]) + hi2(S2[s1]));
+                vf2 du = dls * s1v;
+                vf2 dd = vfma2(us, s1v, s2v * spl2(splat(LN2)));
                 if (FINAL) {
-                    du = vfma(Dv, dys, du);
-                    dDacc = vfma(dys, us, dDacc);
+                    du = vfma2(Dv2, dys, du);
+                    dDacc = vfma(lo2(dys), lo2(us), dDacc);
+                    dDacc = vfma(hi2(dys), hi2(us), dDacc);
                     if (LD_PART) {
-                        du = du + raw_to_f32<T>(rpu[s]);
-                        dd = dd + raw_to_f32<T>(rpd[s]);
+                        du = du + mk2(raw_to_f32<T>(rpu[s0]), raw_to_f32<T>(rpu[s1]));
+                        dd = dd + mk2(raw_to_f32<T>(rpd[s0]), raw_to_f32<T>(rpd[s1]));
                     }
-                    if (SP) dd = dd * (splat(1.f) - vexp2(dls * (-LOG2E)));      // sigmoid(raw) = 1 - exp(-softplus(raw))
-                    dbacc = dbacc + dd;
+                    if (SP) dd = dd * (one2 - vexp2_2(dls * spl2(splat(-LOG2E))));      // sigmoid(raw) = 1 - exp(-softplus(raw))
+                    dbacc = dbacc + lo2(dd);
+                    dbacc = dbacc + hi2(dd);
                 }
-                lds_write_elem<T>(t_du, off, du);
-                lds_write_elem<T>(t_dd, off, dd);
+                lds_write_elem<T>(t_du, el_off + s0 * LROW, lo2(du));
+                lds_write_elem<T>(t_du, el_off + s1 * LROW, hi2(du));
+                lds_write_elem<T>(t_dd, el_off + s0 * LROW, lo2(dd));
+                lds_write_elem<T>(t_dd, el_off + s1 * LROW, hi2(dd));
+            }
+        } else {
+            AUM_UNROLL
+            for (int s = 0; s < SCANT_CK; ++s) {
+                if (s >= s_lo && s < s_hi) {
+                    const vi off = el_off + s * LROW;
+                    const vf dls = (s & 1) ? hi2(Pd[s >> 1]) : lo2(Pd[s >> 1]), dys = (s & 1) ? hi2(Q[s >> 1]) : lo2(Q[s >> 1]);
+                    const vf us = raw_to_f32<T>(rus[s]);
+                    const vf s1 = lo2(S1[s]) + hi2(S1[s]), s2 = lo2(S2[s]) + hi2(S2[s]);
+                    vf du = dls * s1;
+                    vf dd = vfma(us, s1, s2 * LN2);
+                    if (FINAL) {
+                        du = vfma(Dv, dys, du);
+                        dDacc = vfma(dys, us, dDacc);
+                        if (LD_PART) {
+                            du = du + raw_to_f32<T>(rpu[s]);
+                            dd = dd + raw_to_f32<T>(rpd[s]);
+                        }
+                        if (SP) dd = dd * (splat(1.f) - vexp2(dls * (-LOG2E)));      // sigmoid(raw) = 1 - exp(-softplus(raw))
+                        dbacc = dbacc + dd;
+                    }
+                    lds_write_elem<T>(t_du, off, du);
+                    lds_write_elem<T>(t_dd, off, dd);
+                }
             }
         }
         wave_lds_fence();

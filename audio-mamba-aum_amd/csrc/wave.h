@@ -455,6 +455,11 @@ template <class T> AUM_DEV vh gbuf_load8(const gbuf<T>& b, vi voff_bytes, int so
     q.w[0] = v.x; q.w[1] = v.y;
     return q;
 }
+template <class T> AUM_DEV void gbuf_store8(const gbuf<T>& b, vi voff_bytes, int soff_bytes, const vh& q) {
+    typedef int i2 __attribute__((ext_vector_type(2)));
+    const i2 u = {q.w[0], q.w[1]};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(b.r, 0, 0, 0)), u), b.r, voff_bytes, soff_bytes, 0);
+}
 template <class T> AUM_DEV void gbuf_store8_m(const gbuf<T>& b, vi voff_bytes, int soff_bytes, const vh& q, vm m) {
     typedef int i2 __attribute__((ext_vector_type(2)));
     const i2 u = {q.w[0], q.w[1]};
@@ -790,6 +795,13 @@ template <class T> inline vh gbuf_load8(const gbuf<T>& b, const vi& voff_bytes, 
 }
 template <class T> inline void gbuf_store8_m(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes, const vh& q, const vm& m) {
     AUM_LANES if (m.v[l]) {
+        int t[2];
+        for (int k = 0; k < 2; ++k) t[k] = q.w[k].v[l];
+        std::memcpy((char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes, t, 8);
+    }
+}
+template <class T> inline void gbuf_store8(const gbuf<T>& b, const vi& voff_bytes, int soff_bytes, const vh& q) {
+    AUM_LANES {
         int t[2];
         for (int k = 0; k < 2; ++k) t[k] = q.w[k].v[l];
         std::memcpy((char*)b.p + (int64_t)voff_bytes.v[l] + soff_bytes, t, 8);

@@ -67,8 +67,22 @@ def main():
         for c, fn in cfgs.items():
             for k, lib in libs.items():
                 res[c][k].append(timeit(lambda: fn(lib)))
-    for c in cfgs:
-        print(json.dumps({"config": c, **{k: round(statistics.median(v), 4) for k, v in res[c].items()}}), flush=True)
+    def flat(o):
+        if isinstance(o, dict):
+            return [(k, v) for k, v in sorted(o.items()) if v is not None]
+        return [(str(i), v) for i, v in enumerate(o) if v is not None]
+
+    for c, fn in cfgs.items():
+        line = {"config": c, **{k: round(statistics.median(v), 4) for k, v in res[c].items()}}
+        # are the variants' results the default's, bit for bit?  (a re-cut that keeps every IEEE operation and its order must be)
+        ref = [(k, v.clone()) for k, v in flat(fn(libs["default"]))]
+        for name, lib in libs.items():
+            if name == "default":
+                continue
+            got = dict(flat(fn(lib)))
+            bad = [k for k, v in ref if not torch.equal(v, got[k])]
+            line["equal_" + name] = "bit-equal" if not bad else "differs: " + ",".join(bad)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
