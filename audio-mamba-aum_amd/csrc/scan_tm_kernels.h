@@ -30,6 +30,9 @@ namespace aum {
 #ifndef AUM_SCANT_ABL
 #define AUM_SCANT_ABL 0
 #endif
+#ifndef AUM_SCANT_FWD_PAIRS
+#define AUM_SCANT_FWD_PAIRS 1      // 0 (A/B builds): the forward's blocks step by step, as until round 5
+#endif
 constexpr int SCANT_N = 16;                    // states per channel (Mamba's d_state; the only instantiation)
 constexpr int SCANT_CK = AUM_SCAN_TM_CK;       // steps per checkpoint block
 constexpr int SCANT_G = SCANT_CK / 2;          // steps per prefetch group (two groups in flight, ping-pong)
@@ -328,6 +331,91 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
         if (!(AUM_SCANT_ABL & 32)) lds_write_elem<T>(t_o, off, tot);
         else x[0] = x[0] + spl2(tot * 1e-30f);
     };
+    // Four steps [s0, s0 + 4) of a block that lies inside the phase (round 6): the per-step values -- unpack, softplus, delta u, the gate -- are
+    // formed for PAIRS of steps on packed fp32 ahead of the recurrence (the same IEEE operations in the same order as `step`, bit-equal), and a
+    // pair's outputs (D u skip, partial, gate) leave together behind its second step.  Bq: B of step s0 on entry, of step s0 + 4 on exit
+    // (more_b).  (r04_isa_mix_tm.txt: 28 of a step's ~80 vector-ALU instructions were this per-step work, one step at a time.)
+    auto steps4 = [&](int s0, const float* bc, vf2 (&Bq)[N / 2], bool more_b) {
+        vi ru[4], rd[4], rz[4], rp[4];
+        AUM_UNROLL
+        for (int q = 0; q < 4; ++q) {
+            const vi off = el_off + (s0 + q) * ROWB;
+            ru[q] = lds_read_raw<T>(t_u, off);
+            rd[q] = lds_read_raw<T>(t_d, off);
+            if (LD_Z) rz[q] = lds_read_raw<T>(t_z, off);
+            if (LD_PART) rp[q] = lds_read_raw<T>(t_p, off);
+        }
+        vf2 Pd[2], Pu[2], Us[2], G[2];
+        const vf2 bias2 = spl2(biasv), Dv2 = spl2(Dv);
+        AUM_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            Us[i] = mk2(raw_to_f32<T>(ru[2 * i]), raw_to_f32<T>(ru[2 * i + 1]));
+            vf2 d = mk2(raw_to_f32<T>(rd[2 * i]), raw_to_f32<T>(rd[2 * i + 1])) + bias2;
+            if (SP) d = vsoftplus2(d);
+            Pd[i] = d;
+            Pu[i] = d * Us[i];
+            if (LD_Z) {
+                const vf2 zz = mk2(raw_to_f32<T>(rz[2 * i]), raw_to_f32<T>(rz[2 * i + 1]));
+                G[i] = zz * vsigmoid2(zz);
+            }
+        }
+        vf ys_even = splat(0.f);
+        AUM_UNROLL
+        for (int q = 0; q < 4; ++q) {
+            const int s = s0 + q;
+            const float* bcrow = bc + s * SCANT_BC_ROW;
+            vf2 Cp[N / 2], Bn[N / 2];
+            AUM_UNROLL
+            for (int k = 0; k < N / 4; ++k) {
+                vf c4[4];
+                lds_read4_u(bcrow, N + 4 * k, c4);
+                Cp[2 * k] = mk2(c4[0], c4[1]);
+                Cp[2 * k + 1] = mk2(c4[2], c4[3]);
+            }
+            const bool pf = q < 3 || more_b;
+            if (pf) read_B(bcrow + SCANT_BC_ROW, Bn);
+            AUM_SCHED_FENCE();
+            const vf2 dl2 = (q & 1) ? bc_hi(Pd[q >> 1]) : bc_lo(Pd[q >> 1]);
+            const vf2 du2 = (q & 1) ? bc_hi(Pu[q >> 1]) : bc_lo(Pu[q >> 1]);
+            vf2 a[N / 2];
+            AUM_UNROLL
+            for (int j = 0; j < N / 2; ++j) a[j] = dl2 * A2[j];
+            AUM_UNROLL
+            for (int j = 0; j < N / 2; ++j) Bq[j] = du2 * Bq[j];
+            AUM_UNROLL
+            for (int j = 0; j < N / 2; ++j) a[j] = vexp2_2(a[j]);
+            AUM_UNROLL
+            for (int j = 0; j < N / 2; ++j) x[j] = vfma2(a[j], x[j], Bq[j]);
+            vf2 y2[4];
+            AUM_UNROLL
+            for (int j = 0; j < 4; ++j) y2[j] = x[j] * Cp[j];
+            AUM_UNROLL
+            for (int j = 4; j < N / 2; ++j) y2[j & 3] = vfma2(x[j], Cp[j], y2[j & 3]);
+            const vf2 ysum = (y2[0] + y2[1]) + (y2[2] + y2[3]);
+            const vf ys = lo2(ysum) + hi2(ysum);
+            if (PHASE == 1) {
+                lds_write_elem<T>(t_o, el_off + s * ROWB, ys);
+            } else if ((q & 1) == 0) {
+                ys_even = ys;
+            } else {
+                const int i = q >> 1;
+                const vi off0 = el_off + (s - 1) * ROWB, off1 = el_off + s * ROWB;
+                vf2 tot = vfma2(Us[i], Dv2, mk2(ys_even, ys));
+                if (PHASE == 2) tot = tot + mk2(raw_to_f32<T>(rp[q - 1]), raw_to_f32<T>(rp[q]));
+                if (ST_PRE) {
+                    lds_write_elem<T>(t_pre, off0, lo2(tot));
+                    lds_write_elem<T>(t_pre, off1, hi2(tot));
+                }
+                if (HAS_Z) tot = tot * G[i];
+                lds_write_elem<T>(t_o, off0, lo2(tot));
+                lds_write_elem<T>(t_o, off1, hi2(tot));
+            }
+            if (pf) {
+                AUM_UNROLL
+                for (int j = 0; j < N / 2; ++j) Bq[j] = Bn[j];
+            }
+        }
+    };
     auto ckpt_store = [&](int blk) {
         int off = blk * CKR * p.dim * 4;
         if constexpr (CKR == N) {
@@ -386,7 +474,13 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
         if (more) request(blk + 1, nx);
         AUM_TM_STAMP(1);
         const float* bc = t_bc + (blk & 1) * SCANT_BC_BLOCK;
-        if (base >= it0 && base + SCANT_CK <= it1) {
+        if (base >= it0 && base + SCANT_CK <= it1 && !CARRY && !AUM_SCANT_ABL && AUM_SCANT_FWD_PAIRS) {
+            vf2 Bq[N / 2];
+            read_B(bc, Bq);
+            steps4(0, bc, Bq, true);
+            steps4(4, bc, Bq, false);
+            if (want_ck && blk < nck) ckpt_store(blk);
+        } else if (base >= it0 && base + SCANT_CK <= it1) {
             ScanTRaw r;
             vf2 Bq[N / 2];
             read_raw(0, r);

@@ -63,10 +63,14 @@ def main():
         _, pre_sp = aum_hip.scan_tm_fwd(u, dl, A, Bm, Cm, D, z, bias, True, A_b=A_b, want_out_pre=True, ckpt=ck2)
         cfgs["bwd_bidir_sp"] = lambda lib: aum_hip.scan_tm_bwd(u, dl, A, Bm, Cm, D, z, bias, dout, pre_sp, ck2, True, A_b=A_b, lib=lib)
     res = {c: {k: [] for k in libs} for c in cfgs}
-    for rep in range(3):
+    # the library timed first in a group runs ~3 % behind an identical copy timed later (gpurun_out/r6_tm_ab_fwd_pairs.txt: "default" against "same"):
+    # the order rotates with the round, and there are as many rounds as libraries (at least three)
+    names = list(libs)
+    for rep in range(max(3, len(names))):
+        order = names[rep % len(names):] + names[:rep % len(names)]
         for c, fn in cfgs.items():
-            for k, lib in libs.items():
-                res[c][k].append(timeit(lambda: fn(lib)))
+            for k in order:
+                res[c][k].append(timeit(lambda: fn(libs[k])))
     def flat(o):
         if isinstance(o, dict):
             return [(k, v) for k, v in sorted(o.items()) if v is not None]
