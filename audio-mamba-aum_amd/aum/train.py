@@ -113,6 +113,15 @@ def check_scope(args):
         raise NotImplementedError("no / double / randomly placed cls tokens are off the accelerated path")
 
 
+
+def free_port():
+    """a TCP port the kernel hands out as free right now (rendezvous of a world-size-1 process group)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 class Dist:
     """the few things the reference uses `accelerator` for"""
 
@@ -132,7 +141,7 @@ class Dist:
         if self.ddp and not dist.is_initialized():
             if self.world == 1:
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29533")
+                os.environ.setdefault("MASTER_PORT", str(free_port()))      # two forced-DDP runs on one box must not meet on a fixed port
                 os.environ.setdefault("RANK", "0")
                 os.environ.setdefault("WORLD_SIZE", "1")
             backend = os.environ.get("AUM_DIST_BACKEND", "nccl" if self.cuda else "gloo")
@@ -189,7 +198,7 @@ def compress_gradients(ddp, kind):
     from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
     inner = {"no": default_hooks.allreduce_hook, "bf16": default_hooks.bf16_compress_hook, "fp16": default_hooks.fp16_compress_hook}[kind]
     if any(getattr(m, "bimamba_type", None) == "v2" for m in ddp.modules()):
-        ddp.register_comm_hook(None, ssi.ddp_join_streams_hook(inner))      # Bi-Bi blocks: two backward streams to join
+        ssi.register_ddp_join_streams(ddp, None, inner)      # Bi-Bi blocks: two backward streams to join; marks THIS wrapper's blocks
     else:
         # "no" is registered too (the reducer's own exchange, as a hook): without a hook the reducer divides every gradient that already
         # lives in its bucket (ssi.adopt_grad_homes) by the world size one launch per parameter; the hook divides the bucket once

@@ -543,7 +543,7 @@ def scan_tm_ckpt(batch, length, dim, dstate, bidir, device, lib=None, dtype=torc
 SCAN_TM_MAX_SEGMENTS = 32
 
 
-def scan_tm_segments(batch, dim, length, bidir, training=False, nsimd=None):
+def scan_tm_segments(batch, dim, length, bidir, training=False, nsimd=None, device=None):
     """time segments a token-major launch of this shape is cut into (1: not cut).  One wave per (batch entry, 64 channels, direction)
     leaves most SIMDs idle at a small batch while every wave walks the whole row; segments multiply the waves at the price of one
     carry pass (the recurrence once more, without outputs).  Rows are cut only when they are long (>= 1024 steps) and the uncut launch is
@@ -551,7 +551,7 @@ def scan_tm_segments(batch, dim, length, bidir, training=False, nsimd=None):
     launch of its own), ranges no shorter than 128 steps.  Measured at B = 8, L = 4097, E = 1536 (profiles/r04_seg_time.json): 16
     ranges are the fastest cut for the forward (three resident waves per SIMD: one round) AND for the backward (two resident: 11 or
     12 ranges leave a tail round, 16 is 1.5 rounds of shorter waves) -- 0.68 / 1.39 ms against 1.29 / 5.03 ms uncut."""
-    nsimd = 4 * cu_count() if nsimd is None else nsimd          # MI355X: 256 CUs x 4 SIMDs
+    nsimd = 4 * cu_count(device) if nsimd is None else nsimd          # MI355X: 256 CUs x 4 SIMDs; `device`: the operands' (default: current)
     per_dir = batch * (dim // 64)
     waves = per_dir * (2 if bidir else 1)
     if per_dir <= 0 or waves * 2 > nsimd or length < 1024:
@@ -720,9 +720,9 @@ def cu_count(device=None):
     return n
 
 
-def gemm_wgrad_splits(n, k, ncu=None):
+def gemm_wgrad_splits(n, k, ncu=None, device=None):
     """token splits that give every CU one workgroup: (n / 256) (k / 256) output tiles x splits ~ the CU count"""
-    ncu = cu_count() if ncu is None else ncu
+    ncu = cu_count(device) if ncu is None else ncu
     tiles = (n // 256) * max(1, k // 256)          # a skinny operand (k = 48 / 80) is one column tile
     return max(1, min(64, ncu // max(tiles, 1)))
 
@@ -736,7 +736,7 @@ def gemm_wgrad_supported(y, x, splits=None):
             and y.stride(0) % 8 == 0 and y.stride(0) >= y.shape[1] and x.stride(0) >= x.shape[1]
             and x.stride(0) % 8 == 0 and y.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and y.shape[0] > 0):
         return False
-    splits = splits or gemm_wgrad_splits(y.shape[1], x.shape[1])
+    splits = splits or gemm_wgrad_splits(y.shape[1], x.shape[1], device=y.device if y.is_cuda else None)
     if not 0 < splits <= 64:
         return False
     chunk = (-(-y.shape[0] // splits) + 63) // 64 * 64
@@ -749,7 +749,7 @@ def gemm_wgrad(y, x, splits=None, lib=None, partials=False, out=None):
     lib = lib or get()
     t, n = y.shape
     k = x.shape[1]
-    splits = splits or gemm_wgrad_splits(n, k)
+    splits = splits or gemm_wgrad_splits(n, k, device=y.device if y.is_cuda else None)
     if not gemm_wgrad_supported(y, x, splits):
         raise RuntimeError("gemm_wgrad: operands outside the kernel's limits (see gemm_wgrad_supported)")
     lib.check_tensor(y)

@@ -128,7 +128,7 @@ class Mamba(nn.Module):
                 # the bench shape (half of what the time-serial kernels hold), so the two run next to each other on two side streams
                 # (forward here; autograd runs each pipeline's backward on the stream its forward ran on; why BOTH leave the calling
                 # stream: ssi.side_streams).  AUM_V2_STREAMS=0: in line.
-                two = tm and xz.is_cuda and ssi.v2_two_streams((self.conv1d_b.weight, self.x_proj_b.weight, self.dt_proj_b.weight))
+                two = tm and xz.is_cuda and ssi.v2_two_streams(tuple(self.parameters()), module=self)
                 if two:
                     main = torch.cuda.current_stream(xz.device)
                     s_f, s_b = ssi.side_streams(xz.device)

@@ -488,20 +488,19 @@ def _mm_rows(a, b, bit):
 _V2_STREAMS = _dbg_env("AUM_V2_STREAMS", "1") != "0"        # Bi-Bi: the second pipeline on a side stream (mamba_simple.py); 0: in line (A/B)
 _side_streams = {}
 _main_streams = {}
-_DDP_STREAM_JOIN = False        # set by ddp_join_streams_hook: the gradient exchange waits for BOTH backward streams
-
-
-def v2_two_streams(params=()):
+def v2_two_streams(params=(), module=None):
     """Bi-Bi's second pipeline on a side stream?  Autograd runs each pipeline's backward on the stream of its forward, so anything that
     consumes a parameter gradient INSIDE backward sees two producer streams.  DistributedDataParallel's reducer orders a bucket's
     all-reduce behind the stream of the LAST gradient hook only, and a bucket holds gradients of both pipelines: under an initialised
-    process group (any world size) the side stream is used only when the gradient exchange goes through `ddp_join_streams_hook`
-    (aum.train.compress_gradients registers it for models with Bi-Bi blocks), which makes the exchange wait for both streams.  Parameters that carry
-    post-accumulate-grad hooks (FSDP, user hooks: `params`, the side pipeline's) keep the pipelines in line as well."""
+    process group (any world size) the side streams are used only by blocks of a model whose OWN wrapper exchanges gradients through
+    `ddp_join_streams_hook` -- `register_ddp_join_streams(ddp)` (what aum.train.compress_gradients calls for models with Bi-Bi blocks)
+    registers the hook and marks that wrapper's blocks (`module._aum_streams_joined`); a second wrapper in the same process without the hook,
+    or a hook that was built but never registered, leaves its blocks in line.  Parameters that carry post-accumulate-grad hooks (FSDP,
+    optimizer-in-backward, user hooks: `params` = every parameter touched inside the two side-stream regions) keep the pipelines in line too."""
     if not _V2_STREAMS:
         return False
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and not _DDP_STREAM_JOIN:
+    if dist.is_available() and dist.is_initialized() and not getattr(module, "_aum_streams_joined", False):
         return False
     return not any(getattr(p_, "_post_accumulate_grad_hooks", None) for p_ in params)
 
@@ -521,9 +520,9 @@ def side_streams(device):
 
 def ddp_join_streams_hook(hook=None):
     """A DistributedDataParallel communication hook that first makes the CURRENT stream (the one the reducer orders the bucket's
-    collective behind) wait for the other stream Bi-Bi's backward runs on, then hands the bucket to `hook` (default: the plain
-    all-reduce + mean).  Registering it is what allows v2_two_streams() under a process group.  TT:39, TT:168."""
-    global _DDP_STREAM_JOIN
+    collective behind) wait for the other streams Bi-Bi's backward runs on, then hands the bucket to `hook` (default: the plain
+    all-reduce + mean).  Use `register_ddp_join_streams`, which also tells the wrapper's blocks that they may leave the calling stream.
+    TT:39, TT:168."""
     from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
     inner = hook or default_hooks.allreduce_hook
 
@@ -536,8 +535,16 @@ def ddp_join_streams_hook(hook=None):
                     cur.wait_stream(s)
         return inner(state, bucket)
 
-    _DDP_STREAM_JOIN = True
     return joined
+
+
+def register_ddp_join_streams(ddp, state=None, hook=None):
+    """register `ddp_join_streams_hook(hook)` on THIS DistributedDataParallel wrapper and allow the Bi-Bi blocks it wraps to run their two
+    pipelines on side streams (the permission is a flag on each block, not a process-wide latch: ADVICE r5)."""
+    ddp.register_comm_hook(state, ddp_join_streams_hook(hook))
+    for m in ddp.module.modules():
+        if getattr(m, "bimamba_type", None) == "v2":
+            m._aum_streams_joined = True
 
 
 _XDT_BWD_HIP = _dbg_env("AUM_XDT_BWD_LIB", "0") != "1"      # AUM_DEBUG=1 AUM_XDT_BWD_LIB=1: the x_proj / dt_proj gradients as five library calls (A/B)
@@ -657,12 +664,12 @@ _TM_MIN_WAVES = int(_dbg_env("AUM_TM_MIN_WAVES", "1536"))
 _TM_SEGMENTS = int(_dbg_env("AUM_TM_SEGMENTS", "-1"))
 
 
-def tm_segments(batch, d_inner, seqlen, bidirectional, training):
+def tm_segments(batch, d_inner, seqlen, bidirectional, training, device=None):
     if _TM_SEGMENTS == 0 or seqlen is None:
         return 1
     if _TM_SEGMENTS > 1:
         return min(_TM_SEGMENTS, aum_hip.SCAN_TM_MAX_SEGMENTS)
-    return aum_hip.scan_tm_segments(batch, d_inner, seqlen, bidirectional, training)
+    return aum_hip.scan_tm_segments(batch, d_inner, seqlen, bidirectional, training, device=device)
 
 
 def token_major_preferred(batch, d_inner, bidirectional, training=None, seqlen=None):
@@ -729,7 +736,7 @@ def _inner_forward_tm(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_
     cut = waves < (-(-_TM_MIN_WAVES * 4 // 3) if need_bwd and A_b is not None else _TM_MIN_WAVES)
     out_z, out_pre = aum_hip.scan_tm_fwd(conv_out, delta.view(Bsz, L, E), A, Bm, Cm, D, z, delta_bias, delta_softplus,
                                          reverse if A_b is None else False, A_b=A_b, want_out_pre=need_bwd, ckpt=ckpt,
-                                         segments=tm_segments(Bsz, E, L, A_b is not None, False) if cut else 1)
+                                         segments=tm_segments(Bsz, E, L, A_b is not None, False, device=xz.device) if cut else 1)
     ctx.tm_cut = cut
     # the scan backward forms d A .* A only for an A that neg_exp took out of THIS forward's cache (its _NegExpFn node is the consumer)
     ctx.A_cached = (need_bwd and A.dtype == torch.float32 and A.is_contiguous() and A.data_ptr() in _A_CACHE_PTRS
@@ -777,7 +784,7 @@ def _inner_backward_tm(ctx, dout):
     x3 = x_dbl.view(Bsz, L, R + 2 * N)
     g = aum_hip.scan_tm_bwd(conv_out, delta.view(Bsz, L, E), A, x3[:, :, R:R + N], x3[:, :, R + N:], D, z, delta_bias, dout_z, out_pre,
                             ckpt, ctx.delta_softplus, ctx.reverse if A_b is None else False, A_b=A_b, dz_out=dz,
-                            segments=tm_segments(Bsz, E, L, A_b is not None, True) if ctx.tm_cut else 1,
+                            segments=tm_segments(Bsz, E, L, A_b is not None, True, device=conv_out.device) if ctx.tm_cut else 1,
                             want_dA_xA=ctx.A_cached,
                             param_out=dict(dD=H["D"], ddelta_bias=H["dt_bias"], dA_xA=H["A_log"], dA_b_xA=H["A_b_log"]))        # SSI:541-561
     if ctx.A_cached:            # A came out of the forward's cache (neg_exp): its d A_log is ready (see _NegExpFn)

@@ -267,7 +267,11 @@ def main():
     force_ddp = os.environ.get("AUM_BENCH_FORCE_DDP", "0") == "1"
     if world == 1 and force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
+        if "MASTER_PORT" not in os.environ:       # a port the kernel hands out as free: two forced-DDP runs on one box must not collide
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
     if world > 1 or force_ddp:

@@ -47,7 +47,10 @@ def main():
                                                         broadcast_buffers=False)
         homes = compress_gradients(ddp, comp)  # registers the exchange hook (Bi-Bi: ssi.ddp_join_streams_hook(...): from here on it may use its side stream)
         opts = [torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=5e-7, betas=(0.95, 0.999), eps=1e-8, fused=True) for m in (model, ref)]
-        rec = {"two_streams": bool(ssi.v2_two_streams()), "steps": []}
+        # the permission is per wrapped model: this wrapper's Bi-Bi blocks carry it, a block outside any hooked wrapper does not
+        v2_blocks = [m_ for m_ in model.modules() if getattr(m_, "bimamba_type", None) == "v2"]
+        rec = {"two_streams": bool(v2_blocks) and all(ssi.v2_two_streams(module=m_) for m_ in v2_blocks), "steps": []}
+        assert not ssi.v2_two_streams(), "a block that no hooked wrapper marked stays in line under a process group"
         hits0 = ssi.HOME_HITS[0]
         for step in range(4):
             losses = []
