@@ -38,6 +38,15 @@ namespace aumg {
 #ifndef AUM_PS_DEAD_WAVES
 #define AUM_PS_DEAD_WAVES 1     // 0: A/B build -- waves without live rows multiply zeros (as until the split last round)
 #endif
+#ifndef AUM_PS_AUX_A
+#define AUM_PS_AUX_A 0      // cache-policy bits of the activation pieces' loads (gfx950: 1 sc0, 2 nt, 16 sc1); experiments
+#endif
+#ifndef AUM_PS_AUX_B
+#define AUM_PS_AUX_B 0      // the same for the weight pieces
+#endif
+#ifndef AUM_PS_COLGROUPS
+#define AUM_PS_COLGROUPS 0  // 1: in complete rounds an XCD's 32 items come from ONE half of the column tiles (even XCDs the lower half, odd the upper)
+#endif
 #ifndef AUM_PS_ABL
 #define AUM_PS_ABL 0        // timing experiments only (wrong results): 1 no DMA pieces in the steps, 2 no stores, 4 no MFMAs, 8 every store dropped by the range check,
                             // 16 every tile reads the activation rows of row block 0 (L2 hits), 32 the weight rows of column tile 0 (first kernel only)
@@ -72,9 +81,17 @@ __device__ __forceinline__ void ps_item(const GemmLaunch& L, int id, int ntn, in
     }
     const int h = item - L.nwhole;                      // >= 0: half h & 1 of tile nwhole + (h >> 1)
     const int tile = h < 0 ? item : L.nwhole + (h >> 1);
-    const int tm = tile / ntn;
+    int tm = tile / ntn, tn = tile - tm * ntn;
+    if (AUM_PS_COLGROUPS) {
+        const int region = L.nwhole / grid * grid, hn = ntn >> 1;
+        if (grid == 256 && ntn >= 6 && (ntn & 1) == 0 && region % (2 * ntn) == 0 && (region / 2) % 32 == 0 && item < region) {
+            const int b = item >> 5, s = (b >> 1) * 32 + (item & 31);
+            tm = s / hn;
+            tn = (b & 1) * hn + (s - tm * hn);
+        }
+    }
     m0 = tm * BM;
-    n0 = (tile - tm * ntn) * BN;
+    n0 = tn * BN;
     int span = BM;
     if (h >= 0) {
         m0 += (h & 1) * (BM / 2);
@@ -131,9 +148,10 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_ps(GemmLaunch L) {
     // piece n of a K-step (n < 4: activation rows, else weight rows) into stage `dst`
     auto piece = [&](__amdgpu_buffer_rsrc_t ra_s, __amdgpu_buffer_rsrc_t rb_s, int kbyte, char* dst, int n) {
         if (AUM_PS_ABL & 1) return;
-        if (n < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_s, (lds_ptr_t)(dst + (n * 8 + w) * 1024), 16, voff_a, kbyte + n * rowstep_a, 0, 0);
+        if (AUM_PS_ABL & 64) ra_s = rb_s = r_null;          // 64: every piece out of range (issued, zero-filled, no memory traffic)
+        if (n < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_s, (lds_ptr_t)(dst + (n * 8 + w) * 1024), 16, voff_a, kbyte + n * rowstep_a, 0, AUM_PS_AUX_A);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_s, (lds_ptr_t)(dst + TILE_BYTES + ((n - 4) * 8 + w) * 1024), 16, voff_b,
-                                                      kbyte + (n - 4) * rowstep_b, 0, 0);
+                                                      kbyte + (n - 4) * rowstep_b, 0, AUM_PS_AUX_B);
     };
 
     s8v bfA[4], bfB[4], af[4];
@@ -146,8 +164,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_ps(GemmLaunch L) {
     if (!(AUM_PS_ABL & 1)) {
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
-            if (n < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds + (n * 8 + w) * 1024), 16, voff_a, n * rowstep_a, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds + TILE_BYTES + ((n - 4) * 8 + w) * 1024), 16, voff_b, (n - 4) * rowstep_b, 0, 0);
+            if (n < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds + (n * 8 + w) * 1024), 16, voff_a, n * rowstep_a, 0, AUM_PS_AUX_A);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds + TILE_BYTES + ((n - 4) * 8 + w) * 1024), 16, voff_b, (n - 4) * rowstep_b, 0, AUM_PS_AUX_B);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
