@@ -3,10 +3,6 @@
 #include <atomic>
 #include "gemm_kernels.h"
 #include "gemm_ps_kernels.h"
-#include "gemm_r3_kernels.h"
-#ifndef AUM_GEMM_R3
-#define AUM_GEMM_R3 0       // 1: the paced kernel with the activation tiles in a ring of three LDS slots (gemm_r3_kernels.h)
-#endif
 #include "dtproj_kernels.h"
 #include "xdt_kernels.h"
 #include "decode_kernels.h"
@@ -45,10 +41,7 @@ extern "C" int aum_gemm_tn(const AumGemmArgs* p, void* stream) {
         L.g = g;
         aumg::gemm_ps_items(g.m, g.n, ncu, &L);
         const int grid = L.nitems < ncu ? L.nitems : ncu;
-        if (AUM_GEMM_R3) {
-            if (g.dtype == AUM_BF16) hipLaunchKernelGGL(aumg::k_gemm_tn_r3<true>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
-            else hipLaunchKernelGGL(aumg::k_gemm_tn_r3<false>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
-        } else if (g.dtype == AUM_BF16) hipLaunchKernelGGL(aumg::k_gemm_tn_ps<true>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
+        if (g.dtype == AUM_BF16) hipLaunchKernelGGL(aumg::k_gemm_tn_ps<true>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
         else hipLaunchKernelGGL(aumg::k_gemm_tn_ps<false>, dim3(grid), dim3(aumg::THREADS), 0, s, L);
         return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
     }

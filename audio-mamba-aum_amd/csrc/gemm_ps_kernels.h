@@ -29,7 +29,10 @@
 // kernel lost); L2 prefetch touches three steps ahead (64 lines per 4-byte load are 64 tag look-ups in the CU's L1); skipping the MFMAs of
 // fragment rows beyond M (a scalar test per MFMA costs every tile 20 %; a second copy of the steps for ragged tiles makes the register
 // allocator move the accumulators between the copies: 112 spills); two copies of the loop for the two waves of a SIMD with their pieces
-// and stores at different MFMAs (level).
+// and stores at different MFMAs (level).  Second session of round 6 (profiles/r06_gemm_ring3.txt, commit b425e1a): the activation or the weight tiles in
+// a ring of three LDS slots (the weights' piece stream 20 % faster, the kernel level), non-temporal loads (-15..30 %), an XCD's items from one
+// half of the column tiles (level) -- and the ablation that explains them: with every operand line an L2 hit the kernel is no faster; fragment
+// reads + arriving pieces are 256 KB of LDS traffic per K-step and CU = the 2 048 clocks the step's MFMAs take.
 #pragma once
 #include "gemm_kernels.h"
 
@@ -37,15 +40,6 @@ namespace aumg {
 
 #ifndef AUM_PS_DEAD_WAVES
 #define AUM_PS_DEAD_WAVES 1     // 0: A/B build -- waves without live rows multiply zeros (as until the split last round)
-#endif
-#ifndef AUM_PS_AUX_A
-#define AUM_PS_AUX_A 0      // cache-policy bits of the activation pieces' loads (gfx950: 1 sc0, 2 nt, 16 sc1); experiments
-#endif
-#ifndef AUM_PS_AUX_B
-#define AUM_PS_AUX_B 0      // the same for the weight pieces
-#endif
-#ifndef AUM_PS_COLGROUPS
-#define AUM_PS_COLGROUPS 0  // 1: in complete rounds an XCD's 32 items come from ONE half of the column tiles (even XCDs the lower half, odd the upper)
 #endif
 #ifndef AUM_PS_ABL
 #define AUM_PS_ABL 0        // timing experiments only (wrong results): 1 no DMA pieces in the steps, 2 no stores, 4 no MFMAs, 8 every store dropped by the range check,
@@ -81,15 +75,7 @@ __device__ __forceinline__ void ps_item(const GemmLaunch& L, int id, int ntn, in
     }
     const int h = item - L.nwhole;                      // >= 0: half h & 1 of tile nwhole + (h >> 1)
     const int tile = h < 0 ? item : L.nwhole + (h >> 1);
-    int tm = tile / ntn, tn = tile - tm * ntn;
-    if (AUM_PS_COLGROUPS) {
-        const int region = L.nwhole / grid * grid, hn = ntn >> 1;
-        if (grid == 256 && ntn >= 6 && (ntn & 1) == 0 && region % (2 * ntn) == 0 && (region / 2) % 32 == 0 && item < region) {
-            const int b = item >> 5, s = (b >> 1) * 32 + (item & 31);
-            tm = s / hn;
-            tn = (b & 1) * hn + (s - tm * hn);
-        }
-    }
+    const int tm = tile / ntn, tn = tile - tm * ntn;
     m0 = tm * BM;
     n0 = tn * BN;
     int span = BM;
@@ -149,9 +135,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_ps(GemmLaunch L) {
     auto piece = [&](__amdgpu_buffer_rsrc_t ra_s, __amdgpu_buffer_rsrc_t rb_s, int kbyte, char* dst, int n) {
         if (AUM_PS_ABL & 1) return;
         if (AUM_PS_ABL & 64) ra_s = rb_s = r_null;          // 64: every piece out of range (issued, zero-filled, no memory traffic)
-        if (n < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_s, (lds_ptr_t)(dst + (n * 8 + w) * 1024), 16, voff_a, kbyte + n * rowstep_a, 0, AUM_PS_AUX_A);
+        if (n < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_s, (lds_ptr_t)(dst + (n * 8 + w) * 1024), 16, voff_a, kbyte + n * rowstep_a, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_s, (lds_ptr_t)(dst + TILE_BYTES + ((n - 4) * 8 + w) * 1024), 16, voff_b,
-                                                      kbyte + (n - 4) * rowstep_b, 0, AUM_PS_AUX_B);
+                                                      kbyte + (n - 4) * rowstep_b, 0, 0);
     };
 
     s8v bfA[4], bfB[4], af[4];
@@ -164,8 +150,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_gemm_tn_ps(GemmLaunch L) {
     if (!(AUM_PS_ABL & 1)) {
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
-            if (n < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds + (n * 8 + w) * 1024), 16, voff_a, n * rowstep_a, 0, AUM_PS_AUX_A);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds + TILE_BYTES + ((n - 4) * 8 + w) * 1024), 16, voff_b, (n - 4) * rowstep_b, 0, AUM_PS_AUX_B);
+            if (n < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds + (n * 8 + w) * 1024), 16, voff_a, n * rowstep_a, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds + TILE_BYTES + ((n - 4) * 8 + w) * 1024), 16, voff_b, (n - 4) * rowstep_b, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
