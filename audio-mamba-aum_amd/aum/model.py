@@ -71,7 +71,11 @@ class FrontendTokensFn(torch.autograd.Function):
         if time_major:                                                          # back to the cell order f * n_t + t
             gp = gp.reshape(Bsz, nt, -1, Dm).transpose(1, 2).reshape(Bsz, -1, Dm)
         g16 = gp.to(dtype).reshape(-1, Dm)                                      # gradient of the 16-bit conv output
-        dweight = (g16.t() @ patches).to(wdtype).reshape(wshape)
+        import aum_hip
+        if g16.is_cuda and aum_hip.gemm_wgrad_supported(g16, patches):          # 3 output tiles x 64 token splits instead of a one-round library GEMM over 32 768 tokens
+            dweight = aum_hip.gemm_wgrad(g16, patches).to(wdtype).reshape(wshape)
+        else:
+            dweight = (g16.t() @ patches).to(wdtype).reshape(wshape)
         dbias = g16.sum(0).to(wdtype)
         dcls = g[:, cls_pos].sum(0)
         dpos = torch.cat((dcls[None], gp.sum(0)), dim=0)[None]
