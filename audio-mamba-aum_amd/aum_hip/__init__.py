@@ -290,10 +290,19 @@ class LaunchTimer:
     def __init__(self):
         self.enabled = False
         self.only = None        # optional set of kernel names to time (two events per launch cost ~8 us of host time)
+        self.every = 1          # bracket every n-th launch of a name only: an event on the stream is a barrier packet, ~6 us of idle GPU each
+                                # (profiles/r06_step_timeline.txt: two 5.8 us gaps around every bracketed launch)
         self.records = {}       # name -> list of (start_event, end_event, meta)
+        self.seen = {}          # name -> launches seen since reset()
 
     def reset(self):
         self.records = {}
+        self.seen = {}
+
+    def want(self, name):
+        n = self.seen.get(name, 0)
+        self.seen[name] = n + 1
+        return n % self.every == 0
 
     def summary(self):
         torch.cuda.synchronize()
@@ -308,7 +317,7 @@ timer = LaunchTimer()
 
 
 def _launch(fn, args, stream_tensor, lib, name, meta=None):
-    if timer.enabled and not lib.host and (timer.only is None or name in timer.only):
+    if timer.enabled and not lib.host and (timer.only is None or name in timer.only) and timer.want(name):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         rc = fn(C_byref(args), lib.stream(stream_tensor))

@@ -343,6 +343,10 @@ def main():
         aum_hip.timer.only = {max(tot_w, key=tot_w.get)}
     aum_hip.timer.reset()
     aum_hip.timer.enabled = True
+    # ... every 5th of them (24 launches per step: 4 or 5 a step, every layer position over five steps): the two events of a bracket are two
+    # barrier packets on the stream, 2 x 5.8 us of idle GPU per bracketed launch -- 0.28 ms per step when all 24 are bracketed
+    # (profiles/r06_step_timeline.txt); `launches_timed` in the roofline object says how many the average is over
+    aum_hip.timer.every = int(os.environ.get("AUM_BENCH_TIMER_EVERY", "5"))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -354,6 +358,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     aum_hip.timer.enabled = False
+    aum_hip.timer.every = 1
     # the same step without the optimizer (SURVEY 8d asks for both figures); a few extra steps, not part of `value`
     def step_no_opt():
         with torch.autocast("cuda", dtype=torch.bfloat16):
