@@ -190,9 +190,10 @@ class AudioMamba(nn.Module):
         hidden, pos = self.tokens(x) if frontend is None else self.tokens_from_wave(x, frontend)
         with step_cache([layer.mixer for layer in self.layers], _autocast_dtype()):     # all blocks' 16-bit weights and A in a few launches
             hidden, residual = self._run_layers(hidden)
-        hidden = rms_norm_fn(hidden, self.norm_f.weight, self.norm_f.bias, eps=self.norm_f.eps, residual=residual,
-                             prenorm=False, residual_in_fp32=True)                            # MM:646-657
-        return hidden[:, pos]
+        # MM:646-657, then the cls row (MM:660-680).  add + RMSNorm is row-wise and only the cls row is read: the final norm runs on
+        # those `batch` rows instead of on all 513 per clip (same values, same gradients; 0.1 ms per step at the bench shape)
+        return rms_norm_fn(hidden[:, pos], self.norm_f.weight, self.norm_f.bias, eps=self.norm_f.eps,
+                           residual=None if residual is None else residual[:, pos], prenorm=False, residual_in_fp32=True)
 
     def _run_layers(self, hidden):
         residual = None
