@@ -26,7 +26,7 @@ _ERR = {-1: "AUM_E_NULL", -2: "AUM_E_SHAPE", -3: "AUM_E_DTYPE", -4: "AUM_E_UNSUP
         -6: "AUM_E_LAUNCH"}
 
 _i64, _i32, _u32, _vp, _fp = C.c_int64, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class _Debug:
@@ -189,7 +189,7 @@ EXPORTS = ["aum_gemm_tn", "aum_dtproj_tm_fwd", "aum_xdt_tm_fwd", "aum_proj_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows", "aum_sum_rows_multi",
            "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_ckpt_rows", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_scan_tm_seg_fwd", "aum_scan_tm_seg_bwd",
            "aum_scan_tm_seg_carry_bytes", "aum_scan_tm_seg_workspace_bytes", "aum_selftest_wave_sum32",
-           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_gemm_wgrad", "aum_xdt_tm_bwd", "aum_causal_conv1d_update", "aum_selective_state_update"]
+           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_gemm_wgrad", "aum_xdt_tm_bwd", "aum_causal_conv1d_update", "aum_selective_state_update", "aum_cast_bank"]
 
 
 class Lib:
@@ -237,6 +237,7 @@ class Lib:
         self.c.aum_proj_bwd_weight_splits.argtypes = [_i32, _i64]
         self.c.aum_selftest_wave_scan.argtypes = [_vp, _vp, C.c_int, _vp]
         self.c.aum_hbm_copy.argtypes = [_vp, _vp, _i64, _vp]
+        self.c.aum_cast_bank.argtypes = [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]
         self.c.aum_selftest_wave_sum32.argtypes = [_vp, _vp, _vp]
         self.c.aum_sum_rows.argtypes = [_vp, _vp, _i64, _i64, _i64, _i32, _vp]
         self.c.aum_sum_rows_multi.argtypes = [_vp, _i32, _vp]
@@ -1367,6 +1368,37 @@ def sum_rows_multi(parts, tr_cols=None, lib=None, outs=None):
         j.src, j.dst, j.outer, j.inner, j.tr_cols = _ptr(t), _ptr(o), t.shape[0], t[0].numel(), tc
     _chk(lib.c.aum_sum_rows_multi(C.cast(jobs, C.c_void_p), len(parts), lib.stream(parts[0])), "aum_sum_rows_multi")
     return outs
+
+
+_cast_tables = {}
+
+
+def cast_bank(params, dtype, want_t=False, lib=None):
+    """params: equally shaped 2-D fp32 contiguous matrices on one device -> (bank (n, rows, cols) in `dtype`, bank_t (n, cols, rows) or None):
+    every matrix read once, both copies written by ONE launch (aum_cast_bank).  The device table of the n addresses is kept per address
+    tuple (parameters are updated in place: their addresses are stable across steps)."""
+    lib = lib or get()
+    p0 = params[0]
+    rows, cols = p0.shape
+    key = (p0.device, tuple(p.data_ptr() for p in params))
+    tab = _cast_tables.get(key)
+    if tab is None:
+        if len(_cast_tables) > 64:
+            _cast_tables.clear()
+        tab = _cast_tables[key] = torch.tensor(key[1], dtype=torch.int64, device=p0.device)
+    for p in params:
+        lib.check_tensor(p)
+    bank = torch.empty((len(params), rows, cols), dtype=dtype, device=p0.device)
+    bank_t = torch.empty((len(params), cols, rows), dtype=dtype, device=p0.device) if want_t else None
+    _chk(lib.c.aum_cast_bank(_ptr(tab), len(params), rows, cols, _ptr(bank), _ptr(bank_t), _DT[dtype], lib.stream(p0)), "aum_cast_bank")
+    return bank, bank_t
+
+
+def cast_bank_supported(params, dtype):
+    p0 = params[0]
+    return (dtype in (torch.bfloat16, torch.float16) and p0.dim() == 2 and p0.shape[0] % 8 == 0 and p0.shape[1] % 4 == 0
+            and all(p.dtype == torch.float32 and p.is_contiguous() and p.shape == p0.shape and p.device == p0.device and p.data_ptr() % 16 == 0
+                    for p in params))
 
 
 def hbm_copy(src, dst, lib=None):

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT_DIR = os.path.join(os.path.dirname(HERE), "aum_hip")
 OBJ_DIR = os.path.join(HERE, "_obj")
 SRC = os.path.join(HERE, "aum_hip.hip")
-DEPS = ["aum_hip.hip", "aum_api.inc", "wave.h", "scan_kernels.h", "scan_wg_kernels.h", "scan_half_kernels.h", "scan_row_kernels.h", "fbank_kernels.h", "frontend_kernels.h", "proj_kernels.h", "conv_rows_kernels.h", "conv_norm_kernels.h", "scan_tm_kernels.h", "conv_tm_kernels.h", "aum_api_tm.inc", "gemm.hip", "gemm_kernels.h", "gemm_ps_kernels.h", "gemm_args.h", "dtproj_kernels.h", "dtproj_args.h", "xdt_kernels.h", "xdt_args.h", "decode_args.h", "decode_kernels.h",
+DEPS = ["aum_hip.hip", "aum_api.inc", "wave.h", "scan_kernels.h", "scan_wg_kernels.h", "scan_half_kernels.h", "scan_row_kernels.h", "fbank_kernels.h", "frontend_kernels.h", "proj_kernels.h", "conv_rows_kernels.h", "conv_norm_kernels.h", "scan_tm_kernels.h", "conv_tm_kernels.h", "aum_api_tm.inc", "gemm.hip", "gemm_kernels.h", "gemm_ps_kernels.h", "gemm_args.h", "dtproj_kernels.h", "dtproj_args.h", "xdt_kernels.h", "xdt_args.h", "decode_args.h", "decode_kernels.h", "cast_args.h", "cast_kernels.h",
         os.path.join("..", "..", "include", "aum_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",

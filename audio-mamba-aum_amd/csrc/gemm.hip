@@ -6,6 +6,7 @@
 #include "dtproj_kernels.h"
 #include "xdt_kernels.h"
 #include "decode_kernels.h"
+#include "cast_kernels.h"
 
 // CU count of the CURRENT device (one process may drive several devices from several threads): a small per-device cache, filled with
 // relaxed atomics -- racing fillers write the same value
@@ -174,5 +175,19 @@ extern "C" int aum_selective_state_update(const AumStateUpdateArgs* p, void* str
     if (p->dtype == AUM_F32) hipLaunchKernelGGL(aumdec::k_state_update<float>, grid, block, 0, s, *p);
     else if (p->dtype == AUM_BF16) hipLaunchKernelGGL(aumdec::k_state_update<__bf16>, grid, block, 0, s, *p);
     else hipLaunchKernelGGL(aumdec::k_state_update<_Float16>, grid, block, 0, s, *p);
+    return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
+}
+
+extern "C" int aum_cast_bank(const uint64_t* src, int32_t n, int32_t rows, int32_t cols, void* bank, void* bank_t, int32_t dtype, void* stream) {
+    const int rc = aumc::cast_bank_check(src, bank, bank_t, n, rows, cols, dtype);
+    if (rc != AUM_OK) return rc;
+    aumc::CastBank a;
+    a.src = src, a.bank = bank, a.bank_t = bank_t, a.n = n, a.rows = rows, a.cols = cols;
+    a.tiles_r = (rows + aumc::CT - 1) / aumc::CT, a.tiles_c = (cols + aumc::CT - 1) / aumc::CT;
+    const unsigned grid = (unsigned)((int64_t)a.tiles_r * a.tiles_c * n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    if (dtype == AUM_BF16) hipLaunchKernelGGL(aumc::k_cast_bank<true>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(aumc::k_cast_bank<false>, dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? AUM_OK : AUM_E_LAUNCH;
 }

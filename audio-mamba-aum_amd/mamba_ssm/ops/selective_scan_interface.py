@@ -131,6 +131,7 @@ _A_OWNER = {}           # storage address of a cached A (neg_exp) -> the A_log p
 # other's entries (the result stays right -- a missing entry is a per-call cast -- but the saving is lost).  One forward per process at a
 # time is what the launcher and bench.py do.
 _STEP_CACHE = {}
+_CAST_HIP = _dbg_env("AUM_CAST_LIB", "0") != "1"         # AUM_DEBUG=1 AUM_CAST_LIB=1: the step cache's casts / transposes as torch copies (A/B)
 
 
 @contextlib.contextmanager
@@ -152,9 +153,12 @@ def step_cache(mixers, dtype):
     _DA_XA.clear()
     with torch.no_grad():
         for (want_t, shape, dev), ps in groups.items():
-            bank = torch.empty((len(ps),) + shape, dtype=dtype, device=dev)
-            torch._foreach_copy_(list(bank.unbind(0)), [p.detach() for p in ps])          # one multi-tensor cast
-            bank_t = bank.transpose(1, 2).contiguous() if want_t else None
+            if _CAST_HIP and dev.type == "cuda" and aum_hip.cast_bank_supported(ps, dtype):
+                bank, bank_t = aum_hip.cast_bank([p.detach() for p in ps], dtype, want_t)      # every matrix read once, both copies in one launch
+            else:
+                bank = torch.empty((len(ps),) + shape, dtype=dtype, device=dev)
+                torch._foreach_copy_(list(bank.unbind(0)), [p.detach() for p in ps])          # one multi-tensor cast
+                bank_t = bank.transpose(1, 2).contiguous() if want_t else None
             for i, p in enumerate(ps):
                 _STEP_CACHE[id(p)] = (dtype, bank[i], None if bank_t is None else bank_t[i])
                 mine.append(id(p))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AUM_ABI_VERSION 12  /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
+#define AUM_ABI_VERSION 13  /* 2: x_ck (chunk-entry state checkpoint) appended to the two scan argument structs;
                                3: x_lane (lane-entry state checkpoint of the L = 513 row kernels) appended after it;
                                4: aug / noise (per-clip augmentation in the log-mel kernel's epilogue) appended to AumFbankArgs;
                                5: aum_frontend_tokens_fwd (waveform -> token sequence in one launch);
@@ -41,7 +41,8 @@ extern "C" {
                                11: aum_sum_rows_multi (several partial sets summed in one launch);
                                12: experiment switches and entry points removed from the boundary (AUM_GEMM_STAGGERED / _PERSISTENT / _NO_COUNTED_WAIT /
                                    _NO_PREFETCH / _W4 / _RING, aum_gemm_tn_sk, aum_gemm_tn_sk_workspace_bytes, aum_scan_tm_bwd_matrix_sums); AUM_GEMM_PACED;
-                                   aum_sum_rows / aum_sum_rows_multi take any float address as destination */
+                                   aum_sum_rows / aum_sum_rows_multi take any float address as destination;
+                               13: aum_cast_bank (the 16-bit copies -- and transposes -- of a group of fp32 master weights in one launch) */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 
@@ -585,6 +586,15 @@ typedef struct AumSumJob {
     int32_t reserved;
 } AumSumJob;
 int aum_sum_rows_multi(const AumSumJob* jobs, int32_t njobs, void* stream);
+
+/* The 16-bit working copies of fp32 master weights (ABI 13).  Replaces: torch.autocast's per-call cast of F.linear's weight operand (the
+ * reference's in_proj / x_proj / dt_proj / out_proj under --mixed_precision, MS:185-189, SSI:467-468, 517) -- hoisted to one launch per
+ * group of equally shaped matrices at the top of a forward (ssi.step_cache).
+ *   src     DEVICE array of n addresses, each an fp32 (rows, cols) contiguous matrix
+ *   bank    (n, rows, cols) in `dtype` (AUM_BF16 / AUM_F16), round-to-nearest-even (what Tensor.to() does)
+ *   bank_t  (n, cols, rows): the transposes, or NULL
+ * rows % 8 == 0, cols % 4 == 0; bank / bank_t 16-byte aligned. */
+int aum_cast_bank(const uint64_t* src, int32_t n, int32_t rows, int32_t cols, void* bank, void* bank_t, int32_t dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -188,3 +188,26 @@ extern "C" int aum_selective_state_update(const AumStateUpdateArgs* p, void*) {
     if (p->dtype == AUM_F32) run(float{}); else if (p->dtype == AUM_BF16) run(aum::bf16_t{}); else run(aum::f16_t{});
     return AUM_OK;
 }
+
+// aum_cast_bank on host pointers: argument rules (cast_args.h) and one rounding per element
+#include "../../audio-mamba-aum_amd/csrc/cast_args.h"
+extern "C" int aum_cast_bank(const uint64_t* src, int32_t n, int32_t rows, int32_t cols, void* bank, void* bank_t, int32_t dtype, void*) {
+    const int rc = aumc::cast_bank_check(src, bank, bank_t, n, rows, cols, dtype);
+    if (rc != AUM_OK) return rc;
+    auto run = [&](auto tag) {
+        typedef decltype(tag) T;
+        T* b = static_cast<T*>(bank);
+        T* bt = static_cast<T*>(bank_t);
+        for (int m = 0; m < n; ++m) {
+            const float* a = reinterpret_cast<const float*>(src[m]);
+            for (int r = 0; r < rows; ++r)
+                for (int c = 0; c < cols; ++c) {
+                    aum::f32_to_elem(a[(int64_t)r * cols + c], b[((int64_t)m * rows + r) * cols + c]);
+                    if (bt) bt[((int64_t)m * cols + c) * rows + r] = b[((int64_t)m * rows + r) * cols + c];
+                }
+        }
+    };
+    if (dtype == AUM_BF16) run(aum::bf16_t{});
+    else run(aum::f16_t{});
+    return AUM_OK;
+}

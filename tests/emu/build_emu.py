@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "audio-mamba-aum_amd", "csrc")
 CXX = os.environ.get("AUM_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 DEPS = [os.path.join(HERE, "aum_emu.cpp")] + [os.path.join(CSRC, f) for f in
-        ("aum_api.inc", "wave.h", "scan_kernels.h", "scan_wg_kernels.h", "scan_half_kernels.h", "scan_row_kernels.h", "fbank_kernels.h", "frontend_kernels.h", "proj_kernels.h", "conv_rows_kernels.h", "conv_norm_kernels.h", "scan_tm_kernels.h", "conv_tm_kernels.h", "aum_api_tm.inc", "gemm_args.h", "dtproj_args.h", "xdt_args.h", "decode_args.h")] + [os.path.join(ROOT, "include", "aum_hip.h")]
+        ("aum_api.inc", "wave.h", "scan_kernels.h", "scan_wg_kernels.h", "scan_half_kernels.h", "scan_row_kernels.h", "fbank_kernels.h", "frontend_kernels.h", "proj_kernels.h", "conv_rows_kernels.h", "conv_norm_kernels.h", "scan_tm_kernels.h", "conv_tm_kernels.h", "aum_api_tm.inc", "gemm_args.h", "dtproj_args.h", "xdt_args.h", "decode_args.h", "cast_args.h")] + [os.path.join(ROOT, "include", "aum_hip.h")]
 
 
 def build(extra_flags=(), tag=""):

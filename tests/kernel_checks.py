@@ -608,3 +608,37 @@ def check_xdt(lib, dev, ntok, dim, rank, dtype, ncols=80):
     ref_d = x_dbl[:, :rank].double().cpu() @ wdt.double().cpu().t()
     ed = (delta.double().cpu() - ref_d).abs().max().item()
     assert delta.shape == (ntok, dim) and ed <= 1.01 * ulp * ref_d.abs().max().item(), ("delta", ntok, dim, rank, ed)
+
+
+def check_cast_bank(lib, device):
+    """aum_cast_bank (ABI 13): the 16-bit copies and transposes of a group of fp32 matrices, bit-equal to Tensor.to() / .t().contiguous()
+    (round-to-nearest-even), at the model's shapes (in / out / x / dt projections of AuM-Base: ragged 64-tiles in rows = 80 and cols = 48),
+    subnormal / huge / signed-zero / tie values included; argument rules"""
+    import ctypes
+    torch.manual_seed(0)
+    shapes = [(80, 1536), (1536, 48), (768, 1536), (3072, 768), (8, 4), (72, 68)] if device == "cuda" else [(80, 132), (136, 48), (8, 4)]
+    for dtype in (torch.bfloat16, torch.float16):
+        for shape in shapes:
+            n = 3 if shape[0] * shape[1] > 100000 else 5
+            ps = [torch.randn(shape, device=device) * (10.0 ** (i - 2)) for i in range(n)]
+            ps[0].view(-1)[:8] = torch.tensor([0.0, -0.0, 1e-41, -3e38, 1.0 + 2 ** -8, 1.0 + 3 * 2 ** -9, 65520.0, 6e-8], device=device)   # ties, range ends
+            assert aum_hip.cast_bank_supported(ps, dtype)
+            for want_t in (False, True):
+                bank, bank_t = aum_hip.cast_bank(ps, dtype, want_t, lib=lib)
+                assert bank.shape == (n,) + shape and bank.dtype == dtype and (bank_t is None) == (not want_t)
+                for i, p in enumerate(ps):
+                    ref = p.to(dtype)
+                    assert torch.equal(bank[i].view(torch.int16), ref.view(torch.int16)), (shape, dtype, i)
+                    if want_t:
+                        assert bank_t.shape == (n, shape[1], shape[0])
+                        assert torch.equal(bank_t[i].view(torch.int16), ref.t().contiguous().view(torch.int16)), (shape, dtype, i)
+    p = torch.randn(8, 4, device=device)
+    tab = torch.tensor([p.data_ptr()], dtype=torch.int64, device=device)
+    out = torch.empty(8, 4, dtype=torch.bfloat16, device=device)
+    st = lib.stream(p)
+    assert lib.c.aum_cast_bank(tab.data_ptr(), 1, 8, 4, out.data_ptr(), None, 1, st) == 0
+    assert lib.c.aum_cast_bank(tab.data_ptr(), 1, 4, 8, out.data_ptr(), None, 1, st) != 0         # rows % 8
+    assert lib.c.aum_cast_bank(tab.data_ptr(), 1, 8, 6, out.data_ptr(), None, 1, st) != 0         # cols % 4
+    assert lib.c.aum_cast_bank(tab.data_ptr(), 1, 8, 4, out.data_ptr(), None, 0, st) != 0         # fp32 is not a 16-bit type
+    assert lib.c.aum_cast_bank(None, 1, 8, 4, out.data_ptr(), None, 1, st) != 0
+    assert not aum_hip.cast_bank_supported([torch.randn(6, 4, device=device)], torch.bfloat16)

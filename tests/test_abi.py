@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(so_path):
     lib = ctypes.CDLL(so_path)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.aum_abi_version() == aum_hip.ABI_VERSION == 12
+    assert lib.aum_abi_version() == aum_hip.ABI_VERSION == 13
     assert lib.aum_scan_max_single_pass_len() == 576
     assert lib.aum_rmsnorm_bwd_partials(32832) == 4096
 

@@ -220,6 +220,10 @@ def test_sum_rows_multi_emu(emu):
     assert emu.c.aum_sum_rows_multi(ctypes.cast(jobs, ctypes.c_void_p), aum_hip.SUM_MAX_JOBS + 1, None) != 0
 
 
+def test_cast_bank_emu(emu):
+    KC.check_cast_bank(emu, "cpu")
+
+
 # ---- time-serial token-major kernels (scan_tm_kernels.h, conv_tm_kernels.h) ---------------------------------------------------
 def test_wave_sum_butterflies(emu):
     KC.check_wave_sum32(emu, "cpu")

@@ -336,6 +336,11 @@ def test_sum_rows_multi(lib):
             assert torch.equal(g, one.t().contiguous() if tc else one)
 
 
+@pytest.mark.gpu
+def test_cast_bank(lib):
+    KC.check_cast_bank(lib, "cuda")
+
+
 # ---- time-serial token-major kernels --------------------------------------------------------------------------------------------
 def test_wave_sum_butterflies(lib):
     """the masked-DPP / permlane-swap butterflies on the real lanes (the emulator states their result, not their data movement)"""
