@@ -189,7 +189,7 @@ EXPORTS = ["aum_gemm_tn", "aum_dtproj_tm_fwd", "aum_xdt_tm_fwd", "aum_proj_fwd",
            "aum_rmsnorm_bwd", "aum_rmsnorm_bwd_partials", "aum_selftest_wave_scan", "aum_hbm_copy", "aum_sum_rows", "aum_sum_rows_multi",
            "aum_scan_tm_fwd", "aum_scan_tm_nck", "aum_scan_tm_ckpt_rows", "aum_scan_tm_bwd", "aum_scan_tm_workspace_bytes", "aum_scan_tm_seg_fwd", "aum_scan_tm_seg_bwd",
            "aum_scan_tm_seg_carry_bytes", "aum_scan_tm_seg_workspace_bytes", "aum_selftest_wave_sum32",
-           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_gemm_wgrad", "aum_xdt_tm_bwd", "aum_causal_conv1d_update", "aum_selective_state_update", "aum_cast_bank"]
+           "aum_conv1d_tm_fwd", "aum_conv1d_tm_bwd", "aum_conv1d_tm_nparts", "aum_gemm_wgrad", "aum_xdt_tm_bwd", "aum_causal_conv1d_update", "aum_selective_state_update", "aum_cast_bank", "aum_rmsnorm_bwd_partial_rows"]
 
 
 class Lib:
@@ -1098,7 +1098,7 @@ def rmsnorm_bwd(dy, x_saved, weight, rstd, dresidual=None, has_residual=False, x
     weight = _f32c(weight)
     dx = torch.empty((rows, cols), dtype=x_dtype, device=dy.device)
     dres_in = torch.empty_like(x_saved) if (has_residual and x_dtype != x_saved.dtype) else None
-    n_part = int(lib.c.aum_rmsnorm_bwd_partials(rows))
+    n_part = int(lib.c.aum_rmsnorm_bwd_partial_rows(rows, cols, 2 if generic else 0))     # rows the kernel leaves sums in
     dwp = torch.empty((n_part, cols), dtype=torch.float32, device=dy.device)
     a = NormArgs()
     a.x, a.dy, a.dresidual_out, a.weight, a.rstd_in = map(_ptr, (x_saved, dy, dresidual, weight, rstd))

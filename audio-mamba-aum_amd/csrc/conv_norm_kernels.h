@@ -369,17 +369,26 @@ template <class TX, class TR, int NCH> AUM_DEV void rmsnorm_fwd_vec(const AumNor
     }
 }
 
-template <class TX, class TR, int NCH> AUM_DEV void rmsnorm_bwd_vec(const AumNormArgs& p, int wg, int n_partials) {
-    const int rows_per = (p.rows + n_partials - 1) / n_partials;
-    const int r0 = wg * rows_per;
-    const int r1 = r0 + rows_per < p.rows ? r0 + rows_per : p.rows;
+// The backward's waves: one per ~9 rows (aum_rmsnorm_bwd_partials(rows) of them), the weight-gradient terms of a wave's rows in registers.
+// Round 6: NORM_BWD_NW waves form a workgroup and add their sums through LDS in wave order before one row of partials leaves -- 512 partial
+// rows instead of 4 096 for the caller to add (one launch of aum_sum_rows instead of two: 12 -> 4 us per layer).
+constexpr int NORM_BWD_NW = 8;
+template <class TX, class TR, int NCH> AUM_DEV void rmsnorm_bwd_vec(const AumNormArgs& p, int wg, int n_waves, float* lds) {
+    // rows dealt evenly: 64 x 513 rows on 4 096 waves are 8 rows each and a ninth for the first 64 (ceil(rows / waves) = 9 rows each left
+    // 448 of the 4 096 waves without any)
+    const int base = p.rows / n_waves, rem = p.rows - base * n_waves;
     const vi lane = lane_id();
-    vf wv[NCH][8], dwacc[NCH][8];
+    vf dwacc[AUM_PER_WAVE(NORM_BWD_NW)][NCH][8];
+    AUM_FOR_EACH_WAVE(w, NORM_BWD_NW) {
+    const int sub = wg * NORM_BWD_NW + w;
+    const int r0 = sub < n_waves ? sub * base + (sub < rem ? sub : rem) : p.rows;
+    const int r1 = sub < n_waves ? r0 + base + (sub < rem ? 1 : 0) : p.rows;
+    vf wv[NCH][8];
     AUM_UNROLL
     for (int c = 0; c < NCH; ++c) {
         row_load8(p.weight, lane * 8 + c * 512, p.cols, wv[c]);
         AUM_UNROLL
-        for (int j = 0; j < 8; ++j) dwacc[c][j] = splat(0.f);
+        for (int j = 0; j < 8; ++j) dwacc[AUM_W(w)][c][j] = splat(0.f);
     }
     for (int row = r0; row < r1; ++row) {
         const TR* xp = (const TR*)p.x + (int64_t)row * p.row_stride_x;
@@ -401,7 +410,7 @@ template <class TX, class TR, int NCH> AUM_DEV void rmsnorm_bwd_vec(const AumNor
                 xh[c][j] = xh[c][j] * rstd;
                 wdy[c][j] = wv[c][j] * dyv[j];
                 c1 = vfma(xh[c][j], wdy[c][j], c1);
-                dwacc[c][j] = vfma(dyv[j], xh[c][j], dwacc[c][j]);
+                dwacc[AUM_W(w)][c][j] = vfma(dyv[j], xh[c][j], dwacc[AUM_W(w)][c][j]);
             }
         }
         const float cm = wave_sum(c1) / (float)p.cols;
@@ -421,9 +430,31 @@ template <class TX, class TR, int NCH> AUM_DEV void rmsnorm_bwd_vec(const AumNor
             if (drip) row_store8(drip, c0, p.cols, g);
         }
     }
-    float* out = p.dweight_partial + (int64_t)wg * p.cols;
-    AUM_UNROLL
-    for (int c = 0; c < NCH; ++c) row_store8(out, lane * 8 + c * 512, p.cols, dwacc[c]);
+    // waves 1 .. NW-1 hand their sums over: [wave - 1][chunk][j][lane] (a lane's 8 values 64 floats apart: conflict-free)
+    if (w > 0) {
+        float* mine = lds + (w - 1) * (NCH * 512);
+        AUM_UNROLL
+        for (int c = 0; c < NCH; ++c)
+            AUM_UNROLL
+            for (int j = 0; j < 8; ++j) lds_write(mine, lane + (c * 8 + j) * WAVE, dwacc[AUM_W(w)][c][j]);
+    }
+    }
+    AUM_WG_BARRIER();
+    AUM_FOR_EACH_WAVE(w, NORM_BWD_NW) {
+        if (w == 0) {
+            AUM_UNROLL
+            for (int c = 0; c < NCH; ++c)
+                AUM_UNROLL
+                for (int j = 0; j < 8; ++j) {
+                    vf acc = dwacc[AUM_W(0)][c][j];
+                    for (int o = 0; o < NORM_BWD_NW - 1; ++o) acc = acc + lds_read(lds + o * (NCH * 512), lane + (c * 8 + j) * WAVE);
+                    dwacc[AUM_W(0)][c][j] = acc;
+                }
+            float* out = p.dweight_partial + (int64_t)wg * p.cols;
+            AUM_UNROLL
+            for (int c = 0; c < NCH; ++c) row_store8(out, lane * 8 + c * 512, p.cols, dwacc[AUM_W(0)][c]);
+        }
+    }
 }
 
 // float4-style streaming copy used to measure the achievable HBM bandwidth on the box.

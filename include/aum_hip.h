@@ -42,7 +42,8 @@ extern "C" {
                                12: experiment switches and entry points removed from the boundary (AUM_GEMM_STAGGERED / _PERSISTENT / _NO_COUNTED_WAIT /
                                    _NO_PREFETCH / _W4 / _RING, aum_gemm_tn_sk, aum_gemm_tn_sk_workspace_bytes, aum_scan_tm_bwd_matrix_sums); AUM_GEMM_PACED;
                                    aum_sum_rows / aum_sum_rows_multi take any float address as destination;
-                               13: aum_cast_bank (the 16-bit copies -- and transposes -- of a group of fp32 master weights in one launch) */
+                               13: aum_cast_bank (the 16-bit copies -- and transposes -- of a group of fp32 master weights in one launch);
+                                   aum_rmsnorm_bwd_partial_rows (the vectorised norm backward leaves an eighth of the partial rows) */
 
 enum { AUM_F32 = 0, AUM_BF16 = 1, AUM_F16 = 2 };
 
@@ -204,6 +205,9 @@ typedef struct AumNormArgs {
 int aum_rmsnorm_fwd(const AumNormArgs* args, void* stream);
 int aum_rmsnorm_bwd(const AumNormArgs* args, void* stream);
 int aum_rmsnorm_bwd_partials(int32_t rows);
+/* ABI 13: rows of dweight_partial that hold sums after aum_rmsnorm_bwd (<= aum_rmsnorm_bwd_partials(rows), which remains the size to
+ * allocate): the vectorised kernels (cols <= 2048, no AUM_NORM_GENERIC) add eight waves' sums inside the workgroup, in wave order. */
+int aum_rmsnorm_bwd_partial_rows(int32_t rows, int32_t cols, uint32_t flags);
 
 /*
  * Log-mel filterbank frontend (replaces torchaudio.compliance.kaldi.fbank + pad + normalise on the CPU DataLoader

@@ -37,6 +37,8 @@ def test_every_declared_symbol_is_exported(so_path):
     assert lib.aum_abi_version() == aum_hip.ABI_VERSION == 13
     assert lib.aum_scan_max_single_pass_len() == 576
     assert lib.aum_rmsnorm_bwd_partials(32832) == 4096
+    assert lib.aum_rmsnorm_bwd_partial_rows(32832, 768, 0) == 512 and lib.aum_rmsnorm_bwd_partial_rows(32832, 768, 2) == 4096
+    assert lib.aum_rmsnorm_bwd_partial_rows(5, 768, 0) == 1 and lib.aum_rmsnorm_bwd_partial_rows(5, 4096, 0) == 5
 
 
 def test_struct_layouts_match_header(tmp_path):
