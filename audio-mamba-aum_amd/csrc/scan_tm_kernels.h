@@ -37,7 +37,9 @@ constexpr int SCANT_N = 16;                    // states per channel (Mamba's d_
 constexpr int SCANT_CK = AUM_SCAN_TM_CK;       // steps per checkpoint block
 constexpr int SCANT_G = SCANT_CK / 2;          // steps per prefetch group (two groups in flight, ping-pong)
 AUM_HOSTDEV constexpr int scant_nblocks(int len) { return (len + SCANT_CK - 1) / SCANT_CK; }
-AUM_HOSTDEV constexpr int scant_nck(int len) { return scant_nblocks(len) - 1; }        // the last block's exit state is never needed
+// (the last block's exit state is never needed; + SCANT_CK - 1: a direction whose iterations are numbered from scant_grid_shift() instead
+// of 0 can have one block more)
+AUM_HOSTDEV constexpr int scant_nck(int len) { return scant_nblocks(len + SCANT_CK - 1) - 1; }
 // Rows of one checkpoint (dwords per channel).  fp32 activations: the 16 states as they are.  16-bit activations: 8 rows of PAIRS in the
 // activations' own type (states 2j, 2j+1 in one dword) -- the training forward writes 0.8 GB of checkpoints per launch at the bench shape and was HBM-bound on it
 // (1.83 GB in 0.39 ms = 4.7 TB/s); rounding the entry state of an 8-step block to the precision its inputs already have halves that
@@ -530,6 +532,20 @@ AUM_DEV void scant_fwd_run(const AumScanTmFwdArgs& p, int b, int e0, int dir, in
 // iterations the forward-time wave (dir 0) and the reverse-time wave (dir 1) of a pair run before they meet: together they cover
 // every step exactly once
 AUM_HOSTDEV constexpr int scant_first_half(int len, int dir) { return dir == 0 ? len / 2 : len - len / 2; }
+// A direction pair's meeting point on a block boundary.  L = 513 is 256 + 257 iterations: numbered from 0, the reverse direction's boundary falls
+// one step into its block 32, which is then a ragged block in BOTH of its phases (1 + 7 live steps) next to the ragged last block -- and a
+// ragged block of the backward costs 1.25 whole ones (all exponentials, both butterflies, per-step conditions).  So a direction's iterations
+// are NUMBERED from io = (SCANT_CK - first_half % SCANT_CK) % SCANT_CK instead of 0 (the callers pass it0 + io, it1 + io and the time origin
+// moved by io steps; the runners see ordinary ranges): the meeting point is a multiple of SCANT_CK, the direction's first block holds its
+// first SCANT_CK - io steps, 2 ragged blocks per pair instead of 4.  No extra value lives in the kernels (k_scant_bwd is at 254 registers
+// with two more holding spilled scalars: one more scalar and it spills vector registers, whose scratch accesses break every counted vmcnt
+// wait -- profiles/r06_scan_grid_shift.txt; csrc/build.py refuses such a build).
+#ifndef AUM_SCANT_GRID_SHIFT
+#define AUM_SCANT_GRID_SHIFT 1      // 0: A/B build -- iterations numbered from 0 (as until round 6)
+#endif
+AUM_HOSTDEV constexpr int scant_grid_shift(int len, int dir) {
+    return AUM_SCANT_GRID_SHIFT && len >= 8 * SCANT_CK ? (SCANT_CK - scant_first_half(len, dir) % SCANT_CK) % SCANT_CK : 0;
+}
 
 // workgroup = four waves, one per SIMD: two channel groups x two directions (BIDIR: even wave = A forward time, odd wave = A_b reverse
 // time of the same group) or four channel groups.  Units (batch entry, channel group) are numbered batch-major.
@@ -561,19 +577,19 @@ AUM_DEV void scant_fwd(const AumScanTmFwdArgs& p, int wg, float* lds, unsigned l
         return;
     }
     AUM_FOR_EACH_WAVE(w, NW) {
-        const int unit = wg * UPW + (w >> 1), d = w & 1;
+        const int unit = wg * UPW + (w >> 1), d = w & 1, io = scant_grid_shift(L, d);
         if (unit < units) {
             AUM_UNROLL
             for (int j = 0; j < N / 2; ++j) x[AUM_W(w)][j] = spl2(splat(0.f));
-            scant_fwd_run<T, N, 1, SP, HAS_Z, HAS_PRE>(p, unit / gpb, (unit % gpb) * WAVE, d, d ? L - 1 : 0, d ? -1 : 1, 0, scant_first_half(L, d),
+            scant_fwd_run<T, N, 1, SP, HAS_Z, HAS_PRE>(p, unit / gpb, (unit % gpb) * WAVE, d, d ? L - 1 + io : -io, d ? -1 : 1, io, scant_first_half(L, d) + io,
                                                        d ? p.A_b : p.A, 2.f, x[AUM_W(w)], lds + w * scant_lds_wave_floats<T>(), tacc);
         }
     }
     AUM_WG_BARRIER();      // also orders this workgroup's partial stores before the other wave's loads of them (same CU, same L2)
     AUM_FOR_EACH_WAVE(w, NW) {
-        const int unit = wg * UPW + (w >> 1), d = w & 1;
+        const int unit = wg * UPW + (w >> 1), d = w & 1, io = scant_grid_shift(L, d);
         if (unit < units)
-            scant_fwd_run<T, N, 2, SP, HAS_Z, HAS_PRE>(p, unit / gpb, (unit % gpb) * WAVE, d, d ? L - 1 : 0, d ? -1 : 1, scant_first_half(L, d), L,
+            scant_fwd_run<T, N, 2, SP, HAS_Z, HAS_PRE>(p, unit / gpb, (unit % gpb) * WAVE, d, d ? L - 1 + io : -io, d ? -1 : 1, scant_first_half(L, d) + io, L + io,
                                                        d ? p.A_b : p.A, 2.f, x[AUM_W(w)], lds + w * scant_lds_wave_floats<T>(), tacc);
     }
 }
@@ -800,11 +816,12 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
             r.t_lo = tstep > 0 ? tok(base) : tok(base + SCANT_CK - 1);
             r.rowt = st_r;
         } else {
-            // loads: any real step of the direction (the forward sweep of a block re-runs its steps before the phase's first one);
-            // stores: the phase's own steps only
+            // loads: any real step of the direction (the forward sweep of a block re-runs its steps before the phase's first one -- in
+            // PHASE 1; the other phases start at the direction's first step: nothing exists in front of it0; none of the steps behind
+            // it1 - 1 is used); stores: the phase's own steps only
             const vi it = st_i + base;
             r.valid = (it >= it0) && (it < it1);
-            r.rowt = vmax_i(vmin_i(it, L - 1), 0) * tstep + t0;
+            r.rowt = vmax_i(vmin_i(it, it1 - 1), PHASE != 1 ? it0 : 0) * tstep + t0;
         }
         return r;
     };
@@ -904,6 +921,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
         const int base = blk * SCANT_CK;
         const int s_lo = FULL ? 0 : (it0 > base ? it0 - base : 0);                       // steps [s_lo, s_hi) of the block are this phase's
         const int s_hi = FULL ? SCANT_CK : (it1 < base + SCANT_CK ? it1 - base : SCANT_CK);
+        const int s_min = FULL || PHASE == 1 ? 0 : s_lo;       // a phase that starts at the direction's first step: no steps in front of it
         const bool more = blk > blk_lo;
         const bool cknext = more && blk - 1 > 0;        // the next block has a checkpoint to fetch (else its entry rows are zeroed)
         // the block's tensors (requested in the previous block's first lines) are older than that block's partials, the entry rows
@@ -1046,7 +1064,7 @@ AUM_DEV void scant_bwd_run(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int
                     pb[2 * s] = pb[2 * s + 1] = splat(0.f);
                 }
                 vf2 pcs = spl2(splat(0.f));
-                if (FULL || s < s_hi) {
+                if (FULL || (s >= s_min && s < s_hi)) {
                     w[s] = a[s] * x;
                     x = vfma2(US(s), mk2(qb[s][0], qb[s][1]), w[s]);
                     if (FULL || s >= s_lo) {
@@ -1260,7 +1278,7 @@ AUM_DEV void scant_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int wg,
     _Pragma("nounroll")
     for (int stage = 0; stage < 3; ++stage) {
         AUM_FOR_EACH_WAVE(w, NW) {
-            const int h = w >> 1, d = w & 1;
+            const int h = w >> 1, d = w & 1, io = scant_grid_shift(L, d);
             const int slot = h == 0 ? (stage == 2 ? 1 : 0) : (stage == 0 ? 1 : 2);       // X, Y, Z = 0, 1, 2
             const int phase = h == 0 ? (stage == 0 ? 1 : 2) : (stage == 2 ? 2 : 1);
             const int unit = wg * 3 + slot;
@@ -1270,7 +1288,7 @@ AUM_DEV void scant_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int wg,
                 const vi lane = lane_id();
                 if (phase == 1) {
                     init(w);
-                    scant_bwd_run<T, N, 1, SP, HAS_Z>(p, wo, b, e0, d, prt, d ? L - 1 : 0, d ? -1 : 1, scant_first_half(L, d), L, d ? p.A_b : p.A, 2.f,
+                    scant_bwd_run<T, N, 1, SP, HAS_Z>(p, wo, b, e0, d, prt, d ? L - 1 + io : -io, d ? -1 : 1, scant_first_half(L, d) + io, L + io, d ? p.A_b : p.A, 2.f,
                                                       hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)], dbias[AUM_W(w)],
                                                       lds + w * scant_bwd_lds_wave_floats<T>(), tacc);
                     if (slot == 1) {        // Y: phase 2 runs on the other two waves
@@ -1292,7 +1310,7 @@ AUM_DEV void scant_bwd(const AumScanTmBwdArgs& p, const ScanTBwdOut& wo, int wg,
                         dD[AUM_W(w)] = gload_u(cy + 2 * N * WAVE, lane);
                         dbias[AUM_W(w)] = gload_u(cy + (2 * N + 1) * WAVE, lane);
                     }
-                    scant_bwd_run<T, N, 2, SP, HAS_Z>(p, wo, b, e0, d, prt, d ? L - 1 : 0, d ? -1 : 1, 0, scant_first_half(L, d), d ? p.A_b : p.A, 2.f,
+                    scant_bwd_run<T, N, 2, SP, HAS_Z>(p, wo, b, e0, d, prt, d ? L - 1 + io : -io, d ? -1 : 1, io, scant_first_half(L, d) + io, d ? p.A_b : p.A, 2.f,
                                                       hh[AUM_W(w)], dA[AUM_W(w)], dD[AUM_W(w)], dbias[AUM_W(w)],
                                                       lds + w * scant_bwd_lds_wave_floats<T>(), tacc);
                     finish(w, unit, d);
