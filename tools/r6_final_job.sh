@@ -1,5 +1,5 @@
 # round 6: the end-of-round measurement run (tools/final_job.sh + the round's extras)
-export AUM_COMMIT=${AUM_COMMIT:-d3692fe}
+export AUM_COMMIT=${AUM_COMMIT:-71fb870}
 bash tools/final_job.sh
 export PYTHONPATH=$PWD/audio-mamba-aum_amd:$PYTHONPATH
 timeout 600 python tools/variants_bench.py --only bibi_ddp > gpurun_out/final/variants_bibi_ddp.log 2>&1; grep '"size"' gpurun_out/final/variants_bibi_ddp.log
