@@ -98,3 +98,25 @@ def test_product_library_refuses_host_tensors(so_path):
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(ImportError, match="no CPU fallback"):
         aum_hip.Lib(str(tmp_path / "libaum_hip.so"))
+
+
+def test_build_refuses_counted_wait_kernels_that_spill():
+    """csrc/build.py reads hipcc's kernel-resource-usage remarks: a kernel with hand-counted vmcnt waits (k_scant_*, k_gemm_tn*, k_gemm_wgrad*)
+    that uses scratch memory is reported (and the build raises); the channel-major kernels, which wait through the compiler, may spill"""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("aum_build", os.path.join(here, "..", "audio-mamba-aum_amd", "csrc", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    log = """
+x.hip:1:1: remark: Function Name: _ZN3aum11k_scant_bwdINS_6bf16_tELb1ELb1ELb1EEEv16AumScanTmBwdArgsNS_11ScanTBwdOutE [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     VGPRs: 256 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     ScratchSize [bytes/lane]: 16 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark: Function Name: _ZN3aum12k_scanwg_fwdIfLi9ELi0ELi0EEEv14AumScanFwdArgsi [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     ScratchSize [bytes/lane]: 224 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark: Function Name: _ZN4aumg12k_gemm_tn_psILb1EEEvNS_10GemmLaunchE [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]
+"""
+    assert b.spilling_kernels(log) == [("_ZN3aum11k_scant_bwdINS_6bf16_tELb1ELb1ELb1EEEv16AumScanTmBwdArgsNS_11ScanTBwdOutE", 16)]
+    assert b.spilling_kernels("") == []
