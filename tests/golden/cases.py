@@ -55,6 +55,8 @@ SCAN_TM_CASES = [
     ("tm_l40_plain", 2, 64, 40, 16, False, False, False, False),
     ("tm_l65_noz", 1, 64, 65, 16, False, True, True, True),
     ("tm_l66_nod", 1, 64, 66, 16, True, False, False, True),
+    ("tm_l75", 1, 64, 75, 16, True, True, True, True),            # meeting point 37 | 38: the directions' iterations numbered from 3 and 2 (scant_grid_shift)
+    ("tm_l100", 1, 64, 100, 16, True, True, True, True),          # 50 | 50: both from 6, one block more than ceil(100 / 8)
     ("tm_l130", 2, 128, 130, 16, True, True, True, True),
     ("tm_l513", 1, 64, 513, 16, True, True, True, True),
 ]
